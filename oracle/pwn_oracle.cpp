@@ -1,0 +1,867 @@
+/*
+ * pwn_oracle.cpp -- CPU ORACLE: restatement of the reference's PWN hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY (see pwn_oracle.h).  PARITY UNPINNED: the reference cannot be built
+ * here (Eigen3/OpenCV missing) and holds no golden vectors; this file follows the reference
+ * sources line by line and restates the Eigen routines they call.
+ *
+ * Arithmetic conventions (must be compiled with -ffp-contract=off, no -ffast-math):
+ *   - every inner product is evaluated left to right, ((a0*b0 + a1*b1) + a2*b2) + a3*b3, which is
+ *     what Eigen's fixed-size coefficient-based products do and what its SSE3 4-wide reductions
+ *     reduce to when the w-term is 0 (true for every dot on this path);
+ *   - no fused multiply-add;
+ *   - Eigen 3.2.x expression semantics where versions differ (noted at the site).
+ *
+ * References are relative to /root/reference/g2o_frontend/pwn_core/ unless a directory is given.
+ */
+#include "pwn_oracle.h"
+
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+namespace {
+
+struct V4 { float v[4]; };
+struct M3 { float m[9];  inline float& operator()(int r, int c) { return m[r + 3 * c]; } inline float operator()(int r, int c) const { return m[r + 3 * c]; } };
+struct M4 { float m[16]; inline float& operator()(int r, int c) { return m[r + 4 * c]; } inline float operator()(int r, int c) const { return m[r + 4 * c]; } };
+
+inline M4 m4_zero() { M4 r; std::memset(r.m, 0, sizeof(r.m)); return r; }
+inline M4 m4_identity() { M4 r = m4_zero(); r(0,0) = r(1,1) = r(2,2) = r(3,3) = 1.0f; return r; }
+inline M4 m4_load(const float* p) { M4 r; std::memcpy(r.m, p, sizeof(r.m)); return r; }
+
+/* Matrix4f * Vector4f, coefficient-based: sum over k ascending. */
+inline V4 m4_mul_v4(const M4& A, const V4& x) {
+  V4 r;
+  for (int i = 0; i < 4; ++i) {
+    float s = A(i,0) * x.v[0];
+    s = s + A(i,1) * x.v[1];
+    s = s + A(i,2) * x.v[2];
+    s = s + A(i,3) * x.v[3];
+    r.v[i] = s;
+  }
+  return r;
+}
+/* Isometry3f * 4-vector (Eigen transform_right_product_impl): top 3 rows = affine(3x4)*x, last row copied. */
+inline V4 iso_mul_v4(const M4& T, const V4& x) {
+  V4 r;
+  for (int i = 0; i < 3; ++i) {
+    float s = T(i,0) * x.v[0];
+    s = s + T(i,1) * x.v[1];
+    s = s + T(i,2) * x.v[2];
+    s = s + T(i,3) * x.v[3];
+    r.v[i] = s;
+  }
+  r.v[3] = x.v[3];
+  return r;
+}
+inline M4 m4_mul(const M4& A, const M4& B) {
+  M4 R;
+  for (int j = 0; j < 4; ++j)
+    for (int i = 0; i < 4; ++i) {
+      float s = A(i,0) * B(0,j);
+      s = s + A(i,1) * B(1,j);
+      s = s + A(i,2) * B(2,j);
+      s = s + A(i,3) * B(3,j);
+      R(i,j) = s;
+    }
+  return R;
+}
+inline M4 m4_transpose(const M4& A) { M4 R; for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) R(i,j) = A(j,i); return R; }
+inline M3 m3_mul(const M3& A, const M3& B) {
+  M3 R;
+  for (int j = 0; j < 3; ++j)
+    for (int i = 0; i < 3; ++i) {
+      float s = A(i,0) * B(0,j);
+      s = s + A(i,1) * B(1,j);
+      s = s + A(i,2) * B(2,j);
+      R(i,j) = s;
+    }
+  return R;
+}
+inline void m3_mul_v3(const M3& A, const float x[3], float r[3]) {
+  for (int i = 0; i < 3; ++i) {
+    float s = A(i,0) * x[0];
+    s = s + A(i,1) * x[1];
+    s = s + A(i,2) * x[2];
+    r[i] = s;
+  }
+}
+inline float dot4(const V4& a, const V4& b) {
+  float s = a.v[0] * b.v[0];
+  s = s + a.v[1] * b.v[1];
+  s = s + a.v[2] * b.v[2];
+  s = s + a.v[3] * b.v[3];
+  return s;
+}
+inline float sqnorm3(const float a[3]) { float s = a[0]*a[0]; s = s + a[1]*a[1]; s = s + a[2]*a[2]; return s; }
+
+inline M3 iso_linear(const M4& T) { M3 R; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R(i,j) = T(i,j); return R; }
+inline void iso_set(M4& T, const M3& R, const float t[3]) {
+  for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) T(i,j) = R(i,j); T(i,3) = t[i]; }
+  T(3,0) = 0.f; T(3,1) = 0.f; T(3,2) = 0.f; T(3,3) = 1.f;
+}
+inline void force_last_row(M4& T) { T(3,0) = 0.f; T(3,1) = 0.f; T(3,2) = 0.f; T(3,3) = 1.f; }
+
+/* Eigen Transform<float,3,Isometry>::inverse(Isometry): R' = R^T, t' = (-R^T) * t, makeAffine. */
+inline M4 iso_inverse(const M4& T) {
+  M3 Rt; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rt(i,j) = -T(j,i);
+  float t[3] = { T(0,3), T(1,3), T(2,3) }, ti[3];
+  m3_mul_v3(Rt, t, ti);
+  M3 R; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R(i,j) = T(j,i);
+  M4 r; iso_set(r, R, ti); return r;
+}
+/* Eigen transform_transform_product_impl (same affine mode): linear = Rl*Rr, translation = Rl*tr + tl. */
+inline M4 iso_mul(const M4& A, const M4& B) {
+  M3 Ra = iso_linear(A), Rb = iso_linear(B);
+  M3 R = m3_mul(Ra, Rb);
+  float tb[3] = { B(0,3), B(1,3), B(2,3) }, t[3];
+  m3_mul_v3(Ra, tb, t);
+  for (int i = 0; i < 3; ++i) t[i] = t[i] + A(i,3);
+  M4 r; iso_set(r, R, t); return r;
+}
+
+/* Eigen Matrix3f::inverse() (compute_inverse_size3_helper: cofactors, det along column 0). */
+inline float cofactor3(const M3& m, int i, int j) {
+  const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return m(i1,j1) * m(i2,j2) - m(i1,j2) * m(i2,j1);
+}
+inline M3 m3_inverse(const M3& m) {
+  float c0[3] = { cofactor3(m,0,0), cofactor3(m,1,0), cofactor3(m,2,0) };
+  float det = c0[0] * m(0,0); det = det + c0[1] * m(1,0); det = det + c0[2] * m(2,0);
+  const float invdet = 1.0f / det;
+  M3 r;
+  r(0,0) = c0[0] * invdet; r(0,1) = c0[1] * invdet; r(0,2) = c0[2] * invdet;
+  r(1,0) = cofactor3(m,0,1) * invdet; r(1,1) = cofactor3(m,1,1) * invdet; r(1,2) = cofactor3(m,2,1) * invdet;
+  r(2,0) = cofactor3(m,0,2) * invdet; r(2,1) = cofactor3(m,1,2) * invdet; r(2,2) = cofactor3(m,2,2) * invdet;
+  return r;
+}
+
+/* ---------------------------------------------------------------- bm_se3.h:9-52 ------------- */
+inline M3 quat2mat(const float q[3]) {           /* bm_se3.h:9-22 */
+  const float qx = q[0], qy = q[1], qz = q[2];
+  const float qw = std::sqrt(1.f - sqnorm3(q));
+  M3 R;
+  R(0,0) = qw*qw + qx*qx - qy*qy - qz*qz; R(0,1) = 2*(qx*qy - qw*qz);           R(0,2) = 2*(qx*qz + qw*qy);
+  R(1,0) = 2*(qx*qy + qz*qw);            R(1,1) = qw*qw - qx*qx + qy*qy - qz*qz; R(1,2) = 2*(qy*qz - qx*qw);
+  R(2,0) = 2*(qx*qz - qy*qw);            R(2,1) = 2*(qy*qz + qx*qw);            R(2,2) = qw*qw - qx*qx - qy*qy + qz*qz;
+  return R;
+}
+/* Eigen Quaternionf(Matrix3f) (quaternionbase_assign_impl<Other,3,3>) + normalize(); bm_se3.h:25-35 */
+inline void mat2quat(const M3& mat, float rq[3]) {
+  float q[4];  /* x y z w */
+  float t = (mat(0,0) + mat(1,1)) + mat(2,2);
+  if (t > 0.f) {
+    t = std::sqrt(t + 1.0f);
+    q[3] = 0.5f * t;
+    t = 0.5f / t;
+    q[0] = (mat(2,1) - mat(1,2)) * t;
+    q[1] = (mat(0,2) - mat(2,0)) * t;
+    q[2] = (mat(1,0) - mat(0,1)) * t;
+  } else {
+    int i = 0;
+    if (mat(1,1) > mat(0,0)) i = 1;
+    if (mat(2,2) > mat(i,i)) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = std::sqrt(mat(i,i) - mat(j,j) - mat(k,k) + 1.0f);
+    q[i] = 0.5f * t;
+    t = 0.5f / t;
+    q[3] = (mat(k,j) - mat(j,k)) * t;
+    q[j] = (mat(j,i) + mat(i,j)) * t;
+    q[k] = (mat(k,i) + mat(i,k)) * t;
+  }
+  /* normalize(): coeffs /= sqrt(squaredNorm), SSE3 hadd order (x2+y2)+(z2+w2) */
+  const float n2 = (q[0]*q[0] + q[1]*q[1]) + (q[2]*q[2] + q[3]*q[3]);
+  const float n = std::sqrt(n2);
+  for (int a = 0; a < 4; ++a) q[a] = q[a] / n;
+  rq[0] = q[0]; rq[1] = q[1]; rq[2] = q[2];
+  if (q[3] < 0.f) { rq[0] = -rq[0]; rq[1] = -rq[1]; rq[2] = -rq[2]; }
+}
+inline M4 v2t(const float x[6]) {                 /* bm_se3.h:37-43 */
+  M3 R = quat2mat(x + 3);
+  M4 T; iso_set(T, R, x); return T;
+}
+inline void t2v(const M4& T, float v[6]) {        /* bm_se3.h:45-52 */
+  v[0] = T(0,3); v[1] = T(1,3); v[2] = T(2,3);
+  mat2quat(iso_linear(T), v + 3);
+}
+/* bm_se3.h:54-66 skew on a 4-vector: S = -2 [v]x embedded in 4x4 */
+inline M4 skew4(const V4& v) {
+  const float tx = 2 * v.v[0], ty = 2 * v.v[1], tz = 2 * v.v[2];
+  M4 S = m4_zero();
+  S(0,1) = tz;  S(1,0) = -tz;
+  S(0,2) = -ty; S(2,0) = ty;
+  S(1,2) = tx;  S(2,1) = -tx;
+  return S;
+}
+
+/* --------------------------------------- Eigen SelfAdjointEigenSolver<Matrix3f>::computeDirect */
+inline void cross3(const float a[3], const float b[3], float r[3]) {
+  r[0] = a[1]*b[2] - a[2]*b[1];
+  r[1] = a[2]*b[0] - a[0]*b[2];
+  r[2] = a[0]*b[1] - a[1]*b[0];
+}
+inline void eig3_roots(const M3& m, float roots[3]) {
+  const float s_inv3 = 1.0f / 3.0f;
+  const float s_sqrt3 = std::sqrt(3.0f);
+  float c0 = m(0,0)*m(1,1)*m(2,2) + 2.0f*m(1,0)*m(2,0)*m(2,1) - m(0,0)*m(2,1)*m(2,1) - m(1,1)*m(2,0)*m(2,0) - m(2,2)*m(1,0)*m(1,0);
+  float c1 = m(0,0)*m(1,1) - m(1,0)*m(1,0) + m(0,0)*m(2,2) - m(2,0)*m(2,0) + m(1,1)*m(2,2) - m(2,1)*m(2,1);
+  float c2 = m(0,0) + m(1,1) + m(2,2);
+  float c2_over_3 = c2 * s_inv3;
+  float a_over_3 = (c2 * c2_over_3 - c1) * s_inv3;
+  a_over_3 = std::max(a_over_3, 0.0f);
+  float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
+  float q = a_over_3 * a_over_3 * a_over_3 - half_b * half_b;
+  q = std::max(q, 0.0f);
+  float rho = std::sqrt(a_over_3);
+  float theta = std::atan2(std::sqrt(q), half_b) * s_inv3;
+  float cos_theta = std::cos(theta);
+  float sin_theta = std::sin(theta);
+  roots[0] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+  roots[1] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+  roots[2] = c2_over_3 + 2.0f * rho * cos_theta;
+}
+inline void eig3_extract_kernel(const M3& mat, float res[3], float representative[3]) {
+  int i0 = 0; float best = std::fabs(mat(0,0));
+  if (std::fabs(mat(1,1)) > best) { best = std::fabs(mat(1,1)); i0 = 1; }
+  if (std::fabs(mat(2,2)) > best) { best = std::fabs(mat(2,2)); i0 = 2; }
+  for (int i = 0; i < 3; ++i) representative[i] = mat(i, i0);
+  float col1[3], col2[3], c0[3], c1[3];
+  for (int i = 0; i < 3; ++i) { col1[i] = mat(i, (i0 + 1) % 3); col2[i] = mat(i, (i0 + 2) % 3); }
+  cross3(representative, col1, c0);
+  cross3(representative, col2, c1);
+  const float n0 = sqnorm3(c0), n1 = sqnorm3(c1);
+  if (n0 > n1) { const float s = std::sqrt(n0); for (int i = 0; i < 3; ++i) res[i] = c0[i] / s; }
+  else         { const float s = std::sqrt(n1); for (int i = 0; i < 3; ++i) res[i] = c1[i] / s; }
+}
+/* A: symmetric, lower triangle read.  evals ascending, evecs column-major (column k = eigenvector k). */
+void eig3_direct(const M3& A, float evals[3], M3& evecs) {
+  const float eps = FLT_EPSILON;
+  const float shift = ((A(0,0) + A(1,1)) + A(2,2)) / 3.0f;
+  M3 S;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j <= i; ++j) { S(i,j) = A(i,j); S(j,i) = A(i,j); }
+  for (int i = 0; i < 3; ++i) S(i,i) = S(i,i) - shift;
+  float scale = 0.f;
+  for (int k = 0; k < 9; ++k) scale = std::max(scale, std::fabs(S.m[k]));
+  if (scale > 0.f) for (int k = 0; k < 9; ++k) S.m[k] = S.m[k] / scale;
+  eig3_roots(S, evals);
+  if ((evals[2] - evals[0]) <= eps) {
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) evecs(i,j) = (i == j) ? 1.f : 0.f;
+  } else {
+    M3 tmp = S;
+    float d0 = evals[2] - evals[1];
+    float d1 = evals[1] - evals[0];
+    int k = 0, l = 2;
+    if (d0 > d1) { std::swap(k, l); d0 = d1; }
+    float vk[3], vl[3];
+    for (int i = 0; i < 3; ++i) tmp(i,i) = tmp(i,i) - evals[k];
+    eig3_extract_kernel(tmp, vk, vl);
+    if (d0 <= 2 * eps * d1) {
+      float d = vk[0]*vl[0]; d = d + vk[1]*vl[1]; d = d + vk[2]*vl[2];
+      for (int i = 0; i < 3; ++i) vl[i] = vl[i] - d * vl[i];
+      const float n = std::sqrt(sqnorm3(vl));
+      for (int i = 0; i < 3; ++i) vl[i] = vl[i] / n;
+    } else {
+      tmp = S;
+      for (int i = 0; i < 3; ++i) tmp(i,i) = tmp(i,i) - evals[l];
+      float dummy[3];
+      eig3_extract_kernel(tmp, vl, dummy);
+    }
+    for (int i = 0; i < 3; ++i) { evecs(i,k) = vk[i]; evecs(i,l) = vl[i]; }
+    float v2[3] = { evecs(0,2), evecs(1,2), evecs(2,2) }, v0[3] = { evecs(0,0), evecs(1,0), evecs(2,0) }, v1[3];
+    cross3(v2, v0, v1);
+    const float z = sqnorm3(v1);
+    if (z > 0.f) { const float n = std::sqrt(z); for (int i = 0; i < 3; ++i) v1[i] = v1[i] / n; }
+    for (int i = 0; i < 3; ++i) evecs(i,1) = v1[i];
+  }
+  for (int i = 0; i < 3; ++i) { evals[i] = evals[i] * scale; evals[i] = evals[i] + shift; }
+}
+
+/* ----------------------------------------------------- Eigen LDLT<Matrix6f>::solve (fp32) ---- */
+void ldlt_solve6(const float Hin[36], const float bin[6], float x[6]) {
+  const int n = 6;
+  float A[36]; std::memcpy(A, Hin, sizeof(A));
+  auto a = [&](int r, int c) -> float& { return A[r + n * c]; };
+  int tr[6]; float temp[6];
+  float cutoff = 0.f;
+  for (int k = 0; k < n; ++k) {
+    int p = k; float big = std::fabs(a(k,k));
+    for (int i = k + 1; i < n; ++i) if (std::fabs(a(i,i)) > big) { big = std::fabs(a(i,i)); p = i; }
+    if (k == 0) cutoff = std::fabs(FLT_EPSILON * big);
+    if (big < cutoff) { for (int i = k; i < n; ++i) tr[i] = i; break; }
+    tr[k] = p;
+    if (k != p) {
+      const int s = n - p - 1;
+      for (int j = 0; j < k; ++j) std::swap(a(k,j), a(p,j));
+      for (int i = 0; i < s; ++i) std::swap(a(p + 1 + i, k), a(p + 1 + i, p));
+      std::swap(a(k,k), a(p,p));
+      for (int i = k + 1; i < p; ++i) { float t = a(i,k); a(i,k) = a(p,i); a(p,i) = t; }
+    }
+    const int rs = n - k - 1;
+    if (k > 0) {
+      for (int j = 0; j < k; ++j) temp[j] = a(j,j) * a(k,j);
+      float d = 0.f;
+      for (int j = 0; j < k; ++j) { if (j == 0) d = a(k,0) * temp[0]; else d = d + a(k,j) * temp[j]; }
+      a(k,k) = a(k,k) - d;
+      for (int i = 0; i < rs; ++i) {
+        float s2 = 0.f;
+        for (int j = 0; j < k; ++j) { if (j == 0) s2 = a(k+1+i,0) * temp[0]; else s2 = s2 + a(k+1+i,j) * temp[j]; }
+        a(k+1+i,k) = a(k+1+i,k) - s2;
+      }
+    }
+    if (rs > 0 && std::fabs(a(k,k)) > cutoff)
+      for (int i = 0; i < rs; ++i) a(k+1+i,k) = a(k+1+i,k) / a(k,k);
+  }
+  float d[6]; std::memcpy(d, bin, sizeof(d));
+  for (int k = 0; k < n; ++k) if (tr[k] != k) std::swap(d[k], d[tr[k]]);
+  for (int i = 0; i < n; ++i) {                       /* L^-1 (unit lower) */
+    float s = 0.f;
+    for (int j = 0; j < i; ++j) { if (j == 0) s = a(i,0) * d[0]; else s = s + a(i,j) * d[j]; }
+    if (i > 0) d[i] = d[i] - s;
+  }
+  float dmax = 0.f; for (int i = 0; i < n; ++i) dmax = std::max(dmax, std::fabs(a(i,i)));
+  const float tol = std::max(dmax * FLT_EPSILON, 1.0f / FLT_MAX);
+  for (int i = 0; i < n; ++i) { if (std::fabs(a(i,i)) > tol) d[i] = d[i] / a(i,i); else d[i] = 0.f; }
+  for (int i = n - 1; i >= 0; --i) {                  /* L^-T */
+    float s = 0.f; bool first = true;
+    for (int j = i + 1; j < n; ++j) { if (first) { s = a(j,i) * d[j]; first = false; } else s = s + a(j,i) * d[j]; }
+    if (!first) d[i] = d[i] - s;
+  }
+  for (int k = n - 1; k >= 0; --k) if (tr[k] != k) std::swap(d[k], d[tr[k]]);
+  std::memcpy(x, d, sizeof(d));
+}
+
+/* ------------------------------------------------------------------- stats.h:13-121 --------- */
+struct Stats {
+  M4 m; float eig[3]; int n; mutable bool curvatureComputed; mutable float curv;
+  Stats() { n = 0; m = m4_identity(); eig[0] = eig[1] = eig[2] = 0.f; curvatureComputed = false; curv = 1.0f; }  /* stats.h:21-27 */
+  float curvature() const {                                                                  /* stats.h:98-103 */
+    if (!curvatureComputed) curv = (float)((double)eig[0] / ((double)(eig[0] + eig[1] + eig[2]) + 1e-9));
+    curvatureComputed = true;
+    return curv;
+  }
+};
+
+/* pinholepointprojector.cpp:17-31 */
+struct Projector {
+  M3 K, iK; M4 T, KRt, iKRt; float minD, maxD;
+  void update() {
+    M4 t = iso_inverse(T);
+    force_last_row(t);
+    iK = m3_inverse(K);
+    M3 KR = m3_mul(K, iso_linear(t));
+    float tt[3] = { t(0,3), t(1,3), t(2,3) }, Kt[3];
+    m3_mul_v3(K, tt, Kt);
+    M3 iKR = m3_mul(iso_linear(T), iK);
+    KRt = m4_identity(); iKRt = m4_identity();
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) { KRt(i,j) = KR(i,j); iKRt(i,j) = iKR(i,j); } KRt(i,3) = Kt[i]; iKRt(i,3) = T(i,3); }
+  }
+  /* pinholepointprojector.h:224-233 */
+  inline bool project(int& x, int& y, float& d, const V4& p) const {
+    V4 ip = m4_mul_v4(KRt, p);
+    d = ip.v[2];
+    if (d < minD || d > maxD) return false;
+    const float inv = 1.0f / d;
+    x = (int)std::round(ip.v[0] * inv);
+    y = (int)std::round(ip.v[1] * inv);
+    return true;
+  }
+  /* pinholepointprojector.h:246-251 */
+  inline bool unProject(V4& p, int x, int y, float d) const {
+    if (d < minD || d > maxD) return false;
+    V4 in = { { x * d, y * d, d, 1.0f } };
+    p = m4_mul_v4(iKRt, in);
+    p.v[3] = 1.0f;           /* Point::operator= forces w (homogeneousvector4f.h:56-60) */
+    return true;
+  }
+  /* pinholepointprojector.h:264-274 */
+  inline int projectInterval(float d, float worldRadius) const {
+    if (d < minD || d > maxD) return -1;
+    float v[3] = { worldRadius, worldRadius, 0.f }, p[3];
+    m3_mul_v3(K, v, p);
+    const float inv = 1.0f / d;
+    p[0] = p[0] * inv; p[1] = p[1] * inv;
+    if (p[0] > p[1]) return (int)p[0];
+    return (int)p[1];
+  }
+};
+
+}  // namespace
+
+struct orc_cloud {
+  std::vector<V4> points, normals;
+  std::vector<Stats> stats;
+  std::vector<M4> omegaP, omegaN;
+};
+
+namespace {
+
+/* ----------------------------------------- pointaccumulator.h / pointintegralimage.cpp ------ */
+/* 10 unique channels of (sum, squaredSum): x y z n xx xy xz yy yz zz.  The other 10 entries of the
+ * reference's 4+16 floats are bitwise duplicates (p_i*p_j commutes, x*1 == x). */
+enum { CH = 10 };
+struct Acc { float c[CH]; };
+
+void integral_image(const int* index, const V4* points, int rows, int cols, std::vector<Acc>& I) {
+  I.assign((size_t)rows * cols, Acc{ {0,0,0,0,0,0,0,0,0,0} });
+  /* pointintegralimage.cpp:16-27: accumulator(r=img x, c=img y) += point */
+#pragma omp parallel for
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) {
+      const int idx = index[(size_t)r * cols + c];
+      if (idx < 0) continue;
+      const float* p = points[idx].v;
+      Acc& a = I[(size_t)r * cols + c];
+      a.c[0] += p[0]; a.c[1] += p[1]; a.c[2] += p[2]; a.c[3] += p[3];
+      a.c[4] += p[0]*p[0]; a.c[5] += p[0]*p[1]; a.c[6] += p[0]*p[2];
+      a.c[7] += p[1]*p[1]; a.c[8] += p[1]*p[2]; a.c[9] += p[2]*p[2];
+    }
+  /* :30-35 prefix along image x inside every image row, sequential */
+#pragma omp parallel for
+  for (int r = 0; r < rows; ++r)
+    for (int c = 1; c < cols; ++c) {
+      Acc& a = I[(size_t)r * cols + c]; const Acc& b = I[(size_t)r * cols + c - 1];
+      for (int k = 0; k < CH; ++k) a.c[k] = a.c[k] + b.c[k];
+    }
+  /* :38-43 prefix along image y inside every image column, sequential */
+#pragma omp parallel for
+  for (int c = 0; c < cols; ++c)
+    for (int r = 1; r < rows; ++r) {
+      Acc& a = I[(size_t)r * cols + c]; const Acc& b = I[(size_t)(r - 1) * cols + c];
+      for (int k = 0; k < CH; ++k) a.c[k] = a.c[k] + b.c[k];
+    }
+}
+inline int clampi(int v, int lo, int hi) { v = (v < lo) ? lo : v; v = (v > hi) ? hi : v; return v; }
+/* pointintegralimage.cpp:53-66; x indexes image columns, y image rows */
+inline Acc get_region(const std::vector<Acc>& I, int rows, int cols, int xmin, int xmax, int ymin, int ymax) {
+  xmin = clampi(xmin - 1, 0, cols - 1);
+  xmax = clampi(xmax - 1, 0, cols - 1);
+  ymin = clampi(ymin - 1, 0, rows - 1);
+  ymax = clampi(ymax - 1, 0, rows - 1);
+  Acc pa = I[(size_t)ymax * cols + xmax];
+  const Acc& b = I[(size_t)ymin * cols + xmin];
+  const Acc& c = I[(size_t)ymax * cols + xmin];
+  const Acc& d = I[(size_t)ymin * cols + xmax];
+  for (int k = 0; k < CH; ++k) { pa.c[k] = pa.c[k] + b.c[k]; pa.c[k] = pa.c[k] - c.c[k]; pa.c[k] = pa.c[k] - d.c[k]; }
+  return pa;
+}
+
+Projector make_projector(const float K[9], const float T[16], float minD, float maxD) {
+  Projector pr; std::memcpy(pr.K.m, K, sizeof(pr.K.m)); pr.T = m4_load(T); pr.minD = minD; pr.maxD = maxD; pr.update(); return pr;
+}
+
+/* statscalculatorintegralimage.cpp:14-82 */
+void stats_compute(const orc_converter_params* P, const int* index, const int* interval, int rows, int cols,
+                   const std::vector<V4>& points, std::vector<V4>& normals, std::vector<Stats>& stats) {
+  const size_t M = points.size();
+  normals.assign(M, V4{ {0,0,0,0} });
+  stats.assign(M, Stats());
+  std::vector<Acc> I;
+  integral_image(index, points.data(), rows, cols, I);
+#pragma omp parallel for schedule(dynamic, 4)
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) {
+      const int idx = index[(size_t)r * cols + c], itv = interval[(size_t)r * cols + c];
+      if (idx < 0 || itv < 0) continue;
+      int rad = itv;
+      if (rad < P->min_image_radius) rad = P->min_image_radius;
+      if (rad > P->max_image_radius) rad = P->max_image_radius;
+      const Acc acc = get_region(I, rows, cols, c - rad, c + rad, r - rad, r + rad);
+      const int n = (int)acc.c[3];
+      if (n < P->min_points) continue;
+      /* pointaccumulator.h:66-86 */
+      float d = acc.c[3];
+      M3 cov; float mean[3] = {0,0,0};
+      if (d) {
+        d = 1.0f / d;
+        mean[0] = acc.c[0] * d; mean[1] = acc.c[1] * d; mean[2] = acc.c[2] * d;
+        const float sq[3][3] = { { acc.c[4], acc.c[5], acc.c[6] }, { acc.c[5], acc.c[7], acc.c[8] }, { acc.c[6], acc.c[8], acc.c[9] } };
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) cov(i,j) = sq[i][j] * d - mean[i] * mean[j];
+      } else { for (int k = 0; k < 9; ++k) cov.m[k] = 0.f; }
+      float ev[3]; M3 U;
+      eig3_direct(cov, ev, U);
+      Stats& s = stats[idx];
+      s.m = m4_zero();
+      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) s.m(i,j) = U(i,j);
+      s.m(0,3) = mean[0]; s.m(1,3) = mean[1]; s.m(2,3) = mean[2]; s.m(3,3) = 1.0f;
+      if (ev[0] < 0.0f) ev[0] = 0.0f;
+      s.eig[0] = ev[0]; s.eig[1] = ev[1]; s.eig[2] = ev[2];
+      s.n = n;
+      V4 nrm = { { s.m(0,0), s.m(1,0), s.m(2,0), 0.f } };
+      if (s.curvature() < P->stats_curvature_threshold) {
+        if (dot4(nrm, points[idx]) > 0) { nrm.v[0] = -nrm.v[0]; nrm.v[1] = -nrm.v[1]; nrm.v[2] = -nrm.v[2]; nrm.v[3] = 0.f; }
+      } else { nrm = V4{ {0,0,0,0} }; }
+      normals[idx] = nrm;
+    }
+}
+
+inline M4 diag4(const float d[3]) { M4 r = m4_zero(); r(0,0) = d[0]; r(1,1) = d[1]; r(2,2) = d[2]; return r; }
+inline void info_zero_border(M4& m) { for (int i = 0; i < 4; ++i) { m(3,i) = 0.f; m(i,3) = 0.f; } }
+
+/* informationmatrixcalculator.cpp:9-58 */
+void info_compute(const orc_converter_params* P, const std::vector<Stats>& stats, const std::vector<V4>& normals,
+                  std::vector<M4>& omegaP, std::vector<M4>& omegaN) {
+  const size_t M = stats.size();
+  omegaP.assign(M, m4_zero()); omegaN.assign(M, m4_zero());
+  const M4 flatP = diag4(P->point_flat_diag), flatN = diag4(P->normal_flat_diag), nonflatN = diag4(P->normal_nonflat_diag);
+#pragma omp parallel for
+  for (long i = 0; i < (long)M; ++i) {
+    const Stats& s = stats[i];
+    const V4& nm = normals[i];
+    const float sq = dot4(nm, nm);
+    if (sq > 0) {
+      M4 U = m4_zero();
+      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) U(a,b) = s.m(a,b);
+      M4 D;
+      if (s.curvature() < P->point_info_curvature_threshold) D = flatP;
+      else { M4 nf = diag4(P->point_nonflat_diag); nf(0,0) = 1.0f / s.eig[0]; nf(1,1) = 1.0f / s.eig[1]; nf(2,2) = 1.0f / s.eig[2]; D = nf; }
+      M4 O = m4_mul(m4_mul(U, D), m4_transpose(U));
+      info_zero_border(O);
+      omegaP[i] = O;
+      omegaN[i] = (s.curvature() < P->normal_info_curvature_threshold) ? flatN : nonflatN;
+    }
+  }
+}
+
+/* cloud.cpp:173-186 */
+void cloud_transform_in_place(orc_cloud* c, const float Tin[16]) {
+  M4 m = m4_load(Tin);
+  force_last_row(m);
+  const M4 I = m4_identity();
+  bool ident = true; for (int k = 0; k < 16; ++k) ident = ident && (m.m[k] == I.m[k]);   /* cloud.cpp:176 */
+  if (ident) return;
+  const size_t M = c->points.size();
+  for (size_t i = 0; i < M; ++i) { V4 p = m4_mul_v4(m, c->points[i]); p.v[3] = 1.0f; c->points[i] = p; }
+  for (size_t i = 0; i < c->normals.size(); ++i) { V4 n = m4_mul_v4(m, c->normals[i]); n.v[3] = 0.0f; c->normals[i] = n; }
+  for (size_t i = 0; i < c->stats.size(); ++i) c->stats[i].m = m4_mul(m, c->stats[i].m);   /* stats.h:125-131 */
+  M4 T = m; for (int i = 0; i < 4; ++i) { T(3,i) = 0.f; T(i,3) = 0.f; }
+  const M4 Tt = m4_transpose(T);
+  for (size_t i = 0; i < c->omegaP.size(); ++i) { M4 o = m4_mul(m4_mul(T, c->omegaP[i]), Tt); info_zero_border(o); c->omegaP[i] = o; }   /* informationmatrix.h:111-121 */
+  for (size_t i = 0; i < c->omegaN.size(); ++i) { M4 o = m4_mul(m4_mul(T, c->omegaN[i]), Tt); info_zero_border(o); c->omegaN[i] = o; }
+}
+
+void project_points(const Projector& pr, int rows, int cols, const V4* points, int n, int* indexImage, float* depthImage) {
+  /* pinholepointprojector.cpp:33-66 */
+  const size_t N = (size_t)rows * cols;
+  for (size_t i = 0; i < N; ++i) { depthImage[i] = FLT_MAX; indexImage[i] = -1; }
+  for (int i = 0; i < n; ++i) {
+    int x, y; float d;
+    if (!pr.project(x, y, d, points[i]) || d < pr.minD || d > pr.maxD || x < 0 || x >= cols || y < 0 || y >= rows) continue;
+    float& od = depthImage[(size_t)y * cols + x];
+    int& oi = indexImage[(size_t)y * cols + x];
+    if (!od || od > d) { od = d; oi = i; }
+  }
+}
+
+int correspondences(const orc_aligner_params* P, const orc_cloud* ref, const orc_cloud* cur,
+                    const int* refIndex, const int* curIndex, M4 T, int* corr, int* Kout) {
+  /* correspondencefinder.cpp:20-118, numThreads == 1 */
+  force_last_row(T);
+  const float squaredThreshold = P->inlier_distance_threshold * P->inlier_distance_threshold;
+  const float minCurvatureRatio = 1.0f / P->inlier_curvature_ratio_threshold;
+  const float maxCurvatureRatio = P->inlier_curvature_ratio_threshold;
+  int C = 0, K = 0;
+  const int rows = P->rows, cols = P->cols;
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) {
+      const int ri = refIndex[(size_t)r * cols + c], ci = curIndex[(size_t)r * cols + c];
+      if (ri < 0 || ci < 0) continue;
+      ++K;
+      const V4& cn = cur->normals[ci]; const V4& rn0 = ref->normals[ri];
+      const V4& cp = cur->points[ci];  const V4& rp0 = ref->points[ri];
+      if (dot4(cn, cn) == 0.0f || dot4(rn0, rn0) == 0.0f) continue;
+      V4 rp = iso_mul_v4(T, rp0); rp.v[3] = 1.0f;
+      V4 rn = iso_mul_v4(T, rn0); rn.v[3] = 0.0f;
+      if (dot4(cn, rn) < P->inlier_normal_angular_threshold) continue;
+      V4 dd = { { cp.v[0] - rp.v[0], cp.v[1] - rp.v[1], cp.v[2] - rp.v[2], cp.v[3] - rp.v[3] } };
+      if (dot4(dd, dd) > squaredThreshold) continue;
+      float rc = ref->stats[ri].curvature(), cc = cur->stats[ci].curvature();
+      if (rc < P->flat_curvature_threshold) rc = P->flat_curvature_threshold;
+      if (cc < P->flat_curvature_threshold) cc = P->flat_curvature_threshold;
+      const float ratio = (float)(((double)rc + 1e-5) / ((double)cc + 1e-5));
+      if (ratio < minCurvatureRatio || ratio > maxCurvatureRatio) continue;
+      corr[2 * C] = ri; corr[2 * C + 1] = ci; ++C;
+    }
+  if (Kout) *Kout = K;
+  return C;
+}
+
+template <typename ACC>
+void linearize_impl(const orc_aligner_params* P, const orc_cloud* ref, const orc_cloud* cur, const int* corr, int C, M4 T,
+                    float* Hout, float* bout, float* chi2, double* chi2d, int* inliersOut) {
+  /* linearizer.cpp:17-115, numThreads == 1 */
+  force_last_row(T);
+  ACC Htt[16], Htr[16], Hrr[16], bt[4], br[4], error = 0; double errd = 0.0; int inliers = 0;
+  for (int k = 0; k < 16; ++k) Htt[k] = Htr[k] = Hrr[k] = 0;
+  for (int k = 0; k < 4; ++k) bt[k] = br[k] = 0;
+  for (int i = 0; i < C; ++i) {
+    const int ri = corr[2 * i], ci = corr[2 * i + 1];
+    V4 rp = iso_mul_v4(T, ref->points[ri]);  rp.v[3] = 1.0f;
+    V4 rn = iso_mul_v4(T, ref->normals[ri]); rn.v[3] = 0.0f;
+    const V4& cp = cur->points[ci]; const V4& cn = cur->normals[ci];
+    const M4& oP = cur->omegaP[ci]; const M4& oN = cur->omegaN[ci];
+    V4 pe = { { rp.v[0] - cp.v[0], rp.v[1] - cp.v[1], rp.v[2] - cp.v[2], rp.v[3] - cp.v[3] } };
+    V4 ne = { { rn.v[0] - cn.v[0], rn.v[1] - cn.v[1], rn.v[2] - cn.v[2], rn.v[3] - cn.v[3] } };
+    const V4 ep = m4_mul_v4(oP, pe), en = m4_mul_v4(oN, ne);
+    float localError = dot4(pe, ep) + dot4(ne, en);
+    float kscale = 1;
+    if (localError > P->inlier_max_chi2) {
+      if (P->robust_kernel) kscale = std::sqrt(P->inlier_max_chi2 / localError);
+      else continue;
+    }
+    ++inliers;
+    const float term = kscale * localError;
+    error = error + (ACC)term; errd += (double)term;
+    const M4 Sp = skew4(rp), Sn = skew4(rn);
+    const M4 oPSp = m4_mul(oP, Sp);
+    const M4 A = m4_mul(m4_mul(m4_transpose(Sp), oP), Sp);
+    const M4 B = m4_mul(m4_mul(m4_transpose(Sn), oN), Sn);
+    const V4 spe = m4_mul_v4(m4_transpose(Sp), ep), sne = m4_mul_v4(m4_transpose(Sn), en);
+    for (int k = 0; k < 16; ++k) {
+      Htt[k] = Htt[k] + (ACC)oP.m[k];
+      Htr[k] = Htr[k] + (ACC)oPSp.m[k];
+      Hrr[k] = Hrr[k] + (ACC)(A.m[k] + B.m[k]);        /* Eigen 3.2: Hrr += (tmpA + tmpB) */
+    }
+    for (int k = 0; k < 4; ++k) {
+      bt[k] = bt[k] + (ACC)(kscale * ep.v[k]);
+      br[k] = br[k] + (ACC)(kscale * (spe.v[k] + sne.v[k]));
+    }
+  }
+  /* linearizer.cpp:109-114 */
+  float H[36];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
+    H[i + 6 * j] = (float)Htt[i + 4 * j];
+    H[i + 6 * (j + 3)] = (float)Htr[i + 4 * j];
+    H[(i + 3) + 6 * (j + 3)] = (float)Hrr[i + 4 * j];
+  }
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) H[(i + 3) + 6 * j] = H[j + 6 * (i + 3)];
+  std::memcpy(Hout, H, sizeof(H));
+  for (int i = 0; i < 3; ++i) { bout[i] = (float)bt[i]; bout[i + 3] = (float)br[i]; }
+  *chi2 = (float)error; if (chi2d) *chi2d = errd; *inliersOut = inliers;
+}
+
+}  // namespace
+
+extern "C" {
+
+void orc_default_converter_params(orc_converter_params* p) {
+  std::memset(p, 0, sizeof(*p));
+  const float K[9] = { 525.f, 0.f, 0.f, 0.f, 525.f, 0.f, 319.5f, 239.5f, 1.f };   /* pwn_simple_aligner.cpp:226-229 */
+  std::memcpy(p->K, K, sizeof(K));
+  p->min_distance = 0.01f; p->max_distance = 6.0f;
+  p->world_radius = 0.1f; p->min_image_radius = 10; p->max_image_radius = 30; p->min_points = 50;
+  p->stats_curvature_threshold = 0.02f;
+  p->point_info_curvature_threshold = 0.02f; p->normal_info_curvature_threshold = 0.02f;
+  p->point_flat_diag[0] = 1000.f; p->point_flat_diag[1] = 1.f; p->point_flat_diag[2] = 1.f;
+  p->point_nonflat_diag[0] = p->point_nonflat_diag[1] = p->point_nonflat_diag[2] = 1.f;
+  p->normal_flat_diag[0] = p->normal_flat_diag[1] = p->normal_flat_diag[2] = 100.f;
+  p->normal_nonflat_diag[0] = p->normal_nonflat_diag[1] = p->normal_nonflat_diag[2] = 1.f;
+  const M4 I = m4_identity(); std::memcpy(p->sensor_offset, I.m, sizeof(I.m));
+}
+void orc_default_aligner_params(orc_aligner_params* p) {
+  std::memset(p, 0, sizeof(*p));
+  const float K[9] = { 525.f, 0.f, 0.f, 0.f, 525.f, 0.f, 319.5f, 239.5f, 1.f };
+  std::memcpy(p->K, K, sizeof(K));
+  p->min_distance = 0.01f; p->max_distance = 6.0f; p->rows = 480; p->cols = 640;
+  p->inlier_distance_threshold = 0.5f;
+  p->inlier_normal_angular_threshold = (float)std::cos(M_PI / 6);
+  p->flat_curvature_threshold = 0.02f; p->inlier_curvature_ratio_threshold = 1.3f;
+  p->inlier_max_chi2 = 9e3f; p->robust_kernel = 1; p->outer_iterations = 10; p->inner_iterations = 1;
+  const M4 I = m4_identity();
+  std::memcpy(p->reference_sensor_offset, I.m, sizeof(I.m));
+  std::memcpy(p->current_sensor_offset, I.m, sizeof(I.m));
+  std::memcpy(p->initial_guess, I.m, sizeof(I.m));
+  p->accumulate_fp64 = 0;
+}
+
+void orc_convert_16u_to_32f(const uint16_t* src, float* dst, int n, float scale) {
+  for (int i = 0; i < n; ++i) { dst[i] = 0.0f; if (src[i]) dst[i] = scale * src[i]; }
+}
+void orc_convert_32f_to_16u(const float* src, uint16_t* dst, int n, float scale) {
+  for (int i = 0; i < n; ++i) { dst[i] = 0; if (src[i] < FLT_MAX) dst[i] = (uint16_t)(scale * src[i]); }
+}
+void orc_depth_scale(const float* src, int srows, int scols, int step, float maxDepthCov, float* dst) {
+  const int rows = srows / step, cols = scols / step;
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) {
+      dst[(size_t)r * cols + c] = 0.f;
+      float acc = 0, acc2 = 0; int np = 0;
+      const int sr = r * step, sc = c * step;
+      for (int i = 0; i < step; ++i)
+        for (int j = 0; j < step; ++j)
+          if (sr + i < srows && sc + j < scols) {
+            const float f = src[(size_t)(sr + i) * scols + sc + j];
+            acc += f; acc2 += f * f; np += f > 0;
+          }
+      if (np) {
+        const float mu = acc / np;
+        const float sigma = acc2 / np - mu * mu;
+        if (sigma > maxDepthCov) continue;
+        dst[(size_t)r * cols + c] = mu;
+      }
+    }
+}
+
+void orc_projector_matrices(const float K[9], const float T[16], float KRt[16], float iKRt[16], float iK[9]) {
+  Projector pr = make_projector(K, T, 0.f, 0.f);
+  if (KRt) std::memcpy(KRt, pr.KRt.m, sizeof(pr.KRt.m));
+  if (iKRt) std::memcpy(iKRt, pr.iKRt.m, sizeof(pr.iKRt.m));
+  if (iK) std::memcpy(iK, pr.iK.m, sizeof(pr.iK.m));
+}
+
+orc_cloud* orc_cloud_create(void) { return new orc_cloud(); }
+void orc_cloud_destroy(orc_cloud* c) { delete c; }
+int orc_cloud_size(const orc_cloud* c) { return (int)c->points.size(); }
+void orc_cloud_get(const orc_cloud* c, float* points, float* normals, float* curvature, float* stats,
+                   float* eigenvalues, int* npoints, float* omega_p, float* omega_n) {
+  const size_t M = c->points.size();
+  for (size_t i = 0; i < M; ++i) {
+    if (points) std::memcpy(points + 4 * i, c->points[i].v, 16);
+    if (normals) std::memcpy(normals + 4 * i, c->normals[i].v, 16);
+    if (curvature) curvature[i] = c->stats[i].curvature();
+    if (stats) std::memcpy(stats + 16 * i, c->stats[i].m.m, 64);
+    if (eigenvalues) std::memcpy(eigenvalues + 3 * i, c->stats[i].eig, 12);
+    if (npoints) npoints[i] = c->stats[i].n;
+    if (omega_p) std::memcpy(omega_p + 16 * i, c->omegaP[i].m, 64);
+    if (omega_n) std::memcpy(omega_n + 16 * i, c->omegaN[i].m, 64);
+  }
+}
+void orc_cloud_set(orc_cloud* c, int n, const float* points, const float* normals, const float* curvature,
+                   const float* omega_p, const float* omega_n) {
+  c->points.resize(n); c->normals.resize(n); c->stats.assign(n, Stats()); c->omegaP.resize(n); c->omegaN.resize(n);
+  for (int i = 0; i < n; ++i) {
+    std::memcpy(c->points[i].v, points + 4 * i, 16);
+    std::memcpy(c->normals[i].v, normals + 4 * i, 16);
+    c->stats[i].curv = curvature[i]; c->stats[i].curvatureComputed = true;   /* stats.h:105-108 setCurvature */
+    std::memcpy(c->omegaP[i].m, omega_p + 16 * i, 64);
+    std::memcpy(c->omegaN[i].m, omega_n + 16 * i, 64);
+  }
+}
+
+int orc_unproject(const orc_converter_params* p, const float* depth, int rows, int cols, float* points, int* index_image) {
+  const M4 I = m4_identity();
+  Projector pr = make_projector(p->K, I.m, p->min_distance, p->max_distance);
+  int count = 0;
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) {
+      V4 pt;
+      if (!pr.unProject(pt, c, r, depth[(size_t)r * cols + c])) { index_image[(size_t)r * cols + c] = -1; continue; }
+      std::memcpy(points + 4 * (size_t)count, pt.v, 16);
+      index_image[(size_t)r * cols + c] = count++;
+    }
+  return count;
+}
+void orc_project_intervals(const orc_converter_params* p, const float* depth, int rows, int cols, int* interval_image) {
+  const M4 I = m4_identity();
+  Projector pr = make_projector(p->K, I.m, p->min_distance, p->max_distance);
+  for (size_t i = 0; i < (size_t)rows * cols; ++i) interval_image[i] = pr.projectInterval(depth[i], p->world_radius);
+}
+void orc_integral_image(const int* index_image, const float* points, int rows, int cols, float* out) {
+  std::vector<Acc> I;
+  integral_image(index_image, reinterpret_cast<const V4*>(points), rows, cols, I);
+  const size_t N = (size_t)rows * cols;
+  for (int k = 0; k < CH; ++k) for (size_t i = 0; i < N; ++i) out[k * N + i] = I[i].c[k];
+}
+
+void orc_convert(const orc_converter_params* p, const float* depth, int rows, int cols, orc_cloud* cloud,
+                 int* index_image, int* interval_image) {
+  /* depthimageconverterintegralimage.cpp:15-55 */
+  const size_t N = (size_t)rows * cols;
+  std::vector<int> idx(N), itv(N);
+  cloud->points.resize(N);
+  const int M = orc_unproject(p, depth, rows, cols, reinterpret_cast<float*>(cloud->points.data()), idx.data());
+  cloud->points.resize(M);
+  orc_project_intervals(p, depth, rows, cols, itv.data());
+  stats_compute(p, idx.data(), itv.data(), rows, cols, cloud->points, cloud->normals, cloud->stats);
+  info_compute(p, cloud->stats, cloud->normals, cloud->omegaP, cloud->omegaN);
+  cloud_transform_in_place(cloud, p->sensor_offset);
+  if (index_image) std::memcpy(index_image, idx.data(), N * sizeof(int));
+  if (interval_image) std::memcpy(interval_image, itv.data(), N * sizeof(int));
+}
+
+void orc_project(const float K[9], const float T[16], float min_distance, float max_distance, int rows, int cols,
+                 const float* points, int n, int* index_image, float* depth_image) {
+  Projector pr = make_projector(K, T, min_distance, max_distance);
+  project_points(pr, rows, cols, reinterpret_cast<const V4*>(points), n, index_image, depth_image);
+}
+
+int orc_correspondences(const orc_aligner_params* p, const orc_cloud* ref, const orc_cloud* cur, const int* ref_index,
+                        const int* cur_index, const float T[16], int* corr, int* K_out) {
+  return correspondences(p, ref, cur, ref_index, cur_index, m4_load(T), corr, K_out);
+}
+void orc_linearize(const orc_aligner_params* p, const orc_cloud* ref, const orc_cloud* cur, const int* corr, int C,
+                   const float T[16], float* H, float* b, float* chi2, double* chi2_fp64, int* inliers) {
+  if (p->accumulate_fp64) linearize_impl<double>(p, ref, cur, corr, C, m4_load(T), H, b, chi2, chi2_fp64, inliers);
+  else                    linearize_impl<float>(p, ref, cur, corr, C, m4_load(T), H, b, chi2, chi2_fp64, inliers);
+}
+
+void orc_align(const orc_aligner_params* p, const orc_cloud* ref, const orc_cloud* cur, float T_out[16], float* error_out,
+               int* inliers_out, orc_iter_trace* trace, int* ref_index_out, float* ref_depth_out, int* cur_index_out,
+               float* cur_depth_out) {
+  /* aligner.cpp:49-125 */
+  const size_t N = (size_t)p->rows * p->cols;
+  std::vector<int> refIdx(N), curIdx(N), corr(2 * N);
+  std::vector<float> refDepth(N), curDepth(N);
+  Projector pr = make_projector(p->K, p->current_sensor_offset, p->min_distance, p->max_distance);
+  project_points(pr, p->rows, p->cols, cur->points.data(), (int)cur->points.size(), curIdx.data(), curDepth.data());
+  M4 T = m4_load(p->initial_guess);
+  const M4 refOff = m4_load(p->reference_sensor_offset);
+  float err = 0.f; int inl = 0; int it = 0;
+  for (int i = 0; i < p->outer_iterations; ++i) {
+    force_last_row(T);
+    pr.T = iso_mul(T, refOff); pr.update();
+    project_points(pr, p->rows, p->cols, ref->points.data(), (int)ref->points.size(), refIdx.data(), refDepth.data());
+    int K = 0;
+    const int C = correspondences(p, ref, cur, refIdx.data(), curIdx.data(), iso_inverse(T), corr.data(), &K);
+    M4 invT = iso_inverse(T);
+    for (int k = 0; k < p->inner_iterations; ++k, ++it) {
+      force_last_row(invT);
+      float H[36], b[6]; float chi2; double chi2d;
+      orc_linearize(p, ref, cur, corr.data(), C, invT.m, H, b, &chi2, &chi2d, &inl);
+      err = chi2;
+      if (trace) {
+        orc_iter_trace& t = trace[it];
+        t.K = K; t.C = C; t.inliers = inl; t.chi2 = chi2; t.chi2_fp64 = chi2d;
+        std::memcpy(t.H, H, sizeof(H)); std::memcpy(t.b, b, sizeof(b)); std::memcpy(t.T_before, T.m, sizeof(T.m));
+      }
+      for (int d = 0; d < 6; ++d) { H[d + 6 * d] = H[d + 6 * d] + 1.0f; }        /* aligner.cpp:92 */
+      for (int d = 0; d < 6; ++d) { H[d + 6 * d] = H[d + 6 * d] + 1000.0f; }     /* aligner.cpp:94 */
+      float nb[6], dx[6];
+      for (int d = 0; d < 6; ++d) nb[d] = -b[d];
+      ldlt_solve6(H, nb, dx);
+      const M4 dT = v2t(dx);
+      invT = iso_mul(dT, invT);
+    }
+    T = iso_inverse(invT);
+    float v[6]; t2v(T, v); T = v2t(v);
+    force_last_row(T);
+  }
+  std::memcpy(T_out, T.m, sizeof(T.m));
+  if (error_out) *error_out = err;
+  if (inliers_out) *inliers_out = inl;
+  if (ref_index_out) std::memcpy(ref_index_out, refIdx.data(), N * sizeof(int));
+  if (ref_depth_out) std::memcpy(ref_depth_out, refDepth.data(), N * sizeof(float));
+  if (cur_index_out) std::memcpy(cur_index_out, curIdx.data(), N * sizeof(int));
+  if (cur_depth_out) std::memcpy(cur_depth_out, curDepth.data(), N * sizeof(float));
+}
+
+void orc_v2t(const float v[6], float T[16]) { const M4 t = v2t(v); std::memcpy(T, t.m, sizeof(t.m)); }
+void orc_t2v(const float T[16], float v[6]) { t2v(m4_load(T), v); }
+void orc_eigen3(const float A[9], float evals[3], float evecs[9]) {
+  M3 a; std::memcpy(a.m, A, sizeof(a.m)); M3 U; eig3_direct(a, evals, U); std::memcpy(evecs, U.m, sizeof(U.m));
+}
+void orc_ldlt_solve6(const float H[36], const float b[6], float x[6]) { ldlt_solve6(H, b, x); }
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+}  // extern "C"
