@@ -1,0 +1,521 @@
+"""Host-side mirror of the reference's pwn_core operator interface over the C-ABI (include/pwn_hip.h).
+
+Class and method names follow g2o_frontend/pwn_core (file:line cited per class) so that code and tests
+written against the reference read the same here.  Every compute method is one call into
+``libpwn_hip.so``; nothing is computed in Python and nothing falls back to the CPU.
+
+Matrices are numpy arrays indexed [row, col] (converted to the ABI's column-major floats at the
+boundary); images are [rows, cols].  Buffers may be numpy arrays (host) or torch CUDA tensors
+(device, passed by ``data_ptr()``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import AlignerParams, AlignResult, ConverterParams, PwnHipError
+
+
+def _ptr(x):
+    if x is None:
+        return None
+    if hasattr(x, "data_ptr"):                      # torch tensor
+        if not x.is_contiguous():
+            raise ValueError("tensor must be contiguous")
+        return C.c_void_p(x.data_ptr())
+    if isinstance(x, np.ndarray):
+        if not x.flags["C_CONTIGUOUS"]:
+            raise ValueError("array must be C-contiguous")
+        return x.ctypes.data_as(C.c_void_p)
+    raise TypeError(type(x))
+
+
+def _colmajor(M, n):
+    return np.ascontiguousarray(np.asarray(M, dtype=np.float32).reshape(n, n).T.reshape(-1))
+
+
+def _set(field, M, n):
+    for i, v in enumerate(_colmajor(M, n)):
+        field[i] = float(v)
+
+
+def _from_colmajor(a, n):
+    return np.array(list(a), dtype=np.float32).reshape(n, n).T.copy()
+
+
+def device_count() -> int:
+    return _lib.lib().pwn_hip_device_count()
+
+
+class Context:
+    """One per (GPU, host thread): owns the stream and the device workspaces
+    (cf. pwn_cuda createContext, pwn_cuda/cudaaligner.h:59)."""
+
+    def __init__(self, device: int = 0, max_rows: int = 480, max_cols: int = 640, max_batch: int = 1):
+        self._L = _lib.lib()
+        h = C.c_void_p()
+        rc = self._L.pwn_hip_ctx_create(C.byref(h), device, max_rows, max_cols, max_batch)
+        if rc:
+            raise PwnHipError(rc, self._L.pwn_hip_last_error_string(None).decode())
+        self.h = h
+        self.max_rows, self.max_cols, self.max_batch = max_rows, max_cols, max_batch
+
+    def check(self, rc):
+        if rc:
+            raise PwnHipError(rc, self._L.pwn_hip_last_error_string(self.h).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.pwn_hip_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_stream(self, stream_ptr):
+        self.check(self._L.pwn_hip_ctx_set_stream(self.h, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def set_subbatch(self, frames, pairs):
+        self.check(self._L.pwn_hip_ctx_set_subbatch(self.h, frames, pairs))
+
+    def synchronize(self):
+        self.check(self._L.pwn_hip_ctx_synchronize(self.h))
+
+    def set_profiling(self, on: bool):
+        self.check(self._L.pwn_hip_set_profiling(self.h, 1 if on else 0))
+
+    def stage_ms(self, stage: str):
+        ms, n = C.c_float(0), C.c_int(0)
+        self.check(self._L.pwn_hip_last_stage_ms(self.h, stage.encode(), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # ---- pwn_static.cpp ---------------------------------------------------------------------
+    def DepthImage_convert_16UC1_to_32FC1(self, src, scale=0.001):
+        """pwn_core/pwn_static.cpp:54-68"""
+        src = np.ascontiguousarray(src, dtype=np.uint16)
+        dst = np.empty(src.shape, np.float32)
+        self.check(self._L.pwn_hip_depth_u16_to_f32(self.h, _ptr(src), _ptr(dst), src.size, scale))
+        return dst
+
+    def DepthImage_convert_32FC1_to_16UC1(self, src, scale=1000.0):
+        """pwn_core/pwn_static.cpp:38-52"""
+        src = np.ascontiguousarray(src, dtype=np.float32)
+        dst = np.empty(src.shape, np.uint16)
+        self.check(self._L.pwn_hip_depth_f32_to_u16(self.h, _ptr(src), _ptr(dst), src.size, scale))
+        return dst
+
+    def DepthImage_scale(self, src, step, maxDepthCov=0.01):
+        """pwn_core/pwn_static.cpp:5-36"""
+        src = np.ascontiguousarray(src, dtype=np.float32)
+        dst = np.empty((src.shape[0] // step, src.shape[1] // step), np.float32)
+        self.check(self._L.pwn_hip_depth_scale(self.h, _ptr(src), src.shape[0], src.shape[1], step, maxDepthCov, _ptr(dst)))
+        return dst
+
+
+class Cloud:
+    """Device-resident pwn::Cloud (pwn_core/cloud.h:20-187): points, normals, curvature (of Stats) and the
+    two information-matrix vectors."""
+
+    def __init__(self, ctx: Context, capacity: int):
+        self.ctx = ctx
+        h = C.c_void_p()
+        ctx.check(ctx._L.pwn_hip_cloud_create(ctx.h, capacity, C.byref(h)))
+        self.h = h
+        self.capacity = capacity
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None) and self.ctx.h:
+                self.ctx._L.pwn_hip_cloud_destroy(self.ctx.h, self.h)
+            self.h = None
+        except Exception:
+            pass
+
+    def size(self) -> int:
+        n = C.c_int(0)
+        self.ctx.check(self.ctx._L.pwn_hip_cloud_size(self.ctx.h, self.h, C.byref(n)))
+        return n.value
+
+    __len__ = size
+
+    def upload(self, points, normals, curvature, omega_p, omega_n):
+        a = [np.ascontiguousarray(x, dtype=np.float32) for x in (points, normals, curvature, omega_p, omega_n)]
+        self.ctx.check(self.ctx._L.pwn_hip_cloud_upload(self.ctx.h, self.h, len(a[0]), *[_ptr(x) for x in a]))
+
+    def arrays(self, stats: bool = False):
+        n = self.size()
+        out = dict(points=np.empty((n, 4), np.float32), normals=np.empty((n, 4), np.float32),
+                   curvature=np.empty(n, np.float32), omega_p=np.empty((n, 16), np.float32),
+                   omega_n=np.empty((n, 16), np.float32))
+        self.ctx.check(self.ctx._L.pwn_hip_cloud_download(self.ctx.h, self.h, _ptr(out["points"]), _ptr(out["normals"]),
+                                                          _ptr(out["curvature"]), _ptr(out["omega_p"]), _ptr(out["omega_n"])))
+        if stats:
+            out.update(stats=np.empty((n, 16), np.float32), eigenvalues=np.empty((n, 3), np.float32),
+                       npoints=np.empty(n, np.int32))
+            self.ctx.check(self.ctx._L.pwn_hip_cloud_download_stats(self.ctx.h, self.h, _ptr(out["stats"]),
+                                                                    _ptr(out["eigenvalues"]), _ptr(out["npoints"])))
+        return out
+
+    def transformInPlace(self, T):
+        """pwn_core/cloud.cpp:173-186"""
+        self.ctx.check(self.ctx._L.pwn_hip_cloud_transform_in_place(self.ctx.h, self.h, _ptr(_colmajor(T, 4))))
+
+
+class PinholePointProjector:
+    """pwn_core/pinholepointprojector.{h,cpp} + pointprojector.{h,cpp}: parameter holder; project /
+    unProject / projectIntervals run on the GPU."""
+
+    def __init__(self, ctx: Context | None = None):
+        self.ctx = ctx
+        self._K = np.array([[1, 0, 0.5], [0, 1, 0.5], [0, 0, 1]], np.float32)   # pinholepointprojector.cpp:6-9
+        self._transform = np.eye(4, dtype=np.float32)
+        self._minDistance, self._maxDistance = 0.01, 6.0                        # pointprojector.cpp:9-10
+        self._imageRows = self._imageCols = 0
+
+    def cameraMatrix(self): return self._K
+    def setCameraMatrix(self, K): self._K = np.asarray(K, np.float32).reshape(3, 3).copy()
+    def transform(self): return self._transform
+    def setTransform(self, T): self._transform = np.asarray(T, np.float32).reshape(4, 4).copy()
+    def minDistance(self): return self._minDistance
+    def setMinDistance(self, v): self._minDistance = float(v)
+    def maxDistance(self): return self._maxDistance
+    def setMaxDistance(self, v): self._maxDistance = float(v)
+    def imageRows(self): return self._imageRows
+    def imageCols(self): return self._imageCols
+    def setImageSize(self, rows, cols): self._imageRows, self._imageCols = int(rows), int(cols)
+
+    def scale(self, s):
+        """pinholepointprojector.cpp:149-154"""
+        self._K[:2, :] = self._K[:2, :] * np.float32(s)
+        self._imageRows = int(np.float32(self._imageRows) * np.float32(s))
+        self._imageCols = int(np.float32(self._imageCols) * np.float32(s))
+
+    def matrices(self):
+        """_updateMatrices (pinholepointprojector.cpp:17-31): (KRt, iKRt, iK)"""
+        KRt = np.empty(16, np.float32); iKRt = np.empty(16, np.float32); iK = np.empty(9, np.float32)
+        _lib.lib().pwn_hip_projector_matrices(_ptr(_colmajor(self._K, 3)), _ptr(_colmajor(self._transform, 4)), _ptr(KRt), _ptr(iKRt), _ptr(iK))
+        return KRt.reshape(4, 4).T.copy(), iKRt.reshape(4, 4).T.copy(), iK.reshape(3, 3).T.copy()
+
+    def project(self, cloud: Cloud):
+        """project(indexImage, depthImage, points) (pinholepointprojector.cpp:33-66) -> (index, depth)"""
+        ctx = cloud.ctx
+        idx = np.empty((self._imageRows, self._imageCols), np.int32)
+        dep = np.empty((self._imageRows, self._imageCols), np.float32)
+        ctx.check(ctx._L.pwn_hip_project(ctx.h, _ptr(_colmajor(self._K, 3)), _ptr(_colmajor(self._transform, 4)), self._minDistance,
+                                         self._maxDistance, self._imageRows, self._imageCols, cloud.h, _ptr(idx), _ptr(dep)))
+        return idx, dep
+
+    def _params(self, world_radius=0.1) -> ConverterParams:
+        p = ConverterParams()
+        _lib.lib().pwn_hip_default_converter_params(C.byref(p))
+        _set(p.K, self._K, 3)
+        p.min_distance, p.max_distance, p.world_radius = self._minDistance, self._maxDistance, world_radius
+        return p
+
+    def unProject(self, cloud: Cloud, depthImage):
+        """unProject(points, gaussians, indexImage, depthImage) (pinholepointprojector.cpp:93-133) -> index image"""
+        ctx = cloud.ctx
+        depth = depthImage if hasattr(depthImage, "data_ptr") else np.ascontiguousarray(depthImage, np.float32)
+        rows, cols = depth.shape
+        idx = np.empty((rows, cols), np.int32)
+        p = self._params()
+        ctx.check(ctx._L.pwn_hip_unproject(ctx.h, C.byref(p), _ptr(_colmajor(self._transform, 4)), _ptr(depth), rows, cols, cloud.h, _ptr(idx)))
+        return idx
+
+    def projectIntervals(self, ctx: Context, depthImage, worldRadius):
+        """projectIntervals (pinholepointprojector.cpp:135-147) -> interval image"""
+        depth = np.ascontiguousarray(depthImage, np.float32)
+        rows, cols = depth.shape
+        out = np.empty((rows, cols), np.int32)
+        p = self._params(worldRadius)
+        ctx.check(ctx._L.pwn_hip_project_intervals(ctx.h, C.byref(p), _ptr(depth), rows, cols, _ptr(out)))
+        return out
+
+
+class StatsCalculatorIntegralImage:
+    """pwn_core/statscalculatorintegralimage.{h,cpp}: parameters (defaults :6-12)."""
+
+    def __init__(self):
+        self._worldRadius, self._maxImageRadius, self._minImageRadius = 0.1, 30, 10
+        self._minPoints, self._curvatureThreshold = 50, 0.02
+
+    def setWorldRadius(self, v): self._worldRadius = float(v)
+    def worldRadius(self): return self._worldRadius
+    def setMaxImageRadius(self, v): self._maxImageRadius = int(v)
+    def setMinImageRadius(self, v): self._minImageRadius = int(v)
+    def setMinPoints(self, v): self._minPoints = int(v)
+    def setCurvatureThreshold(self, v): self._curvatureThreshold = float(v)
+
+    @staticmethod
+    def integralImage(cloud: Cloud, indexImage):
+        """PointIntegralImage::compute (pointintegralimage.cpp:7-44): 10 planes [10, rows, cols]"""
+        ctx = cloud.ctx
+        idx = np.ascontiguousarray(indexImage, np.int32)
+        out = np.empty((10,) + idx.shape, np.float32)
+        ctx.check(ctx._L.pwn_hip_integral_image(ctx.h, _ptr(idx), cloud.h, idx.shape[0], idx.shape[1], _ptr(out)))
+        return out
+
+
+class _InformationMatrixCalculator:
+    def __init__(self, flat, nonflat, thr):
+        self._flat, self._nonflat, self._curvatureThreshold = list(flat), list(nonflat), thr
+
+    def setCurvatureThreshold(self, v): self._curvatureThreshold = float(v)
+    def setFlatInformationMatrix(self, diag): self._flat = [float(x) for x in diag]
+    def setNonFlatInformationMatrix(self, diag): self._nonflat = [float(x) for x in diag]
+
+
+class PointInformationMatrixCalculator(_InformationMatrixCalculator):
+    """pwn_core/informationmatrixcalculator.h:95-118 (defaults :106-110)"""
+
+    def __init__(self): super().__init__((1000.0, 1.0, 1.0), (1.0, 1.0, 1.0), 0.02)
+
+
+class NormalInformationMatrixCalculator(_InformationMatrixCalculator):
+    """pwn_core/informationmatrixcalculator.h:130-153 (defaults :141-145)"""
+
+    def __init__(self): super().__init__((100.0, 100.0, 100.0), (1.0, 1.0, 1.0), 0.02)
+
+
+class DepthImageConverterIntegralImage:
+    """pwn_core/depthimageconverterintegralimage.{h,cpp}: compute(cloud, depthImage, sensorOffset)."""
+
+    def __init__(self, projector, statsCalculator, pointInformationMatrixCalculator, normalInformationMatrixCalculator):
+        self._projector, self._stats = projector, statsCalculator
+        self._pinfo, self._ninfo = pointInformationMatrixCalculator, normalInformationMatrixCalculator
+        self._indexImage = None
+        self._intervalImage = None
+
+    def projector(self): return self._projector
+    def indexImage(self): return self._indexImage
+    def intervalImage(self): return self._intervalImage
+
+    def params(self, sensorOffset=None) -> ConverterParams:
+        p = self._projector._params(self._stats._worldRadius)
+        p.min_image_radius, p.max_image_radius = self._stats._minImageRadius, self._stats._maxImageRadius
+        p.min_points, p.stats_curvature_threshold = self._stats._minPoints, self._stats._curvatureThreshold
+        p.point_info_curvature_threshold = self._pinfo._curvatureThreshold
+        p.normal_info_curvature_threshold = self._ninfo._curvatureThreshold
+        for i in range(3):
+            p.point_flat_diag[i], p.point_nonflat_diag[i] = self._pinfo._flat[i], self._pinfo._nonflat[i]
+            p.normal_flat_diag[i], p.normal_nonflat_diag[i] = self._ninfo._flat[i], self._ninfo._nonflat[i]
+        _set(p.sensor_offset, np.eye(4) if sensorOffset is None else sensorOffset, 4)
+        return p
+
+    def compute(self, cloud: Cloud, depthImage, sensorOffset=None, keep_stats: bool = False, images: bool = True):
+        ctx = cloud.ctx
+        depth = depthImage if hasattr(depthImage, "data_ptr") else np.ascontiguousarray(depthImage, np.float32)
+        rows, cols = depth.shape
+        # side effects of the reference: projector image size set, transform reset (depthimageconverterintegralimage.cpp:30,38)
+        self._projector.setImageSize(rows, cols)
+        self._projector.setTransform(np.eye(4, dtype=np.float32))
+        p = self.params(sensorOffset)
+        idx = np.empty((rows, cols), np.int32) if images else None
+        itv = np.empty((rows, cols), np.int32) if images else None
+        ctx.check(ctx._L.pwn_hip_convert(ctx.h, C.byref(p), _ptr(depth), rows, cols, cloud.h, _ptr(idx), _ptr(itv), 1 if keep_stats else 0))
+        self._indexImage, self._intervalImage = idx, itv
+
+    def computeBatch(self, clouds, depthImages, sensorOffset=None, raw_scale=None):
+        """n independent frames in one call.  depthImages: list of float32 [rows, cols] arrays / CUDA tensors,
+        or uint16 millimetre frames when raw_scale is given (fuses DepthImage_convert_16UC1_to_32FC1)."""
+        ctx = clouds[0].ctx
+        n = len(clouds)
+        rows, cols = depthImages[0].shape
+        p = self.params(sensorOffset)
+        ptrs = (C.c_void_p * n)(*[_ptr(d) for d in depthImages])
+        handles = (C.c_void_p * n)(*[c.h for c in clouds])
+        if raw_scale is None:
+            ctx.check(ctx._L.pwn_hip_convert_batch(ctx.h, C.byref(p), ptrs, n, rows, cols, handles))
+        else:
+            ctx.check(ctx._L.pwn_hip_convert_batch_u16(ctx.h, C.byref(p), ptrs, raw_scale, n, rows, cols, handles))
+
+
+class CorrespondenceFinder:
+    """pwn_core/correspondencefinder.{h,cpp}: parameters (defaults .cpp:9-18) + compute()."""
+
+    def __init__(self):
+        self._inlierDistanceThreshold = 0.5
+        self._inlierNormalAngularThreshold = float(np.float32(np.cos(np.pi / 6)))
+        self._flatCurvatureThreshold, self._inlierCurvatureRatioThreshold = 0.02, 1.3
+        self._rows = self._cols = 0
+        self._correspondences = None
+        self._numCorrespondences = 0
+        self._images = {}
+
+    def setInlierDistanceThreshold(self, v): self._inlierDistanceThreshold = float(v)
+    def setInlierNormalAngularThreshold(self, v): self._inlierNormalAngularThreshold = float(v)
+    def setFlatCurvatureThreshold(self, v): self._flatCurvatureThreshold = float(v)
+    def setInlierCurvatureRatioThreshold(self, v): self._inlierCurvatureRatioThreshold = float(v)
+    def setImageSize(self, rows, cols): self._rows, self._cols = int(rows), int(cols)
+    def imageRows(self): return self._rows
+    def imageCols(self): return self._cols
+    def numCorrespondences(self): return self._numCorrespondences
+    def correspondences(self): return self._correspondences
+    def referenceIndexImage(self): return self._images.get("ref_index")
+    def currentIndexImage(self): return self._images.get("cur_index")
+    def referenceDepthImage(self): return self._images.get("ref_depth")
+    def currentDepthImage(self): return self._images.get("cur_depth")
+
+
+class Linearizer:
+    """pwn_core/linearizer.{h,cpp}: parameters (defaults .cpp:9-15); H/b/error/inliers of the last update."""
+
+    def __init__(self):
+        self._inlierMaxChi2, self._robustKernel = 9e3, True
+        self._H = np.zeros((6, 6), np.float32); self._b = np.zeros(6, np.float32)
+        self._error, self._inliers = 0.0, 0
+        self._T = np.eye(4, dtype=np.float32)
+        self._aligner = None
+
+    def setAligner(self, a): self._aligner = a
+    def setInlierMaxChi2(self, v): self._inlierMaxChi2 = float(v)
+    def setRobustKernel(self, v): self._robustKernel = bool(v)
+    def setT(self, T):
+        self._T = np.asarray(T, np.float32).reshape(4, 4).copy(); self._T[3] = (0, 0, 0, 1)   # linearizer.h:62-65
+    def H(self): return self._H
+    def b(self): return self._b
+    def error(self): return self._error
+    def inliers(self): return self._inliers
+
+
+class Aligner:
+    """pwn_core/aligner.{h,cpp}.  align() runs the whole Gauss-Newton loop on the GPU (pwn_hip_align)."""
+
+    def __init__(self, ctx: Context):
+        self.ctx = ctx
+        self._projector = self._linearizer = self._correspondenceFinder = None
+        self._referenceCloud = self._currentCloud = None
+        self._outerIterations, self._innerIterations = 10, 1          # aligner.cpp:19-20
+        I = np.eye(4, dtype=np.float32)
+        self._T, self._initialGuess = I.copy(), I.copy()
+        self._referenceSensorOffset, self._currentSensorOffset = I.copy(), I.copy()
+        self._totalTime, self._error, self._inliers = 0.0, 0.0, 0
+        self._result = None
+
+    @staticmethod
+    def _iso(T):
+        T = np.asarray(T, np.float32).reshape(4, 4).copy(); T[3] = (0, 0, 0, 1); return T     # aligner.h:130-190 force the last row
+
+    def setProjector(self, p): self._projector = p
+    def setLinearizer(self, l): self._linearizer = l; l.setAligner(self)
+    def setCorrespondenceFinder(self, f): self._correspondenceFinder = f
+    def projector(self): return self._projector
+    def linearizer(self): return self._linearizer
+    def correspondenceFinder(self): return self._correspondenceFinder
+    def setReferenceCloud(self, c): self._referenceCloud = c
+    def setCurrentCloud(self, c): self._currentCloud = c
+    def setOuterIterations(self, n): self._outerIterations = int(n)
+    def setInnerIterations(self, n): self._innerIterations = int(n)
+    def setInitialGuess(self, T): self._initialGuess = self._iso(T)
+    def setSensorOffset(self, T): self._referenceSensorOffset = self._iso(T); self._currentSensorOffset = self._iso(T)
+    def setReferenceSensorOffset(self, T): self._referenceSensorOffset = self._iso(T)
+    def setCurrentSensorOffset(self, T): self._currentSensorOffset = self._iso(T)
+    def T(self): return self._T
+    def error(self): return self._error
+    def inliers(self): return self._inliers
+    def totalTime(self): return self._totalTime
+    def result(self): return self._result
+
+    def params(self) -> AlignerParams:
+        assert self._projector is not None and self._linearizer is not None and self._correspondenceFinder is not None, "Aligner: missing collaborator"
+        p = AlignerParams()
+        _lib.lib().pwn_hip_default_aligner_params(C.byref(p))
+        pr, f, l = self._projector, self._correspondenceFinder, self._linearizer
+        _set(p.K, pr._K, 3)
+        p.min_distance, p.max_distance = pr._minDistance, pr._maxDistance
+        p.rows, p.cols = pr._imageRows, pr._imageCols
+        p.inlier_distance_threshold = f._inlierDistanceThreshold
+        p.inlier_normal_angular_threshold = f._inlierNormalAngularThreshold
+        p.flat_curvature_threshold = f._flatCurvatureThreshold
+        p.inlier_curvature_ratio_threshold = f._inlierCurvatureRatioThreshold
+        p.inlier_max_chi2 = l._inlierMaxChi2
+        p.robust_kernel = 1 if l._robustKernel else 0
+        p.outer_iterations, p.inner_iterations = self._outerIterations, self._innerIterations
+        _set(p.reference_sensor_offset, self._referenceSensorOffset, 4)
+        _set(p.current_sensor_offset, self._currentSensorOffset, 4)
+        _set(p.initial_guess, self._initialGuess, 4)
+        return p
+
+    @staticmethod
+    def _unpack(r: AlignResult):
+        n = r.iterations
+        return dict(T=_from_colmajor(r.T, 4), error=r.error, inliers=r.inliers, iterations=n, total_time_ms=r.total_time_ms,
+                    chi2=np.array(r.chi2[:n], np.float32), iter_inliers=np.array(r.iter_inliers[:n], np.int32),
+                    C=np.array(r.iter_correspondences[:n], np.int32), K=np.array(r.iter_candidates[:n], np.int32),
+                    n_reference=r.n_reference, n_current=r.n_current)
+
+    def align(self, images: bool = False):
+        """aligner.cpp:49-125"""
+        assert self._referenceCloud is not None and self._currentCloud is not None, "Aligner: missing cloud"
+        p = self.params()
+        r = AlignResult()
+        self.ctx.check(self.ctx._L.pwn_hip_align(self.ctx.h, C.byref(p), self._referenceCloud.h, self._currentCloud.h, C.byref(r)))
+        self._result = self._unpack(r)
+        self._T, self._error, self._inliers = self._result["T"], r.error, r.inliers
+        self._totalTime = r.total_time_ms
+        self._linearizer._error, self._linearizer._inliers = r.error, r.inliers
+        if images:
+            f = self._correspondenceFinder
+            ri = np.empty((p.rows, p.cols), np.int32); ci = np.empty((p.rows, p.cols), np.int32)
+            rd = np.empty((p.rows, p.cols), np.float32); cd = np.empty((p.rows, p.cols), np.float32)
+            self.ctx.check(self.ctx._L.pwn_hip_align_images(self.ctx.h, _ptr(ri), _ptr(rd), _ptr(ci), _ptr(cd)))
+            f._images = dict(ref_index=ri, ref_depth=rd, cur_index=ci, cur_depth=cd)
+        return self._result
+
+    def alignBatch(self, references, currents, initialGuesses=None):
+        """n independent alignments with this aligner's parameters (the loop-closure candidate batch,
+        pwn_tracker/pwn_closer.cpp:92-111)."""
+        n = len(references)
+        p = self.params()
+        res = (AlignResult * n)()
+        refs = (C.c_void_p * n)(*[c.h for c in references])
+        curs = (C.c_void_p * n)(*[c.h for c in currents])
+        g = None
+        if initialGuesses is not None:
+            g = np.ascontiguousarray(np.stack([_colmajor(self._iso(T), 4) for T in initialGuesses]), np.float32)
+        self.ctx.check(self.ctx._L.pwn_hip_align_batch(self.ctx.h, C.byref(p), n, refs, curs, _ptr(g), res))
+        return [self._unpack(r) for r in res]
+
+    # stage-level entry points (CorrespondenceFinder::compute / Linearizer::update with explicit inputs)
+    def computeCorrespondences(self, referenceIndexImage, currentIndexImage, T):
+        """correspondencefinder.cpp:20-118 -> (correspondences [C,2], K)"""
+        p = self.params()
+        ri = np.ascontiguousarray(referenceIndexImage, np.int32); ci = np.ascontiguousarray(currentIndexImage, np.int32)
+        corr = np.empty((p.rows * p.cols, 2), np.int32)
+        nC, nK = C.c_int(0), C.c_int(0)
+        self.ctx.check(self.ctx._L.pwn_hip_correspondences(self.ctx.h, C.byref(p), self._referenceCloud.h, self._currentCloud.h, _ptr(ri), _ptr(ci),
+                                                           _ptr(_colmajor(T, 4)), _ptr(corr), C.byref(nC), C.byref(nK)))
+        f = self._correspondenceFinder
+        f._correspondences, f._numCorrespondences = corr, nC.value
+        return corr[:nC.value].copy(), nK.value
+
+    def linearize(self, correspondences, T):
+        """linearizer.cpp:17-115 with _T = T"""
+        p = self.params()
+        corr = np.ascontiguousarray(correspondences, np.int32)
+        H = np.empty(36, np.float32); b = np.empty(6, np.float32)
+        err, inl = C.c_float(0), C.c_int(0)
+        self.ctx.check(self.ctx._L.pwn_hip_linearize(self.ctx.h, C.byref(p), self._referenceCloud.h, self._currentCloud.h, _ptr(corr), len(corr),
+                                                     _ptr(_colmajor(T, 4)), _ptr(H), _ptr(b), C.byref(err), C.byref(inl)))
+        l = self._linearizer
+        l._H, l._b, l._error, l._inliers = H.reshape(6, 6).T.copy(), b, err.value, inl.value
+        return dict(H=l._H, b=b, chi2=err.value, inliers=inl.value)
+
+
+def v2t(v):
+    """pwn_core/bm_se3.h:37-43"""
+    v = np.ascontiguousarray(v, np.float32); T = np.empty(16, np.float32)
+    _lib.lib().pwn_hip_v2t(_ptr(v), _ptr(T))
+    return T.reshape(4, 4).T.copy()
+
+
+def t2v(T):
+    """pwn_core/bm_se3.h:45-52"""
+    v = np.empty(6, np.float32)
+    _lib.lib().pwn_hip_t2v(_ptr(_colmajor(T, 4)), _ptr(v))
+    return v

@@ -1,0 +1,29 @@
+"""Builds the in-tree HIP extension ``libpwn_hip.so`` for gfx950 (hipcc cross-compiles without a GPU)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("pwn_hip_capi.hip", "pwn_kernels.h", "pwn_math.h")]
+HEADER = os.path.join(os.path.dirname(_HERE), "include", "pwn_hip.h")
+OUT = os.path.join(_HERE, "libpwn_hip.so")
+# -ffp-contract=off: the kernels reproduce the CPU path's evaluation order; a fused multiply-add would change bits.
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    deps = SOURCES + [HEADER, __file__]
+    stale = (not os.path.exists(OUT)) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps)
+    if force or stale:
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        cmd = [hipcc] + FLAGS + ["-o", OUT, SOURCES[0]]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        subprocess.check_call(cmd)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,853 @@
+// pwn_hip_capi.hip -- implementation of include/pwn_hip.h: context, device clouds and the launch
+// sequences that replace the reference's DepthImageConverterIntegralImage::compute
+// (pwn_core/depthimageconverterintegralimage.cpp:15-55) and Aligner::align (pwn_core/aligner.cpp:49-125).
+//
+// Host code only orchestrates: every per-pixel / per-point / per-correspondence loop of the reference runs
+// in a kernel of pwn_kernels.h, and the Gauss-Newton loop runs without host round trips (the 6x6 solve and
+// the SE(3) update are a one-wave kernel).  There is no CPU fallback: without a HIP device every entry point
+// returns PWN_HIP_ERR_NO_DEVICE.
+#include "../../include/pwn_hip.h"
+#include "pwn_kernels.h"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+using namespace pwnhip;
+
+namespace {
+
+thread_local std::string g_err = "";
+
+struct StageAcc { float ms = 0.f; int launches = 0; };
+struct EventRec { std::string stage; hipEvent_t a, b; };
+
+}  // namespace
+
+struct pwn_hip_cloud {
+  CloudDev d;
+  int n_host = 0;
+  bool has_stats = false;
+};
+
+struct pwn_hip_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;
+  int max_rows = 0, max_cols = 0, max_batch = 0;
+  size_t N = 0;
+  int sub_frames = 8, sub_pairs = 8;
+  // convert workspaces (per slot)
+  float* depth_ws = nullptr; int* index_ws = nullptr; int* interval_ws = nullptr; float* integral_ws = nullptr; int* rowoff_ws = nullptr;
+  uint16_t* raw_ws = nullptr;
+  // align workspaces (per slot)
+  unsigned long long* zref_ws = nullptr; unsigned long long* zcur_ws = nullptr; double* partials_ws = nullptr; PairState* state_ws = nullptr;
+  int nblocks_max = 0;
+  // descriptors
+  FrameDesc* frames_dev = nullptr; PairDesc* pairs_dev = nullptr; RawDesc* raw_dev = nullptr;
+  FrameDesc* frames_host = nullptr; PairDesc* pairs_host = nullptr; RawDesc* raw_host = nullptr; PairState* state_host = nullptr;
+  // misc scratch
+  SolveOut* solve_dev = nullptr; int* counters_dev = nullptr; int2* corr_ws = nullptr; int* scratch_count = nullptr;
+  float* io_ws = nullptr;   // N*16 floats staging for cloud up/download
+  // images of the last single align
+  int img_rows = 0, img_cols = 0; bool img_valid = false;
+  std::string err;
+  bool profiling = false;
+  std::map<std::string, StageAcc> stages;
+  std::vector<EventRec> pending;
+  std::vector<hipEvent_t> event_pool;
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+};
+
+namespace {
+
+int fail(pwn_hip_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg;
+  g_err = msg;
+  return code;
+}
+#define HIPCHK(ctx, call, code)                                                                               \
+  do {                                                                                                        \
+    hipError_t e_ = (call);                                                                                   \
+    if (e_ != hipSuccess) return fail(ctx, code, std::string(#call) + ": " + hipGetErrorString(e_));           \
+  } while (0)
+
+bool is_device_ptr(const void* p) {
+  if (!p) return false;
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, p);
+  if (e != hipSuccess) { (void)hipGetLastError(); return false; }
+  return attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged;
+}
+// copy helper: any combination of host/device
+hipError_t copy_any(void* dst, const void* src, size_t bytes, hipStream_t s) {
+  return hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, s);
+}
+
+hipEvent_t get_event(pwn_hip_ctx* ctx) {
+  if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
+  hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+struct StageTimer {
+  pwn_hip_ctx* ctx; EventRec rec; bool on;
+  StageTimer(pwn_hip_ctx* c, const char* stage) : ctx(c), on(c->profiling) {
+    if (on) { rec.stage = stage; rec.a = get_event(ctx); rec.b = get_event(ctx); (void)hipEventRecord(rec.a, ctx->stream); }
+  }
+  ~StageTimer() { if (on) { (void)hipEventRecord(rec.b, ctx->stream); ctx->pending.push_back(rec); } }
+};
+void collect_stage_times(pwn_hip_ctx* ctx) {
+  for (auto& r : ctx->pending) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) { auto& s = ctx->stages[r.stage]; s.ms += ms; s.launches += 1; }
+    ctx->event_pool.push_back(r.a); ctx->event_pool.push_back(r.b);
+  }
+  ctx->pending.clear();
+}
+
+Mat4 forced(const float* T) { Mat4 m = mat4_from(T); set_last_row(m); return m; }
+bool is_identity(const Mat4& m) { const Mat4 I = mat4_identity(); for (int i = 0; i < 16; ++i) if (m.m[i] != I.m[i]) return false; return true; }
+
+ConvertParams make_convert_params(const pwn_hip_converter_params* p, const float* T, int rows, int cols, int keep_stats) {
+  ConvertParams cp;
+  cp.rows = rows; cp.cols = cols;
+  const Mat3 K = mat3_from(p->K);
+  Mat4 KRt; Mat3 iK;
+  projector_matrices(K, T ? mat4_from(T) : mat4_identity(), KRt, cp.iKRt, iK);
+  // _projectInterval: p = K * (R, R, 0)   (pinholepointprojector.h:269)
+  const float R = p->world_radius;
+  cp.ivx = dot3seq(K(0,0), R, K(0,1), R, K(0,2), 0.f);
+  cp.ivy = dot3seq(K(1,0), R, K(1,1), R, K(1,2), 0.f);
+  cp.minD = p->min_distance; cp.maxD = p->max_distance;
+  cp.minRadius = p->min_image_radius; cp.maxRadius = p->max_image_radius; cp.minPoints = p->min_points;
+  cp.statsCurvThr = p->stats_curvature_threshold;
+  cp.pointInfoCurvThr = p->point_info_curvature_threshold; cp.normalInfoCurvThr = p->normal_info_curvature_threshold;
+  for (int i = 0; i < 3; ++i) { cp.pFlat[i] = p->point_flat_diag[i]; cp.pNonFlat[i] = p->point_nonflat_diag[i]; }
+  cp.offset = forced(p->sensor_offset);
+  cp.hasOffset = is_identity(cp.offset) ? 0 : 1;
+  cp.keepStats = keep_stats;
+  return cp;
+}
+// class matrices of the normal information matrix, after Cloud::transformInPlace (T * Omega * T^t, informationmatrix.h:111-121)
+void make_omega_n_classes(const pwn_hip_converter_params* p, CloudDev& d) {
+  const Mat4 m = forced(p->sensor_offset);
+  const bool ident = is_identity(m);
+  for (int c = 0; c < 2; ++c) {
+    const float* dg = c == 0 ? p->normal_flat_diag : p->normal_nonflat_diag;
+    float om[9] = { dg[0], 0, 0, 0, dg[1], 0, 0, 0, dg[2] };
+    if (!ident) {
+      float t1[9];
+      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) t1[3 * i + j] = dot3seq(m(i,0), om[0 + j], m(i,1), om[3 + j], m(i,2), om[6 + j]);
+      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) om[3 * i + j] = dot3seq(t1[3 * i], m(j,0), t1[3 * i + 1], m(j,1), t1[3 * i + 2], m(j,2));
+    }
+    for (int k = 0; k < 9; ++k) d.omN[c][k] = om[k];
+  }
+}
+AlignParams make_align_params(const pwn_hip_aligner_params* p) {
+  AlignParams ap;
+  ap.rows = p->rows; ap.cols = p->cols;
+  ap.K = mat3_from(p->K);
+  ap.refOffset = mat4_from(p->reference_sensor_offset);
+  ap.minD = p->min_distance; ap.maxD = p->max_distance;
+  ap.sqDist = p->inlier_distance_threshold * p->inlier_distance_threshold;
+  ap.normalThr = p->inlier_normal_angular_threshold;
+  ap.flatThr = p->flat_curvature_threshold;
+  ap.minRatio = 1.0f / p->inlier_curvature_ratio_threshold;
+  ap.maxRatio = p->inlier_curvature_ratio_threshold;
+  ap.maxChi2 = p->inlier_max_chi2;
+  ap.robust = p->robust_kernel;
+  return ap;
+}
+
+int check_image(pwn_hip_ctx* ctx, int rows, int cols) {
+  if (rows <= 0 || cols <= 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "image has zero size");
+  if ((size_t)rows * cols > ctx->N || rows > std::max(ctx->max_rows, ctx->max_cols))
+    return fail(ctx, PWN_HIP_ERR_CAPACITY, "image larger than the context was created for");
+  return PWN_HIP_OK;
+}
+int align_nblocks(int N) { return (N + kAlignBlock * kPixPerThread - 1) / (kAlignBlock * kPixPerThread); }
+
+// launch sequence of the converter for frames [0, n) described in ctx->frames_host
+int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int n) {
+  HIPCHK(ctx, hipMemcpyAsync(ctx->frames_dev, ctx->frames_host, sizeof(FrameDesc) * n, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
+  { StageTimer t(ctx, "unproject");
+    hipLaunchKernelGGL(k_row_count, dim3(cp.rows, n), dim3(256), 0, ctx->stream, ctx->frames_dev, cp);
+    hipLaunchKernelGGL(k_row_offsets, dim3(n), dim3(1024), 0, ctx->stream, ctx->frames_dev, cp.rows);
+    hipLaunchKernelGGL(k_unproject, dim3(cp.rows, n), dim3(256), 0, ctx->stream, ctx->frames_dev, cp); }
+  { StageTimer t(ctx, "integral_rows");
+    hipLaunchKernelGGL(k_integral_rows, dim3((cp.rows + kIR_Rows - 1) / kIR_Rows, n), dim3(256), 0, ctx->stream, ctx->frames_dev, cp.rows, cp.cols); }
+  { StageTimer t(ctx, "integral_cols");
+    hipLaunchKernelGGL(k_integral_cols, dim3((cp.cols + 255) / 256, kIntegralChannels, n), dim3(256), 0, ctx->stream, ctx->frames_dev, cp.rows, cp.cols); }
+  { StageTimer t(ctx, "stats");
+    hipLaunchKernelGGL(k_stats, dim3((cp.cols + 255) / 256, cp.rows, n), dim3(256), 0, ctx->stream, ctx->frames_dev, cp); }
+  HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
+  return PWN_HIP_OK;
+}
+void fill_frame(pwn_hip_ctx* ctx, int slot, const float* depth_dev, const CloudDev& cl, int rows) {
+  FrameDesc& f = ctx->frames_host[slot];
+  f.depth = depth_dev;
+  f.index = ctx->index_ws + (size_t)slot * ctx->N;
+  f.interval = ctx->interval_ws + (size_t)slot * ctx->N;
+  f.integral = ctx->integral_ws + (size_t)slot * ctx->N * kIntegralChannels;
+  (void)rows;
+  f.rowoff = ctx->rowoff_ws + (size_t)slot * (size_t)std::max(ctx->max_rows, ctx->max_cols);
+  f.cloud = cl;
+}
+int ensure_stats(pwn_hip_ctx* ctx, pwn_hip_cloud* c) {
+  if (!c->d.St) HIPCHK(ctx, hipMalloc(&c->d.St, sizeof(float) * 16 * (size_t)c->d.capacity), PWN_HIP_ERR_ALLOCATION);
+  return PWN_HIP_OK;
+}
+int sync_and_counts(pwn_hip_ctx* ctx, pwn_hip_cloud* const* clouds, int n) {
+  std::vector<int> counts(n);
+  for (int i = 0; i < n; ++i) HIPCHK(ctx, hipMemcpyAsync(&counts[i], clouds[i]->d.count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+  for (int i = 0; i < n; ++i) {
+    if (counts[i] > clouds[i]->d.capacity) return fail(ctx, PWN_HIP_ERR_CAPACITY, "cloud capacity smaller than the number of valid depth pixels");
+    clouds[i]->n_host = counts[i];
+  }
+  collect_stage_times(ctx);
+  return PWN_HIP_OK;
+}
+
+template <typename SRC>
+int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const SRC* const* frames, float depth_scale, int n,
+                       int rows, int cols, pwn_hip_cloud* const* clouds, int keep_stats) {
+  if (!ctx || !p || !frames || !clouds || n < 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (int rc = check_image(ctx, rows, cols)) return rc;
+  const size_t N = (size_t)rows * cols;
+  ctx->stages.clear();
+  const ConvertParams cp = make_convert_params(p, nullptr, rows, cols, keep_stats);
+  const int sub = std::max(1, std::min(ctx->sub_frames, ctx->max_batch));
+  for (int base = 0; base < n; base += sub) {
+    const int m = std::min(sub, n - base);
+    if (base > 0) HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);   // descriptors are reused
+    for (int i = 0; i < m; ++i) {
+      pwn_hip_cloud* c = clouds[base + i];
+      if (!c || !frames[base + i]) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null frame or cloud");
+      if ((size_t)c->d.capacity < 1) return fail(ctx, PWN_HIP_ERR_CAPACITY, "cloud has zero capacity");
+      if (keep_stats) { if (int rc = ensure_stats(ctx, c)) return rc; }
+      c->has_stats = keep_stats != 0;
+      if (c->d.OmN) { (void)hipFree(c->d.OmN); c->d.OmN = nullptr; }
+      make_omega_n_classes(p, c->d);
+      const float* depth_dev = nullptr;
+      if (std::is_same<SRC, uint16_t>::value) {
+        const uint16_t* src = reinterpret_cast<const uint16_t*>(frames[base + i]);
+        const uint16_t* src_dev = src;
+        if (!is_device_ptr(src)) {
+          uint16_t* dst = ctx->raw_ws + (size_t)i * ctx->N;
+          HIPCHK(ctx, hipMemcpyAsync(dst, src, N * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
+          src_dev = dst;
+        }
+        ctx->raw_host[i].src = src_dev;
+        ctx->raw_host[i].dst = ctx->depth_ws + (size_t)i * ctx->N;
+        depth_dev = ctx->raw_host[i].dst;
+      } else {
+        const float* src = reinterpret_cast<const float*>(frames[base + i]);
+        if (is_device_ptr(src)) depth_dev = src;
+        else {
+          float* dst = ctx->depth_ws + (size_t)i * ctx->N;
+          HIPCHK(ctx, hipMemcpyAsync(dst, src, N * sizeof(float), hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
+          depth_dev = dst;
+        }
+      }
+      fill_frame(ctx, i, depth_dev, c->d, rows);
+    }
+    if (std::is_same<SRC, uint16_t>::value) {
+      HIPCHK(ctx, hipMemcpyAsync(ctx->raw_dev, ctx->raw_host, sizeof(RawDesc) * m, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
+      StageTimer t(ctx, "u16_to_f32");
+      hipLaunchKernelGGL(k_u16_to_f32, dim3(std::min<size_t>((N + 255) / 256, 1024), m), dim3(256), 0, ctx->stream, ctx->raw_dev, (int)N, depth_scale);
+    }
+    if (int rc = launch_convert(ctx, cp, m)) return rc;
+  }
+  return sync_and_counts(ctx, clouds, n);
+}
+
+}  // namespace
+
+// ================================================================================================================
+extern "C" {
+
+int pwn_hip_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+const char* pwn_hip_last_error_string(const pwn_hip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+void pwn_hip_default_converter_params(pwn_hip_converter_params* p) {
+  std::memset(p, 0, sizeof(*p));
+  const float K[9] = { 1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.5f, 0.5f, 1.f };   // pinholepointprojector.cpp:6-9
+  std::memcpy(p->K, K, sizeof(K));
+  p->min_distance = 0.01f; p->max_distance = 6.0f;
+  p->world_radius = 0.1f; p->min_image_radius = 10; p->max_image_radius = 30; p->min_points = 50;
+  p->stats_curvature_threshold = 0.02f; p->point_info_curvature_threshold = 0.02f; p->normal_info_curvature_threshold = 0.02f;
+  p->point_flat_diag[0] = 1000.f; p->point_flat_diag[1] = 1.f; p->point_flat_diag[2] = 1.f;
+  for (int i = 0; i < 3; ++i) { p->point_nonflat_diag[i] = 1.f; p->normal_flat_diag[i] = 100.f; p->normal_nonflat_diag[i] = 1.f; }
+  const Mat4 I = mat4_identity();
+  std::memcpy(p->sensor_offset, I.m, sizeof(I.m));
+}
+void pwn_hip_default_aligner_params(pwn_hip_aligner_params* p) {
+  std::memset(p, 0, sizeof(*p));
+  const float K[9] = { 1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.5f, 0.5f, 1.f };
+  std::memcpy(p->K, K, sizeof(K));
+  p->min_distance = 0.01f; p->max_distance = 6.0f;
+  p->rows = 0; p->cols = 0;
+  p->inlier_distance_threshold = 0.5f;
+  p->inlier_normal_angular_threshold = (float)cos(M_PI / 6);
+  p->flat_curvature_threshold = 0.02f; p->inlier_curvature_ratio_threshold = 1.3f;
+  p->inlier_max_chi2 = 9e3f; p->robust_kernel = 1; p->outer_iterations = 10; p->inner_iterations = 1;
+  const Mat4 I = mat4_identity();
+  std::memcpy(p->reference_sensor_offset, I.m, sizeof(I.m));
+  std::memcpy(p->current_sensor_offset, I.m, sizeof(I.m));
+  std::memcpy(p->initial_guess, I.m, sizeof(I.m));
+}
+
+int pwn_hip_ctx_create(pwn_hip_ctx** out, int device, int max_rows, int max_cols, int max_batch) {
+  if (!out || max_rows <= 0 || max_cols <= 0 || max_batch <= 0) return fail(nullptr, PWN_HIP_ERR_INVALID_ARGUMENT, "bad ctx_create argument");
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { (void)hipGetLastError(); return fail(nullptr, PWN_HIP_ERR_NO_DEVICE, "no HIP device available (this library has no CPU fallback)"); }
+  if (device < 0 || device >= ndev) return fail(nullptr, PWN_HIP_ERR_NO_DEVICE, "device index out of range");
+  HIPCHK(nullptr, hipSetDevice(device), PWN_HIP_ERR_NO_DEVICE);
+  pwn_hip_ctx* ctx = new pwn_hip_ctx();
+  ctx->device = device; ctx->max_rows = max_rows; ctx->max_cols = max_cols; ctx->max_batch = max_batch;
+  ctx->N = (size_t)max_rows * max_cols;
+  const size_t N = ctx->N, B = (size_t)max_batch;
+  ctx->nblocks_max = align_nblocks((int)N);
+#define ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc((void**)&(ptr), (bytes)); if (e_ != hipSuccess) { std::string m = std::string("hipMalloc ") + #ptr + ": " + hipGetErrorString(e_); pwn_hip_ctx_destroy(ctx); return fail(nullptr, PWN_HIP_ERR_ALLOCATION, m); } } while (0)
+#define HALLOC(ptr, bytes) do { hipError_t e_ = hipHostMalloc((void**)&(ptr), (bytes)); if (e_ != hipSuccess) { std::string m = std::string("hipHostMalloc ") + #ptr + ": " + hipGetErrorString(e_); pwn_hip_ctx_destroy(ctx); return fail(nullptr, PWN_HIP_ERR_ALLOCATION, m); } } while (0)
+  if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return fail(nullptr, PWN_HIP_ERR_ALLOCATION, "hipStreamCreate failed"); }
+  ctx->stream = ctx->own_stream;
+  ALLOC(ctx->depth_ws, B * N * sizeof(float));
+  ALLOC(ctx->raw_ws, B * N * sizeof(uint16_t));
+  ALLOC(ctx->index_ws, B * N * sizeof(int));
+  ALLOC(ctx->interval_ws, B * N * sizeof(int));
+  ALLOC(ctx->integral_ws, B * N * kIntegralChannels * sizeof(float));
+  ALLOC(ctx->rowoff_ws, B * (size_t)std::max(max_rows, max_cols) * sizeof(int) + 64);
+  ALLOC(ctx->zref_ws, B * N * sizeof(unsigned long long));
+  ALLOC(ctx->zcur_ws, B * N * sizeof(unsigned long long));
+  ALLOC(ctx->partials_ws, B * (size_t)ctx->nblocks_max * kAccN * sizeof(double));
+  ALLOC(ctx->state_ws, B * sizeof(PairState));
+  ALLOC(ctx->frames_dev, B * sizeof(FrameDesc));
+  ALLOC(ctx->pairs_dev, B * sizeof(PairDesc));
+  ALLOC(ctx->raw_dev, B * sizeof(RawDesc));
+  ALLOC(ctx->solve_dev, sizeof(SolveOut));
+  ALLOC(ctx->counters_dev, 16 * sizeof(int));
+  ALLOC(ctx->corr_ws, N * sizeof(int2));
+  ALLOC(ctx->scratch_count, sizeof(int));
+  ALLOC(ctx->io_ws, N * 16 * sizeof(float));
+  HALLOC(ctx->frames_host, B * sizeof(FrameDesc));
+  HALLOC(ctx->pairs_host, B * sizeof(PairDesc));
+  HALLOC(ctx->raw_host, B * sizeof(RawDesc));
+  HALLOC(ctx->state_host, B * sizeof(PairState));
+#undef ALLOC
+#undef HALLOC
+  (void)hipEventCreate(&ctx->t0); (void)hipEventCreate(&ctx->t1);
+  *out = ctx;
+  return PWN_HIP_OK;
+}
+int pwn_hip_ctx_destroy(pwn_hip_ctx* ctx) {
+  if (!ctx) return PWN_HIP_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  void* dev[] = { ctx->depth_ws, ctx->raw_ws, ctx->index_ws, ctx->interval_ws, ctx->integral_ws, ctx->rowoff_ws, ctx->zref_ws, ctx->zcur_ws,
+                  ctx->partials_ws, ctx->state_ws, ctx->frames_dev, ctx->pairs_dev, ctx->raw_dev, ctx->solve_dev, ctx->counters_dev,
+                  ctx->corr_ws, ctx->scratch_count, ctx->io_ws };
+  for (void* p : dev) if (p) (void)hipFree(p);
+  void* host[] = { ctx->frames_host, ctx->pairs_host, ctx->raw_host, ctx->state_host };
+  for (void* p : host) if (p) (void)hipHostFree(p);
+  collect_stage_times(ctx);
+  for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
+  if (ctx->t0) (void)hipEventDestroy(ctx->t0);
+  if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  delete ctx;
+  return PWN_HIP_OK;
+}
+int pwn_hip_ctx_set_stream(pwn_hip_ctx* ctx, void* hip_stream) {
+  if (!ctx) return fail(nullptr, PWN_HIP_ERR_INVALID_ARGUMENT, "null ctx");
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+  ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return PWN_HIP_OK;
+}
+int pwn_hip_ctx_synchronize(pwn_hip_ctx* ctx) {
+  if (!ctx) return fail(nullptr, PWN_HIP_ERR_INVALID_ARGUMENT, "null ctx");
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+  return PWN_HIP_OK;
+}
+int pwn_hip_ctx_set_subbatch(pwn_hip_ctx* ctx, int frames, int pairs) {
+  if (!ctx || frames <= 0 || pairs <= 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "bad subbatch");
+  ctx->sub_frames = std::min(frames, ctx->max_batch); ctx->sub_pairs = std::min(pairs, ctx->max_batch);
+  return PWN_HIP_OK;
+}
+int pwn_hip_set_profiling(pwn_hip_ctx* ctx, int enabled) {
+  if (!ctx) return fail(nullptr, PWN_HIP_ERR_INVALID_ARGUMENT, "null ctx");
+  ctx->profiling = enabled != 0;
+  return PWN_HIP_OK;
+}
+int pwn_hip_last_stage_ms(pwn_hip_ctx* ctx, const char* stage, float* ms, int* launches) {
+  if (!ctx || !stage) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  auto it = ctx->stages.find(stage);
+  if (ms) *ms = it == ctx->stages.end() ? 0.f : it->second.ms;
+  if (launches) *launches = it == ctx->stages.end() ? 0 : it->second.launches;
+  return PWN_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------- clouds
+int pwn_hip_cloud_create(pwn_hip_ctx* ctx, int capacity, pwn_hip_cloud** out) {
+  if (!ctx || !out || capacity <= 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "bad cloud_create argument");
+  HIPCHK(ctx, hipSetDevice(ctx->device), PWN_HIP_ERR_NO_DEVICE);
+  pwn_hip_cloud* c = new pwn_hip_cloud();
+  std::memset(&c->d, 0, sizeof(c->d));
+  c->d.capacity = capacity;
+  const size_t cap = (size_t)capacity;
+  hipError_t e = hipMalloc((void**)&c->d.P, cap * sizeof(float4));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d.Nm, cap * sizeof(float4));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d.Om, cap * 9 * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d.count, sizeof(int));
+  if (e == hipSuccess) e = hipMemsetAsync(c->d.count, 0, sizeof(int), ctx->stream);
+  if (e != hipSuccess) { pwn_hip_cloud_destroy(ctx, c); return fail(ctx, PWN_HIP_ERR_ALLOCATION, std::string("cloud allocation: ") + hipGetErrorString(e)); }
+  *out = c;
+  return PWN_HIP_OK;
+}
+int pwn_hip_cloud_destroy(pwn_hip_ctx* ctx, pwn_hip_cloud* c) {
+  if (!c) return PWN_HIP_OK;
+  if (ctx) (void)hipStreamSynchronize(ctx->stream);
+  void* p[] = { c->d.P, c->d.Nm, c->d.Om, c->d.OmN, c->d.St, c->d.count };
+  for (void* q : p) if (q) (void)hipFree(q);
+  delete c;
+  return PWN_HIP_OK;
+}
+int pwn_hip_cloud_size(pwn_hip_ctx* ctx, const pwn_hip_cloud* c, int* n) {
+  if (!c || !n) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  *n = c->n_host;
+  return PWN_HIP_OK;
+}
+int pwn_hip_cloud_upload(pwn_hip_ctx* ctx, pwn_hip_cloud* c, int n, const float* points, const float* normals, const float* curvature,
+                         const float* omega_p, const float* omega_n) {
+  if (!ctx || !c || n < 0 || !points || !normals || !curvature || !omega_p || !omega_n) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (n > c->d.capacity) return fail(ctx, PWN_HIP_ERR_CAPACITY, "cloud capacity too small");
+  // repack on the host into the device layout (upload is not on the hot path)
+  std::vector<float> hp((size_t)n * 4), hn((size_t)n * 4), hc(n), hop((size_t)n * 16), hon((size_t)n * 16);
+  HIPCHK(ctx, copy_any(hp.data(), points, hp.size() * 4, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, copy_any(hn.data(), normals, hn.size() * 4, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, copy_any(hc.data(), curvature, hc.size() * 4, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, copy_any(hop.data(), omega_p, hop.size() * 4, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, copy_any(hon.data(), omega_n, hon.size() * 4, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_COPY);
+  const size_t cap = (size_t)c->d.capacity;
+  std::vector<float> P((size_t)n * 4), Nm((size_t)n * 4), Om(cap * 9, 0.f), OmN(cap * 9, 0.f);
+  for (int i = 0; i < n; ++i) {
+    P[4 * i] = hp[4 * i]; P[4 * i + 1] = hp[4 * i + 1]; P[4 * i + 2] = hp[4 * i + 2]; P[4 * i + 3] = hc[i];
+    Nm[4 * i] = hn[4 * i]; Nm[4 * i + 1] = hn[4 * i + 1]; Nm[4 * i + 2] = hn[4 * i + 2];
+    const int one = 1; std::memcpy(&Nm[4 * i + 3], &one, 4);
+    for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) {
+      Om[(size_t)(3 * r + q) * cap + i] = hop[(size_t)16 * i + r + 4 * q];      // column-major 4x4 -> plane (r,q)
+      OmN[(size_t)(3 * r + q) * cap + i] = hon[(size_t)16 * i + r + 4 * q];
+    }
+  }
+  if (!c->d.OmN) HIPCHK(ctx, hipMalloc((void**)&c->d.OmN, cap * 9 * sizeof(float)), PWN_HIP_ERR_ALLOCATION);
+  HIPCHK(ctx, hipMemcpy(c->d.P, P.data(), P.size() * 4, hipMemcpyHostToDevice), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipMemcpy(c->d.Nm, Nm.data(), Nm.size() * 4, hipMemcpyHostToDevice), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipMemcpy(c->d.Om, Om.data(), Om.size() * 4, hipMemcpyHostToDevice), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipMemcpy(c->d.OmN, OmN.data(), OmN.size() * 4, hipMemcpyHostToDevice), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipMemcpy(c->d.count, &n, sizeof(int), hipMemcpyHostToDevice), PWN_HIP_ERR_COPY);
+  c->n_host = n; c->has_stats = false;
+  return PWN_HIP_OK;
+}
+int pwn_hip_cloud_download(pwn_hip_ctx* ctx, const pwn_hip_cloud* c, float* points, float* normals, float* curvature, float* omega_p, float* omega_n) {
+  if (!ctx || !c) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  const int n = c->n_host; const size_t cap = (size_t)c->d.capacity;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+  std::vector<float> P((size_t)n * 4), Nm((size_t)n * 4);
+  HIPCHK(ctx, hipMemcpy(P.data(), c->d.P, P.size() * 4, hipMemcpyDeviceToHost), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipMemcpy(Nm.data(), c->d.Nm, Nm.size() * 4, hipMemcpyDeviceToHost), PWN_HIP_ERR_COPY);
+  std::vector<float> hp, hn, hc, hop, hon;
+  if (points) { hp.resize((size_t)n * 4); for (int i = 0; i < n; ++i) { hp[4*i] = P[4*i]; hp[4*i+1] = P[4*i+1]; hp[4*i+2] = P[4*i+2]; hp[4*i+3] = 1.0f; } }
+  if (normals) { hn.resize((size_t)n * 4); for (int i = 0; i < n; ++i) { hn[4*i] = Nm[4*i]; hn[4*i+1] = Nm[4*i+1]; hn[4*i+2] = Nm[4*i+2]; hn[4*i+3] = 0.0f; } }
+  if (curvature) { hc.resize(n); for (int i = 0; i < n; ++i) hc[i] = P[4*i+3]; }
+  if (omega_p || omega_n) {
+    std::vector<float> Om(cap * 9), OmN;
+    HIPCHK(ctx, hipMemcpy(Om.data(), c->d.Om, Om.size() * 4, hipMemcpyDeviceToHost), PWN_HIP_ERR_COPY);
+    if (c->d.OmN) { OmN.resize(cap * 9); HIPCHK(ctx, hipMemcpy(OmN.data(), c->d.OmN, OmN.size() * 4, hipMemcpyDeviceToHost), PWN_HIP_ERR_COPY); }
+    if (omega_p) hop.assign((size_t)n * 16, 0.f);
+    if (omega_n) hon.assign((size_t)n * 16, 0.f);
+    for (int i = 0; i < n; ++i) {
+      int cls; std::memcpy(&cls, &Nm[4 * i + 3], 4);
+      for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) {
+        if (omega_p) hop[(size_t)16 * i + r + 4 * q] = Om[(size_t)(3 * r + q) * cap + i];
+        if (omega_n) {
+          float v = 0.f;
+          if (c->d.OmN) v = OmN[(size_t)(3 * r + q) * cap + i];
+          else if (cls == 1) v = c->d.omN[0][3 * r + q];
+          else if (cls == 2) v = c->d.omN[1][3 * r + q];
+          hon[(size_t)16 * i + r + 4 * q] = v;
+        }
+      }
+    }
+  }
+  if (points) HIPCHK(ctx, hipMemcpy(points, hp.data(), hp.size() * 4, hipMemcpyDefault), PWN_HIP_ERR_COPY);
+  if (normals) HIPCHK(ctx, hipMemcpy(normals, hn.data(), hn.size() * 4, hipMemcpyDefault), PWN_HIP_ERR_COPY);
+  if (curvature) HIPCHK(ctx, hipMemcpy(curvature, hc.data(), hc.size() * 4, hipMemcpyDefault), PWN_HIP_ERR_COPY);
+  if (omega_p) HIPCHK(ctx, hipMemcpy(omega_p, hop.data(), hop.size() * 4, hipMemcpyDefault), PWN_HIP_ERR_COPY);
+  if (omega_n) HIPCHK(ctx, hipMemcpy(omega_n, hon.data(), hon.size() * 4, hipMemcpyDefault), PWN_HIP_ERR_COPY);
+  return PWN_HIP_OK;
+}
+int pwn_hip_cloud_download_stats(pwn_hip_ctx* ctx, const pwn_hip_cloud* c, float* stats, float* eigenvalues, int* npoints) {
+  if (!ctx || !c) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (!c->has_stats || !c->d.St) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "cloud was not converted with keep_stats");
+  const int n = c->n_host;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+  std::vector<float> St((size_t)n * 16);
+  HIPCHK(ctx, hipMemcpy(St.data(), c->d.St, St.size() * 4, hipMemcpyDeviceToHost), PWN_HIP_ERR_COPY);
+  std::vector<float> hs, he; std::vector<int> hn;
+  if (stats) hs.assign((size_t)n * 16, 0.f);
+  if (eigenvalues) he.resize((size_t)n * 3);
+  if (npoints) hn.resize(n);
+  for (int i = 0; i < n; ++i) {
+    const float* s = &St[(size_t)16 * i];
+    if (stats) {
+      float* o = &hs[(size_t)16 * i];
+      for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) o[r + 4 * q] = s[r + 3 * q];
+      o[12] = s[12]; o[13] = s[13]; o[14] = s[14]; o[15] = 1.0f;
+    }
+    if (eigenvalues) { he[3 * i] = s[9]; he[3 * i + 1] = s[10]; he[3 * i + 2] = s[11]; }
+    if (npoints) hn[i] = (int)s[15];
+  }
+  if (stats) HIPCHK(ctx, hipMemcpy(stats, hs.data(), hs.size() * 4, hipMemcpyDefault), PWN_HIP_ERR_COPY);
+  if (eigenvalues) HIPCHK(ctx, hipMemcpy(eigenvalues, he.data(), he.size() * 4, hipMemcpyDefault), PWN_HIP_ERR_COPY);
+  if (npoints) HIPCHK(ctx, hipMemcpy(npoints, hn.data(), hn.size() * 4, hipMemcpyDefault), PWN_HIP_ERR_COPY);
+  return PWN_HIP_OK;
+}
+int pwn_hip_cloud_transform_in_place(pwn_hip_ctx* ctx, pwn_hip_cloud* c, const float T[16]) {
+  if (!ctx || !c || !T) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  const Mat4 m = forced(T);
+  if (is_identity(m)) return PWN_HIP_OK;                       // cloud.cpp:176
+  if (!c->d.OmN) {                                             // class matrices transform with the cloud
+    for (int k = 0; k < 2; ++k) {
+      float* om = c->d.omN[k]; float t1[9], o2[9];
+      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) t1[3 * i + j] = dot3seq(m(i,0), om[0 + j], m(i,1), om[3 + j], m(i,2), om[6 + j]);
+      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) o2[3 * i + j] = dot3seq(t1[3 * i], m(j,0), t1[3 * i + 1], m(j,1), t1[3 * i + 2], m(j,2));
+      std::memcpy(om, o2, sizeof(o2));
+    }
+  }
+  hipLaunchKernelGGL(k_cloud_transform, dim3((c->d.capacity + 255) / 256), dim3(256), 0, ctx->stream, c->d, m);
+  HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+  c->has_stats = false;
+  return PWN_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------ input conditioning
+int pwn_hip_depth_u16_to_f32(pwn_hip_ctx* ctx, const uint16_t* src, float* dst, int n, float scale) {
+  if (!ctx || !src || !dst || n < 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if ((size_t)n > ctx->N * ctx->max_batch) return fail(ctx, PWN_HIP_ERR_CAPACITY, "image larger than the context workspaces");
+  const uint16_t* s = src; float* d = dst;
+  if (!is_device_ptr(src)) { HIPCHK(ctx, hipMemcpyAsync(ctx->raw_ws, src, (size_t)n * 2, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY); s = ctx->raw_ws; }
+  if (!is_device_ptr(dst)) d = ctx->depth_ws;
+  ctx->raw_host[0].src = s; ctx->raw_host[0].dst = d;
+  HIPCHK(ctx, hipMemcpyAsync(ctx->raw_dev, ctx->raw_host, sizeof(RawDesc), hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
+  hipLaunchKernelGGL(k_u16_to_f32, dim3(std::min((n + 255) / 256, 2048), 1), dim3(256), 0, ctx->stream, ctx->raw_dev, n, scale);
+  HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
+  if (d != dst) HIPCHK(ctx, hipMemcpyAsync(dst, d, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+  return PWN_HIP_OK;
+}
+int pwn_hip_depth_f32_to_u16(pwn_hip_ctx* ctx, const float* src, uint16_t* dst, int n, float scale) {
+  if (!ctx || !src || !dst || n < 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if ((size_t)n > ctx->N * ctx->max_batch) return fail(ctx, PWN_HIP_ERR_CAPACITY, "image larger than the context workspaces");
+  const float* s = src; uint16_t* d = dst;
+  if (!is_device_ptr(src)) { HIPCHK(ctx, hipMemcpyAsync(ctx->depth_ws, src, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY); s = ctx->depth_ws; }
+  if (!is_device_ptr(dst)) d = ctx->raw_ws;
+  hipLaunchKernelGGL(k_f32_to_u16, dim3(std::min((n + 255) / 256, 2048)), dim3(256), 0, ctx->stream, s, d, n, scale);
+  HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
+  if (d != dst) HIPCHK(ctx, hipMemcpyAsync(dst, d, (size_t)n * 2, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+  return PWN_HIP_OK;
+}
+int pwn_hip_depth_scale(pwn_hip_ctx* ctx, const float* src, int rows, int cols, int step, float max_depth_cov, float* dst) {
+  if (!ctx || !src || !dst || step <= 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "bad argument");
+  if (int rc = check_image(ctx, rows, cols)) return rc;
+  const size_t n = (size_t)rows * cols; const int orows = rows / step, ocols = cols / step; const size_t on = (size_t)orows * ocols;
+  const float* s = src; float* d = dst;
+  if (!is_device_ptr(src)) { HIPCHK(ctx, hipMemcpyAsync(ctx->depth_ws, src, n * 4, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY); s = ctx->depth_ws; }
+  if (!is_device_ptr(dst)) d = ctx->io_ws;
+  if (on > 0) hipLaunchKernelGGL(k_depth_scale, dim3((unsigned)((on + 255) / 256)), dim3(256), 0, ctx->stream, s, rows, cols, step, max_depth_cov, d);
+  HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
+  if (d != dst) HIPCHK(ctx, hipMemcpyAsync(dst, d, on * 4, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+  return PWN_HIP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- converter stages
+static int stage_depth(pwn_hip_ctx* ctx, const float* depth, size_t N, const float** out) {
+  if (is_device_ptr(depth)) { *out = depth; return PWN_HIP_OK; }
+  HIPCHK(ctx, hipMemcpyAsync(ctx->depth_ws, depth, N * 4, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
+  *out = ctx->depth_ws;
+  return PWN_HIP_OK;
+}
+int pwn_hip_unproject(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float T[16], const float* depth, int rows, int cols,
+                      pwn_hip_cloud* cloud, int* index_image) {
+  if (!ctx || !p || !depth || !cloud) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (int rc = check_image(ctx, rows, cols)) return rc;
+  const size_t N = (size_t)rows * cols;
+  const ConvertParams cp = make_convert_params(p, T, rows, cols, 0);
+  const float* d = nullptr;
+  if (int rc = stage_depth(ctx, depth, N, &d)) return rc;
+  HIPCHK(ctx, hipMemsetAsync(cloud->d.Nm, 0, sizeof(float4) * (size_t)cloud->d.capacity, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipMemsetAsync(cloud->d.Om, 0, sizeof(float) * 9 * (size_t)cloud->d.capacity, ctx->stream), PWN_HIP_ERR_COPY);
+  fill_frame(ctx, 0, d, cloud->d, rows);
+  HIPCHK(ctx, hipMemcpyAsync(ctx->frames_dev, ctx->frames_host, sizeof(FrameDesc), hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
+  hipLaunchKernelGGL(k_row_count, dim3(rows, 1), dim3(256), 0, ctx->stream, ctx->frames_dev, cp);
+  hipLaunchKernelGGL(k_row_offsets, dim3(1), dim3(1024), 0, ctx->stream, ctx->frames_dev, rows);
+  hipLaunchKernelGGL(k_unproject, dim3(rows, 1), dim3(256), 0, ctx->stream, ctx->frames_dev, cp);
+  HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
+  if (index_image) HIPCHK(ctx, copy_any(index_image, ctx->frames_host[0].index, N * 4, ctx->stream), PWN_HIP_ERR_COPY);
+  cloud->has_stats = false;
+  pwn_hip_cloud* arr[1] = { cloud };
+  return sync_and_counts(ctx, arr, 1);
+}
+int pwn_hip_project_intervals(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float* depth, int rows, int cols, int* interval_image) {
+  if (!ctx || !p || !depth || !interval_image) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (int rc = check_image(ctx, rows, cols)) return rc;
+  const size_t N = (size_t)rows * cols;
+  const ConvertParams cp = make_convert_params(p, nullptr, rows, cols, 0);
+  const float* d = nullptr;
+  if (int rc = stage_depth(ctx, depth, N, &d)) return rc;
+  CloudDev none; std::memset(&none, 0, sizeof(none)); none.count = ctx->scratch_count; none.capacity = 0;
+  fill_frame(ctx, 0, d, none, rows);
+  HIPCHK(ctx, hipMemcpyAsync(ctx->frames_dev, ctx->frames_host, sizeof(FrameDesc), hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
+  hipLaunchKernelGGL(k_row_count, dim3(rows, 1), dim3(256), 0, ctx->stream, ctx->frames_dev, cp);
+  hipLaunchKernelGGL(k_row_offsets, dim3(1), dim3(1024), 0, ctx->stream, ctx->frames_dev, rows);
+  hipLaunchKernelGGL(k_unproject, dim3(rows, 1), dim3(256), 0, ctx->stream, ctx->frames_dev, cp);
+  HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
+  HIPCHK(ctx, copy_any(interval_image, ctx->frames_host[0].interval, N * 4, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+  return PWN_HIP_OK;
+}
+int pwn_hip_integral_image(pwn_hip_ctx* ctx, const int* index_image, const pwn_hip_cloud* cloud, int rows, int cols, float* out) {
+  if (!ctx || !index_image || !cloud || !out) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (int rc = check_image(ctx, rows, cols)) return rc;
+  const size_t N = (size_t)rows * cols;
+  fill_frame(ctx, 0, nullptr, cloud->d, rows);
+  HIPCHK(ctx, copy_any(ctx->frames_host[0].index, index_image, N * 4, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipMemcpyAsync(ctx->frames_dev, ctx->frames_host, sizeof(FrameDesc), hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
+  hipLaunchKernelGGL(k_integral_rows, dim3((rows + kIR_Rows - 1) / kIR_Rows, 1), dim3(256), 0, ctx->stream, ctx->frames_dev, rows, cols);
+  hipLaunchKernelGGL(k_integral_cols, dim3((cols + 255) / 256, kIntegralChannels, 1), dim3(256), 0, ctx->stream, ctx->frames_dev, rows, cols);
+  HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
+  HIPCHK(ctx, copy_any(out, ctx->frames_host[0].integral, N * kIntegralChannels * 4, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+  return PWN_HIP_OK;
+}
+int pwn_hip_convert(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float* depth, int rows, int cols, pwn_hip_cloud* cloud,
+                    int* index_image, int* interval_image, int keep_stats) {
+  const float* frames[1] = { depth };
+  pwn_hip_cloud* clouds[1] = { cloud };
+  if (int rc = convert_batch_impl<float>(ctx, p, frames, 0.f, 1, rows, cols, clouds, keep_stats)) return rc;
+  const size_t N = (size_t)rows * cols;
+  if (index_image) HIPCHK(ctx, hipMemcpy(index_image, ctx->frames_host[0].index, N * 4, hipMemcpyDefault), PWN_HIP_ERR_COPY);
+  if (interval_image) HIPCHK(ctx, hipMemcpy(interval_image, ctx->frames_host[0].interval, N * 4, hipMemcpyDefault), PWN_HIP_ERR_COPY);
+  return PWN_HIP_OK;
+}
+int pwn_hip_convert_batch(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float* const* depth_frames, int n, int rows, int cols,
+                          pwn_hip_cloud* const* clouds) {
+  return convert_batch_impl<float>(ctx, p, depth_frames, 0.f, n, rows, cols, clouds, 0);
+}
+int pwn_hip_convert_batch_u16(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const uint16_t* const* raw_frames, float depth_scale, int n,
+                              int rows, int cols, pwn_hip_cloud* const* clouds) {
+  return convert_batch_impl<uint16_t>(ctx, p, raw_frames, depth_scale, n, rows, cols, clouds, 0);
+}
+
+// ------------------------------------------------------------------------------------------------ aligner stages
+int pwn_hip_project(pwn_hip_ctx* ctx, const float K[9], const float T[16], float min_distance, float max_distance, int rows, int cols,
+                    const pwn_hip_cloud* cloud, int* index_image, float* depth_image) {
+  if (!ctx || !K || !T || !cloud) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (int rc = check_image(ctx, rows, cols)) return rc;
+  const size_t N = (size_t)rows * cols;
+  Mat4 KRt, iKRt; Mat3 iK;
+  projector_matrices(mat3_from(K), mat4_from(T), KRt, iKRt, iK);
+  HIPCHK(ctx, hipMemsetAsync(ctx->zref_ws, 0xFF, N * 8, ctx->stream), PWN_HIP_ERR_COPY);
+  { StageTimer t(ctx, "project");
+    hipLaunchKernelGGL(k_project_single, dim3((cloud->d.capacity + 255) / 256), dim3(256), 0, ctx->stream, cloud->d, KRt, min_distance, max_distance, rows, cols, ctx->zref_ws); }
+  int* di = index_image ? (is_device_ptr(index_image) ? index_image : ctx->index_ws) : nullptr;
+  float* dd = depth_image ? (is_device_ptr(depth_image) ? depth_image : ctx->depth_ws) : nullptr;
+  hipLaunchKernelGGL(k_zbuf_resolve, dim3((unsigned)std::min<size_t>((N + 255) / 256, 2048)), dim3(256), 0, ctx->stream, ctx->zref_ws, (int)N, di, dd);
+  HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
+  if (index_image && di != index_image) HIPCHK(ctx, hipMemcpyAsync(index_image, di, N * 4, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
+  if (depth_image && dd != depth_image) HIPCHK(ctx, hipMemcpyAsync(depth_image, dd, N * 4, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+  ctx->img_valid = false;
+  collect_stage_times(ctx);
+  return PWN_HIP_OK;
+}
+int pwn_hip_correspondences(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, const pwn_hip_cloud* ref, const pwn_hip_cloud* cur,
+                            const int* ref_index, const int* cur_index, const float T[16], int* corr, int* n_corr, int* n_cand) {
+  if (!ctx || !p || !ref || !cur || !ref_index || !cur_index || !T || !corr || !n_corr) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (int rc = check_image(ctx, p->rows, p->cols)) return rc;
+  const size_t N = (size_t)p->rows * p->cols;
+  const AlignParams ap = make_align_params(p);
+  int* ri = ctx->index_ws; int* ci = ctx->interval_ws;
+  HIPCHK(ctx, copy_any(ri, ref_index, N * 4, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, copy_any(ci, cur_index, N * 4, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipMemsetAsync(ctx->counters_dev, 0, 16 * sizeof(int), ctx->stream), PWN_HIP_ERR_COPY);
+  hipLaunchKernelGGL(k_correspondence_image, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, ref->d, cur->d, ri, ci, ap, forced(T), ctx->corr_ws, ctx->counters_dev);
+  HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
+  std::vector<int2> img(N); int cand = 0;
+  HIPCHK(ctx, hipMemcpyAsync(img.data(), ctx->corr_ws, N * sizeof(int2), hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipMemcpyAsync(&cand, ctx->counters_dev, sizeof(int), hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+  std::vector<int> out(2 * N, -1);
+  int C = 0;
+  for (size_t i = 0; i < N; ++i) if (img[i].x >= 0) { out[2 * C] = img[i].x; out[2 * C + 1] = img[i].y; ++C; }   // row-major order
+  HIPCHK(ctx, hipMemcpy(corr, out.data(), 2 * N * sizeof(int), hipMemcpyDefault), PWN_HIP_ERR_COPY);
+  *n_corr = C;
+  if (n_cand) *n_cand = cand;
+  return PWN_HIP_OK;
+}
+int pwn_hip_linearize(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, const pwn_hip_cloud* ref, const pwn_hip_cloud* cur, const int* corr,
+                      int C, const float T[16], float* H, float* b, float* error, int* inliers) {
+  if (!ctx || !p || !ref || !cur || (!corr && C > 0) || !T || C < 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if ((size_t)C > ctx->N) return fail(ctx, PWN_HIP_ERR_CAPACITY, "more correspondences than pixels");
+  const AlignParams ap = make_align_params(p);
+  if (C > 0) HIPCHK(ctx, copy_any(ctx->corr_ws, corr, (size_t)C * sizeof(int2), ctx->stream), PWN_HIP_ERR_COPY);
+  const int nb = std::max(1, align_nblocks(C));
+  { StageTimer t(ctx, "corr_linearize");
+    hipLaunchKernelGGL(k_linearize_list, dim3(nb), dim3(kAlignBlock), 0, ctx->stream, ref->d, cur->d, ctx->corr_ws, C, ap, forced(T), ctx->partials_ws); }
+  hipLaunchKernelGGL(k_reduce_only, dim3(1), dim3(64), 0, ctx->stream, ctx->partials_ws, nb, ctx->solve_dev);
+  HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
+  SolveOut so;
+  HIPCHK(ctx, hipMemcpyAsync(&so, ctx->solve_dev, sizeof(so), hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+  if (H) std::memcpy(H, so.H, sizeof(so.H));
+  if (b) std::memcpy(b, so.b, sizeof(so.b));
+  if (error) *error = so.chi2;
+  if (inliers) *inliers = so.inliers;
+  collect_stage_times(ctx);
+  return PWN_HIP_OK;
+}
+
+int pwn_hip_align_batch(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* refs, pwn_hip_cloud* const* curs,
+                        const float* guesses, pwn_hip_align_result* results) {
+  if (!ctx || !p || !refs || !curs || !results || n < 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (int rc = check_image(ctx, p->rows, p->cols)) return rc;
+  const int nit = p->outer_iterations * p->inner_iterations;
+  if (p->outer_iterations < 0 || p->inner_iterations < 0 || nit > PWN_HIP_MAX_ITERATIONS)
+    return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "outer*inner iterations exceeds PWN_HIP_MAX_ITERATIONS");
+  const int N = p->rows * p->cols;
+  const AlignParams ap = make_align_params(p);
+  const int nb = align_nblocks(N);
+  ctx->stages.clear();
+  const int sub = std::max(1, std::min(ctx->sub_pairs, ctx->max_batch));
+  HIPCHK(ctx, hipEventRecord(ctx->t0, ctx->stream), PWN_HIP_ERR_LAUNCH);
+  int maxcap_ref = 0, maxcap_cur = 0;
+  for (int base = 0; base < n; base += sub) {
+    const int m = std::min(sub, n - base);
+    if (base > 0) HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);   // descriptor / state staging buffers are reused
+    maxcap_ref = 0; maxcap_cur = 0;
+    for (int i = 0; i < m; ++i) {
+      const pwn_hip_cloud* r = refs[base + i]; const pwn_hip_cloud* c = curs[base + i];
+      if (!r || !c) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null cloud in batch");
+      PairDesc& pd = ctx->pairs_host[i];
+      pd.ref = r->d; pd.cur = c->d;
+      pd.zref = ctx->zref_ws + (size_t)i * ctx->N;
+      pd.zcur = ctx->zcur_ws + (size_t)i * ctx->N;
+      pd.partials = ctx->partials_ws + (size_t)i * ctx->nblocks_max * kAccN;
+      pd.state = ctx->state_ws + i;
+      maxcap_ref = std::max(maxcap_ref, r->d.capacity); maxcap_cur = std::max(maxcap_cur, c->d.capacity);
+      // initial state: aligner.cpp:60-64,72-73,79,84
+      PairState& st = ctx->state_host[i];
+      std::memset(&st, 0, sizeof(st));
+      Mat4 T = mat4_from(guesses ? guesses + 16 * (size_t)(base + i) : p->initial_guess);
+      set_last_row(T);
+      st.T = T;
+      st.invTcorr = iso_inverse(T);
+      st.invT = st.invTcorr; set_last_row(st.invT);
+      Mat4 iKRt; Mat3 iK;
+      projector_matrices(ap.K, iso_mul(T, ap.refOffset), st.KRt, iKRt, iK);
+      projector_matrices(ap.K, mat4_from(p->current_sensor_offset), st.KRtCur, iKRt, iK);
+      st.it = 0;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pairs_dev, ctx->pairs_host, sizeof(PairDesc) * m, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->state_ws, ctx->state_host, sizeof(PairState) * m, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
+    // z-buffers start empty; slots are contiguous
+    HIPCHK(ctx, hipMemsetAsync(ctx->zref_ws, 0xFF, (size_t)m * ctx->N * 8, ctx->stream), PWN_HIP_ERR_COPY);
+    HIPCHK(ctx, hipMemsetAsync(ctx->zcur_ws, 0xFF, (size_t)m * ctx->N * 8, ctx->stream), PWN_HIP_ERR_COPY);
+    { StageTimer t(ctx, "project");
+      hipLaunchKernelGGL(k_project, dim3((maxcap_cur + 255) / 256, m), dim3(256), 0, ctx->stream, ctx->pairs_dev, ap, 1); }
+    for (int i = 0; i < p->outer_iterations; ++i) {
+      { StageTimer t(ctx, "project");
+        hipLaunchKernelGGL(k_project, dim3((maxcap_ref + 255) / 256, m), dim3(256), 0, ctx->stream, ctx->pairs_dev, ap, 0); }
+      for (int k = 0; k < p->inner_iterations; ++k) {
+        const bool lastInner = (k == p->inner_iterations - 1);
+        const bool lastOuter = (i == p->outer_iterations - 1);
+        // the reference z-buffer is consumed (reset) by the last inner pass of every outer iteration but the final one
+        const int keepZ = (!lastInner || lastOuter) ? 1 : 0;
+        { StageTimer t(ctx, "corr_linearize");
+          hipLaunchKernelGGL(k_corr_linearize, dim3(nb, m), dim3(kAlignBlock), 0, ctx->stream, ctx->pairs_dev, ap, keepZ); }
+        { StageTimer t(ctx, "solve");
+          hipLaunchKernelGGL(k_solve_update, dim3(m), dim3(64), 0, ctx->stream, ctx->pairs_dev, ap, nb, lastInner ? 1 : 0); }
+      }
+    }
+    HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->state_host, ctx->state_ws, sizeof(PairState) * m, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+    for (int i = 0; i < m; ++i) {
+      const PairState& st = ctx->state_host[i];
+      pwn_hip_align_result& r = results[base + i];
+      std::memset(&r, 0, sizeof(r));
+      std::memcpy(r.T, st.T.m, sizeof(r.T));
+      r.iterations = st.it;
+      for (int k = 0; k < st.it && k < PWN_HIP_MAX_ITERATIONS; ++k) {
+        r.chi2[k] = st.chi2[k]; r.iter_inliers[k] = st.inliers[k]; r.iter_correspondences[k] = st.ncorr[k]; r.iter_candidates[k] = st.ncand[k];
+      }
+      if (st.it > 0) { r.error = st.chi2[st.it - 1]; r.inliers = st.inliers[st.it - 1]; }
+      r.n_reference = refs[base + i]->n_host; r.n_current = curs[base + i]->n_host;
+    }
+  }
+  HIPCHK(ctx, hipEventRecord(ctx->t1, ctx->stream), PWN_HIP_ERR_LAUNCH);
+  HIPCHK(ctx, hipEventSynchronize(ctx->t1), PWN_HIP_ERR_LAUNCH);
+  float ms = 0.f; (void)hipEventElapsedTime(&ms, ctx->t0, ctx->t1);
+  for (int i = 0; i < n; ++i) results[i].total_time_ms = n > 0 ? ms / n : 0.f;
+  ctx->img_rows = p->rows; ctx->img_cols = p->cols; ctx->img_valid = n > 0;
+  collect_stage_times(ctx);
+  return PWN_HIP_OK;
+}
+int pwn_hip_align(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, const pwn_hip_cloud* ref, const pwn_hip_cloud* cur, pwn_hip_align_result* result) {
+  pwn_hip_cloud* r[1] = { const_cast<pwn_hip_cloud*>(ref) };
+  pwn_hip_cloud* c[1] = { const_cast<pwn_hip_cloud*>(cur) };
+  return pwn_hip_align_batch(ctx, p, 1, r, c, nullptr, result);
+}
+int pwn_hip_align_images(pwn_hip_ctx* ctx, int* ref_index, float* ref_depth, int* cur_index, float* cur_depth) {
+  if (!ctx) return fail(nullptr, PWN_HIP_ERR_INVALID_ARGUMENT, "null ctx");
+  if (!ctx->img_valid) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "no alignment has run on this context");
+  const size_t N = (size_t)ctx->img_rows * ctx->img_cols;
+  for (int pass = 0; pass < 2; ++pass) {
+    int* oi = pass == 0 ? ref_index : cur_index; float* od = pass == 0 ? ref_depth : cur_depth;
+    if (!oi && !od) continue;
+    const unsigned long long* z = pass == 0 ? ctx->zref_ws : ctx->zcur_ws;   // slot 0 = last pair of the last sub-batch... single align: the pair
+    int* di = oi ? (is_device_ptr(oi) ? oi : ctx->index_ws) : nullptr;
+    float* dd = od ? (is_device_ptr(od) ? od : ctx->depth_ws) : nullptr;
+    hipLaunchKernelGGL(k_zbuf_resolve, dim3((unsigned)std::min<size_t>((N + 255) / 256, 2048)), dim3(256), 0, ctx->stream, z, (int)N, di, dd);
+    HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
+    if (oi && di != oi) HIPCHK(ctx, hipMemcpyAsync(oi, di, N * 4, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
+    if (od && dd != od) HIPCHK(ctx, hipMemcpyAsync(od, dd, N * 4, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+  }
+  return PWN_HIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------- helpers
+void pwn_hip_projector_matrices(const float K[9], const float T[16], float KRt[16], float iKRt[16], float iK[9]) {
+  Mat4 a, b; Mat3 c;
+  projector_matrices(mat3_from(K), mat4_from(T), a, b, c);
+  if (KRt) std::memcpy(KRt, a.m, sizeof(a.m));
+  if (iKRt) std::memcpy(iKRt, b.m, sizeof(b.m));
+  if (iK) std::memcpy(iK, c.m, sizeof(c.m));
+}
+void pwn_hip_v2t(const float v[6], float T[16]) { const Mat4 t = v2t(v); std::memcpy(T, t.m, sizeof(t.m)); }
+void pwn_hip_t2v(const float T[16], float v[6]) { t2v(mat4_from(T), v); }
+
+}  // extern "C"

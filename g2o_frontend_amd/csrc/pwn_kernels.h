@@ -1,0 +1,805 @@
+// pwn_kernels.h -- hand-written gfx950 kernels of the PWN dense-registration path.
+//
+// One kernel per stage of the reference's CPU path (g2o_frontend/pwn_core/, cited per kernel).
+// All kernels are batched: blockIdx.y selects the frame / pair, whose buffers are described by a
+// FrameDesc / PairDesc record in device memory.  Layout in HBM is SoA:
+//   cloud:  P[i]  = float4(x, y, z, curvature)            (Point + Stats::curvature())
+//           Nm[i] = float4(nx, ny, nz, bits(omegaN class)) (Normal; class 0 = zero, 1 = flat, 2 = non-flat)
+//           Om[k*cap + i], k = 3*r + c                     (point information matrix, 9 planes)
+//   images: row-major int32 / float32, lanes along image x (row-coalesced loads)
+//   integral image: 10 planes [ch][rows][cols] (x y z n xx xy xz yy yz zz)
+//   z-buffer: uint64 per pixel = float_bits(depth) << 32 | point index; empty = ~0
+// Arithmetic follows the reference's evaluation order (left-to-right inner products, no FMA:
+// compiled with -ffp-contract=off) so integer outputs are bit-exact and fp32 outputs differ from
+// the CPU path only through libm-vs-ocml trig and summation order of the H/b reduction.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "pwn_math.h"
+
+namespace pwnhip {
+
+constexpr int kMaxIter = 64;
+constexpr int kIntegralChannels = 10;
+constexpr int kAccN = 37;              // Htt9 Htr9 Hrr9 bt3 br3 chi2 inliers C K
+constexpr int kPixPerThread = 4;
+constexpr int kAlignBlock = 256;
+constexpr unsigned long long kZEmpty = ~0ull;
+
+struct CloudDev {
+  float4* P;
+  float4* Nm;
+  float*  Om;        // [9][capacity]
+  float*  OmN;       // optional [9][capacity] full normal information matrices (uploaded clouds), else nullptr
+  float*  St;        // optional [capacity][16] stats: U(9, column-major) eigenvalues(3) mean(3) n(1)
+  int*    count;
+  int     capacity;
+  float   omN[2][9]; // class matrices (row-major 3x3): [0] flat, [1] non-flat
+};
+
+struct FrameDesc {
+  const float* depth;
+  int* index;
+  int* interval;
+  float* integral;   // [10][rows*cols]
+  int* rowoff;       // [rows]
+  CloudDev cloud;
+};
+
+struct ConvertParams {
+  int rows, cols;
+  Mat4 iKRt;
+  float ivx, ivy;            // K*(R,R,0): pixels-per-metre of the world radius at unit depth
+  float minD, maxD;
+  int minRadius, maxRadius, minPoints;
+  float statsCurvThr, pointInfoCurvThr, normalInfoCurvThr;
+  float pFlat[3], pNonFlat[3];
+  int hasOffset;
+  Mat4 offset;               // sensor offset with last row forced
+  int keepStats;
+};
+
+struct PairState {
+  Mat4 T;          // Aligner::_T
+  Mat4 invTcorr;   // _T.inverse() handed to CorrespondenceFinder::compute
+  Mat4 invT;       // Linearizer::_T
+  Mat4 KRt;        // projector matrix of the next reference projection
+  Mat4 KRtCur;     // projector matrix of the current-cloud projection
+  int   it;
+  int   pad[3];
+  float chi2[kMaxIter];
+  int   inliers[kMaxIter];
+  int   ncorr[kMaxIter];
+  int   ncand[kMaxIter];
+};
+
+struct PairDesc {
+  CloudDev ref, cur;
+  unsigned long long* zref;
+  unsigned long long* zcur;
+  double* partials;        // [nblocks][kAccN]
+  PairState* state;
+};
+
+struct AlignParams {
+  int rows, cols;
+  Mat3 K;
+  Mat4 refOffset;
+  float minD, maxD;
+  float sqDist, normalThr, flatThr, minRatio, maxRatio;
+  float maxChi2;
+  int robust;
+};
+
+// ------------------------------------------------------------------------------------------------------------------
+// small device helpers
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+
+// ------------------------------------------------------------------------------------------------------------------
+// DepthImage_convert_16UC1_to_32FC1 (pwn_core/pwn_static.cpp:54-68).  grid.y = frame
+struct RawDesc { const uint16_t* src; float* dst; };
+__global__ void k_u16_to_f32(const RawDesc* __restrict__ d, int n, float scale) {
+  const RawDesc rd = d[blockIdx.y];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const uint16_t s = rd.src[i];
+    rd.dst[i] = s ? scale * (float)s : 0.0f;
+  }
+}
+// DepthImage_convert_32FC1_to_16UC1 (pwn_core/pwn_static.cpp:38-52)
+__global__ void k_f32_to_u16(const float* __restrict__ src, uint16_t* __restrict__ dst, int n, float scale) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const float f = src[i];
+    dst[i] = (f < FLT_MAX) ? (uint16_t)(scale * f) : (uint16_t)0;
+  }
+}
+// DepthImage_scale (pwn_core/pwn_static.cpp:5-36): one thread per destination pixel
+__global__ void k_depth_scale(const float* __restrict__ src, int srows, int scols, int step, float maxCov, float* __restrict__ dst) {
+  const int rows = srows / step, cols = scols / step;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int r = i / cols, c = i % cols;
+  float acc = 0, acc2 = 0; int np = 0;
+  const int sr = r * step, sc = c * step;
+  for (int a = 0; a < step; ++a)
+    for (int b = 0; b < step; ++b)
+      if (sr + a < srows && sc + b < scols) {
+        const float f = src[(size_t)(sr + a) * scols + sc + b];
+        acc += f; acc2 += f * f; np += f > 0;
+      }
+  float out = 0.f;
+  if (np) {
+    const float mu = acc / np;
+    const float sigma = acc2 / np - mu * mu;
+    if (!(sigma > maxCov)) out = mu;
+  }
+  dst[i] = out;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Ordered compaction, step 1: valid pixels per image row.  grid = (rows, frames), block = 256.
+// validity test = PinholePointProjector::_unProject (pwn_core/pinholepointprojector.h:246-248)
+__global__ void __launch_bounds__(256) k_row_count(const FrameDesc* __restrict__ frames, ConvertParams cp) {
+  const FrameDesc& f = frames[blockIdx.y];
+  const int r = blockIdx.x;
+  const float* row = f.depth + (size_t)r * cp.cols;
+  int cnt = 0;
+  for (int c = threadIdx.x; c < cp.cols; c += 256) {
+    const float d = row[c];
+    cnt += !(d < cp.minD || d > cp.maxD);
+  }
+  __shared__ int s[4];
+  float t = wave_sum((float)cnt);           // <= 64*N small ints: exact in fp32
+  if (lane_id() == 0) s[threadIdx.x >> 6] = (int)t;
+  __syncthreads();
+  if (threadIdx.x == 0) f.rowoff[r] = s[0] + s[1] + s[2] + s[3];
+}
+// step 2: exclusive scan of the row counts (in place) + total.  grid = frames, block = 1024
+__global__ void __launch_bounds__(1024) k_row_offsets(const FrameDesc* __restrict__ frames, int rows) {
+  const FrameDesc& f = frames[blockIdx.x];
+  __shared__ int s[1024];
+  __shared__ int carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int base = 0; base < rows; base += 1024) {
+    const int r = base + threadIdx.x;
+    const int v = (r < rows) ? f.rowoff[r] : 0;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int add = (threadIdx.x >= off) ? s[threadIdx.x - off] : 0;
+      __syncthreads();
+      s[threadIdx.x] += add;
+      __syncthreads();
+    }
+    const int incl = s[threadIdx.x];
+    const int c0 = carry;
+    if (r < rows) f.rowoff[r] = c0 + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry = c0 + incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *f.cloud.count = carry;
+}
+// step 3: PinholePointProjector::unProject (pwn_core/pinholepointprojector.cpp:93-133) + projectIntervals (:135-147).
+// Point index = row-major rank of the valid pixel.  grid = (rows, frames), block = 256.
+__global__ void __launch_bounds__(256) k_unproject(const FrameDesc* __restrict__ frames, ConvertParams cp) {
+  const FrameDesc& f = frames[blockIdx.y];
+  const int r = blockIdx.x;
+  __shared__ int wcount[4];
+  int base = f.rowoff[r];
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  for (int c0 = 0; c0 < cp.cols; c0 += 256) {
+    const int c = c0 + threadIdx.x;
+    const bool in = c < cp.cols;
+    const float d = in ? f.depth[(size_t)r * cp.cols + c] : 0.f;
+    const bool valid = in && !(d < cp.minD || d > cp.maxD);
+    const unsigned long long bal = __ballot(valid);
+    const int rank = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wcount[wave] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { const int n = wcount[w]; if (w < wave) woff += n; tot += n; }
+    if (in) {
+      const size_t pix = (size_t)r * cp.cols + c;
+      int idx = -1, itv = -1;
+      if (valid) {
+        idx = base + woff + rank;
+        // _unProject: p = iKRt * (x*d, y*d, d, 1)
+        const float a = (float)c * d, b = (float)r * d;
+        float4 p;
+        p.x = dot4seq(cp.iKRt(0,0), a, cp.iKRt(0,1), b, cp.iKRt(0,2), d, cp.iKRt(0,3), 1.0f);
+        p.y = dot4seq(cp.iKRt(1,0), a, cp.iKRt(1,1), b, cp.iKRt(1,2), d, cp.iKRt(1,3), 1.0f);
+        p.z = dot4seq(cp.iKRt(2,0), a, cp.iKRt(2,1), b, cp.iKRt(2,2), d, cp.iKRt(2,3), 1.0f);
+        p.w = 0.f;
+        if (f.cloud.P && idx < f.cloud.capacity) f.cloud.P[idx] = p;
+        // _projectInterval: int(max(fx*R/d, fy*R/d))
+        const float inv = 1.0f / d;
+        const float px = cp.ivx * inv, py = cp.ivy * inv;
+        itv = (px > py) ? (int)px : (int)py;
+      }
+      f.index[pix] = idx;
+      f.interval[pix] = itv;
+    }
+    base += tot;
+    __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// PointIntegralImage::compute, passes 1+2 (pwn_core/pointintegralimage.cpp:16-35): scatter the points into the
+// accumulators and prefix-sum along image x inside each image row.  fp32 addition is not associative and
+// the covariance downstream differences these sums, so every chain keeps the reference's strictly sequential
+// left-to-right order: one thread per (row, channel) chain, tiles staged through LDS so that all global
+// traffic is row-coalesced.  grid = (ceil(rows/16), frames), block = 256.
+constexpr int kIR_Rows = 16, kIR_Cols = 64, kIR_Stride = kIR_Cols + 1;
+__global__ void __launch_bounds__(256) k_integral_rows(const FrameDesc* __restrict__ frames, int rows, int cols) {
+  const FrameDesc& f = frames[blockIdx.y];
+  const int r0 = blockIdx.x * kIR_Rows;
+  __shared__ float tile[kIntegralChannels * kIR_Rows * kIR_Stride];   // 41.6 KB
+  const int tid = threadIdx.x;
+  const size_t N = (size_t)rows * cols;
+  // scan role: thread t < 160 owns chain (row = t % 16, ch = t / 16)
+  const int srow = tid % kIR_Rows, sch = tid / kIR_Rows;
+  float carry = 0.f;
+  for (int x0 = 0; x0 < cols; x0 += kIR_Cols) {
+    // phase 1: 1024 pixels, 4 per thread, lanes along x
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = tid + 256 * j;
+      const int lr = q / kIR_Cols, lc = q % kIR_Cols;
+      const int r = r0 + lr, c = x0 + lc;
+      float v[kIntegralChannels];
+#pragma unroll
+      for (int k = 0; k < kIntegralChannels; ++k) v[k] = 0.f;
+      if (r < rows && c < cols) {
+        const int idx = f.index[(size_t)r * cols + c];
+        if (idx >= 0 && idx < f.cloud.capacity) {
+          const float4 p = f.cloud.P[idx];
+          v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = 1.0f;
+          v[4] = p.x * p.x; v[5] = p.x * p.y; v[6] = p.x * p.z;
+          v[7] = p.y * p.y; v[8] = p.y * p.z; v[9] = p.z * p.z;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < kIntegralChannels; ++k) tile[(k * kIR_Rows + lr) * kIR_Stride + lc] = v[k];
+    }
+    __syncthreads();
+    // phase 2: sequential scan of 64 columns per chain
+    if (tid < kIntegralChannels * kIR_Rows) {
+      float* t = &tile[(sch * kIR_Rows + srow) * kIR_Stride];
+      float vals[kIR_Cols];
+#pragma unroll
+      for (int c = 0; c < kIR_Cols; ++c) vals[c] = t[c];
+#pragma unroll
+      for (int c = 0; c < kIR_Cols; ++c) { carry = vals[c] + carry; vals[c] = carry; }
+#pragma unroll
+      for (int c = 0; c < kIR_Cols; ++c) t[c] = vals[c];
+    }
+    __syncthreads();
+    // phase 3: coalesced write-back, plane by plane
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int q = tid + 256 * j;
+      const int lr = q / kIR_Cols, lc = q % kIR_Cols;
+      const int r = r0 + lr, c = x0 + lc;
+      if (r < rows && c < cols) {
+#pragma unroll
+        for (int k = 0; k < kIntegralChannels; ++k)
+          f.integral[k * N + (size_t)r * cols + c] = tile[(k * kIR_Rows + lr) * kIR_Stride + lc];
+      }
+    }
+    __syncthreads();
+  }
+}
+// pass 3 (pwn_core/pointintegralimage.cpp:38-43): prefix-sum along image y inside each image column, sequential.
+// one thread per (column, channel) chain, lanes along x.  grid = (ceil(cols/256), 10, frames), block = 256.
+__global__ void __launch_bounds__(256) k_integral_cols(const FrameDesc* __restrict__ frames, int rows, int cols) {
+  const FrameDesc& f = frames[blockIdx.z];
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cols) return;
+  float* p = f.integral + (size_t)blockIdx.y * rows * cols + c;
+  float carry = 0.f;
+  int r = 0;
+  constexpr int U = 16;
+  for (; r + U <= rows; r += U) {
+    float v[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) v[k] = p[(size_t)(r + k) * cols];
+#pragma unroll
+    for (int k = 0; k < U; ++k) { carry = v[k] + carry; v[k] = carry; }
+#pragma unroll
+    for (int k = 0; k < U; ++k) p[(size_t)(r + k) * cols] = v[k];
+  }
+  for (; r < rows; ++r) { carry = p[(size_t)r * cols] + carry; p[(size_t)r * cols] = carry; }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// StatsCalculatorIntegralImage::compute per-pixel loop (pwn_core/statscalculatorintegralimage.cpp:33-80) fused with
+// PointInformationMatrixCalculator / NormalInformationMatrixCalculator::compute (informationmatrixcalculator.cpp:9-58)
+// and Cloud::transformInPlace (cloud.cpp:173-186).  One thread per pixel, lanes along x.
+// grid = (ceil(cols/256), rows, frames), block = 256.
+__device__ __forceinline__ int clampi(int v, int lo, int hi) { v = (v < lo) ? lo : v; v = (v > hi) ? hi : v; return v; }
+
+__global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ frames, ConvertParams cp) {
+  const FrameDesc& f = frames[blockIdx.z];
+  const int r = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= cp.cols) return;
+  const int rows = cp.rows, cols = cp.cols;
+  const size_t N = (size_t)rows * cols;
+  const size_t pix = (size_t)r * cols + c;
+  const int idx = f.index[pix];
+  if (idx < 0 || idx >= f.cloud.capacity) return;
+  const int itv = f.interval[pix];
+  float4 P = f.cloud.P[idx];
+  float nx = 0.f, ny = 0.f, nz = 0.f;
+  float curvature = 0.f;          // Stats() default: eigenvalues 0 -> curvature() = 0/(0+1e-9) = 0  (stats.h:21-27,98-103)
+  int cls = 0;
+  float om[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) om[k] = 0.f;
+  float U[9] = { 1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f };   // column-major
+  float ev[3] = { 0.f, 0.f, 0.f };
+  float mean[3] = { 0.f, 0.f, 0.f };
+  int npts = 0;
+  if (itv >= 0) {
+    int rad = itv;
+    if (rad < cp.minRadius) rad = cp.minRadius;
+    if (rad > cp.maxRadius) rad = cp.maxRadius;
+    // PointIntegralImage::getRegion (pointintegralimage.cpp:53-66)
+    const int xmin = clampi(c - rad - 1, 0, cols - 1), xmax = clampi(c + rad - 1, 0, cols - 1);
+    const int ymin = clampi(r - rad - 1, 0, rows - 1), ymax = clampi(r + rad - 1, 0, rows - 1);
+    const size_t oA = (size_t)ymax * cols + xmax, oB = (size_t)ymin * cols + xmin;
+    const size_t oC = (size_t)ymax * cols + xmin, oD = (size_t)ymin * cols + xmax;
+    float a[kIntegralChannels];
+#pragma unroll
+    for (int k = 0; k < kIntegralChannels; ++k) {
+      const float* pl = f.integral + k * N;
+      float v = pl[oA];
+      v = v + pl[oB];
+      v = v - pl[oC];
+      v = v - pl[oD];
+      a[k] = v;
+    }
+    const int n = (int)a[3];
+    if (n >= cp.minPoints) {
+      npts = n;
+      // PointAccumulator::mean / covariance (pointaccumulator.h:66-86)
+      float d = a[3];
+      float c00 = 0, c10 = 0, c20 = 0, c11 = 0, c21 = 0, c22 = 0;
+      if (d != 0.f) {
+        d = 1.0f / d;
+        mean[0] = a[0] * d; mean[1] = a[1] * d; mean[2] = a[2] * d;
+        c00 = a[4] * d - mean[0] * mean[0];
+        c10 = a[5] * d - mean[1] * mean[0];
+        c20 = a[6] * d - mean[2] * mean[0];
+        c11 = a[7] * d - mean[1] * mean[1];
+        c21 = a[8] * d - mean[2] * mean[1];
+        c22 = a[9] * d - mean[2] * mean[2];
+      }
+      Vec3 v0, v1, v2;
+      eig3_direct(c00, c10, c20, c11, c21, c22, ev, v0, v1, v2);
+      if (ev[0] < 0.0f) ev[0] = 0.0f;
+      U[0] = v0.x; U[1] = v0.y; U[2] = v0.z; U[3] = v1.x; U[4] = v1.y; U[5] = v1.z; U[6] = v2.x; U[7] = v2.y; U[8] = v2.z;
+      // Stats::curvature (stats.h:98-103): fp32 sum, double +1e-9 and divide
+      curvature = (float)((double)ev[0] / ((double)(ev[0] + ev[1] + ev[2]) + 1e-9));
+      if (curvature < cp.statsCurvThr) {
+        nx = v0.x; ny = v0.y; nz = v0.z;
+        // normal.dot(point) > 0 -> flip (4-vector dot, w term 0*1)
+        const float dp = dot4seq(nx, P.x, ny, P.y, nz, P.z, 0.f, 1.f);
+        if (dp > 0) { nx = -nx; ny = -ny; nz = -nz; }
+      }
+    }
+  }
+  // information matrices
+  const float sq = dot4seq(nx, nx, ny, ny, nz, nz, 0.f, 0.f);
+  if (sq > 0) {
+    float dg[3];
+    if (curvature < cp.pointInfoCurvThr) { dg[0] = cp.pFlat[0]; dg[1] = cp.pFlat[1]; dg[2] = cp.pFlat[2]; }
+    else { dg[0] = 1.0f / ev[0]; dg[1] = 1.0f / ev[1]; dg[2] = 1.0f / ev[2]; }
+    // (U * D) * U^T, U(i,k) = U[i + 3k]
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+        om[3 * i + j] = dot3seq(U[i] * dg[0], U[j], U[i + 3] * dg[1], U[j + 3], U[i + 6] * dg[2], U[j + 6]);
+    cls = (curvature < cp.normalInfoCurvThr) ? 1 : 2;
+  }
+  if (cp.keepStats && f.cloud.St) {
+    float* st = f.cloud.St + (size_t)idx * 16;
+    // Stats 4x4 after the optional sensor-offset left-multiplication (stats.h:125-131)
+    if (cp.hasOffset) {
+      Mat4 S = mat4_identity();
+      if (npts > 0) {
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) S(i,j) = U[i + 3 * j];
+        S(0,3) = mean[0]; S(1,3) = mean[1]; S(2,3) = mean[2]; S(3,3) = 1.f;
+      }
+      const Mat4 R = mat4_mul(cp.offset, S);
+      for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) st[i + 3 * j] = R(i,j);
+      st[12] = R(0,3); st[13] = R(1,3); st[14] = R(2,3);
+    } else {
+      for (int k = 0; k < 9; ++k) st[k] = U[k];
+      st[12] = mean[0]; st[13] = mean[1]; st[14] = mean[2];
+    }
+    st[9] = ev[0]; st[10] = ev[1]; st[11] = ev[2];
+    st[15] = (float)npts;
+  }
+  if (cp.hasOffset) {
+    // Cloud::transformInPlace: p = m*p, n = m*n, Omega = T*Omega*T^t with T = m without last row/col
+    const Mat4& m = cp.offset;
+    const float px = dot4seq(m(0,0), P.x, m(0,1), P.y, m(0,2), P.z, m(0,3), 1.0f);
+    const float py = dot4seq(m(1,0), P.x, m(1,1), P.y, m(1,2), P.z, m(1,3), 1.0f);
+    const float pz = dot4seq(m(2,0), P.x, m(2,1), P.y, m(2,2), P.z, m(2,3), 1.0f);
+    P.x = px; P.y = py; P.z = pz;
+    const float tx = dot4seq(m(0,0), nx, m(0,1), ny, m(0,2), nz, m(0,3), 0.0f);
+    const float ty = dot4seq(m(1,0), nx, m(1,1), ny, m(1,2), nz, m(1,3), 0.0f);
+    const float tz = dot4seq(m(2,0), nx, m(2,1), ny, m(2,2), nz, m(2,3), 0.0f);
+    nx = tx; ny = ty; nz = tz;
+    float t1[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) t1[3 * i + j] = dot3seq(m(i,0), om[0 + j], m(i,1), om[3 + j], m(i,2), om[6 + j]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) om[3 * i + j] = dot3seq(t1[3 * i], m(j,0), t1[3 * i + 1], m(j,1), t1[3 * i + 2], m(j,2));
+  }
+  P.w = curvature;
+  f.cloud.P[idx] = P;
+  f.cloud.Nm[idx] = make_float4(nx, ny, nz, __int_as_float(cls));
+  const int cap = f.cloud.capacity;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) f.cloud.Om[(size_t)k * cap + idx] = om[k];
+}
+
+// Cloud::transformInPlace on an existing device cloud (cloud.cpp:173-186); grid = ceil(cap/256)
+__global__ void __launch_bounds__(256) k_cloud_transform(CloudDev cl, Mat4 m) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= *cl.count || i >= cl.capacity) return;
+  float4 P = cl.P[i]; float4 Nm = cl.Nm[i];
+  const float px = dot4seq(m(0,0), P.x, m(0,1), P.y, m(0,2), P.z, m(0,3), 1.0f);
+  const float py = dot4seq(m(1,0), P.x, m(1,1), P.y, m(1,2), P.z, m(1,3), 1.0f);
+  const float pz = dot4seq(m(2,0), P.x, m(2,1), P.y, m(2,2), P.z, m(2,3), 1.0f);
+  P.x = px; P.y = py; P.z = pz;
+  const float tx = dot4seq(m(0,0), Nm.x, m(0,1), Nm.y, m(0,2), Nm.z, m(0,3), 0.0f);
+  const float ty = dot4seq(m(1,0), Nm.x, m(1,1), Nm.y, m(1,2), Nm.z, m(1,3), 0.0f);
+  const float tz = dot4seq(m(2,0), Nm.x, m(2,1), Nm.y, m(2,2), Nm.z, m(2,3), 0.0f);
+  Nm.x = tx; Nm.y = ty; Nm.z = tz;
+  cl.P[i] = P; cl.Nm[i] = Nm;
+  for (int pass = 0; pass < 2; ++pass) {
+    float* base = pass == 0 ? cl.Om : cl.OmN;
+    if (!base) continue;
+    float om[9], t1[9];
+    for (int k = 0; k < 9; ++k) om[k] = base[(size_t)k * cl.capacity + i];
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) t1[3 * a + b] = dot3seq(m(a,0), om[0 + b], m(a,1), om[3 + b], m(a,2), om[6 + b]);
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) om[3 * a + b] = dot3seq(t1[3 * a], m(b,0), t1[3 * a + 1], m(b,1), t1[3 * a + 2], m(b,2));
+    for (int k = 0; k < 9; ++k) base[(size_t)k * cl.capacity + i] = om[k];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// PinholePointProjector::project (pwn_core/pinholepointprojector.cpp:33-66): z-buffer by 64-bit atomicMin on
+// (depth bits, point index): nearest point wins, ties keep the lowest index (the reference's strict '>' in a
+// sequential loop).  grid = (ceil(capacity/256), pairs), block = 256.  which: 0 = reference cloud, 1 = current.
+__device__ __forceinline__ void project_point(const Mat4& KRt, float minD, float maxD, int rows, int cols,
+                                              const float4 p, int i, unsigned long long* z) {
+  const float ix = dot4seq(KRt(0,0), p.x, KRt(0,1), p.y, KRt(0,2), p.z, KRt(0,3), 1.0f);
+  const float iy = dot4seq(KRt(1,0), p.x, KRt(1,1), p.y, KRt(1,2), p.z, KRt(1,3), 1.0f);
+  const float d  = dot4seq(KRt(2,0), p.x, KRt(2,1), p.y, KRt(2,2), p.z, KRt(2,3), 1.0f);
+  if (d < minD || d > maxD) return;
+  const float inv = 1.0f / d;
+  const float fx = roundf(ix * inv), fy = roundf(iy * inv);
+  // int conversion of out-of-range floats is undefined on the CPU; such points are rejected by the bounds test
+  if (!(fx >= 0.f && fx < (float)cols && fy >= 0.f && fy < (float)rows)) return;
+  const int x = (int)fx, y = (int)fy;
+  const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)i;
+  atomicMin(&z[(size_t)y * cols + x], key);
+}
+__global__ void __launch_bounds__(256) k_project(const PairDesc* __restrict__ pairs, AlignParams ap, int which) {
+  const PairDesc& pd = pairs[blockIdx.y];
+  const CloudDev& cl = which ? pd.cur : pd.ref;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int n = min(*cl.count, cl.capacity);
+  if (i >= n) return;
+  const Mat4 KRt = which ? pd.state->KRtCur : pd.state->KRt;
+  project_point(KRt, ap.minD, ap.maxD, ap.rows, ap.cols, cl.P[i], i, which ? pd.zcur : pd.zref);
+}
+// stand-alone projection with an explicit matrix (pwn_hip_project)
+__global__ void __launch_bounds__(256) k_project_single(CloudDev cl, Mat4 KRt, float minD, float maxD, int rows, int cols,
+                                                        unsigned long long* z) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int n = min(*cl.count, cl.capacity);
+  if (i >= n) return;
+  project_point(KRt, minD, maxD, rows, cols, cl.P[i], i, z);
+}
+// z-buffer -> (index image, depth image): empty pixels -1 / FLT_MAX (pinholepointprojector.cpp:41-42)
+__global__ void k_zbuf_resolve(const unsigned long long* __restrict__ z, int n, int* __restrict__ index, float* __restrict__ depth) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const unsigned long long k = z[i];
+    if (index) index[i] = (int)(unsigned int)(k & 0xffffffffu);
+    if (depth) depth[i] = (k == kZEmpty) ? FLT_MAX : __uint_as_float((unsigned int)(k >> 32));
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// One correspondence's contribution to the normal equations: Linearizer::update loop body
+// (pwn_core/linearizer.cpp:57-88).  oP / oN: row-major 3x3 information matrices of the CURRENT point.
+// The 4x4 products of the reference are written out for the non-zero 3x3 part; dropped terms are exact zeros.
+__device__ __forceinline__ void skewT_mul(float tx, float ty, float tz, const float* m /*row-major 3x3*/, float* out) {
+  // out = S^T * m with S = skew(v) = -2[v]x, (tx,ty,tz) = 2v   (bm_se3.h:54-66)
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    out[0 + j] = (-tz) * m[3 + j] + ty * m[6 + j];
+    out[3 + j] = tz * m[0 + j] + (-tx) * m[6 + j];
+    out[6 + j] = (-ty) * m[0 + j] + tx * m[3 + j];
+  }
+}
+__device__ __forceinline__ void mul_skew(const float* a /*row-major 3x3*/, float tx, float ty, float tz, float* out) {
+  // out = a * S
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    out[3 * i + 0] = a[3 * i + 1] * (-tz) + a[3 * i + 2] * ty;
+    out[3 * i + 1] = a[3 * i + 0] * tz + a[3 * i + 2] * (-tx);
+    out[3 * i + 2] = a[3 * i + 0] * (-ty) + a[3 * i + 1] * tx;
+  }
+}
+// returns false if the term is rejected (non-robust kernel and chi2 above threshold)
+__device__ __forceinline__ bool linearize_term(const float3 rp, const float3 rn, const float3 cp, const float3 cn,
+                                               const float* oP, const float* oN, float maxChi2, int robust, float* acc) {
+  const float pe0 = rp.x - cp.x, pe1 = rp.y - cp.y, pe2 = rp.z - cp.z;
+  const float ne0 = rn.x - cn.x, ne1 = rn.y - cn.y, ne2 = rn.z - cn.z;
+  float ep[3], en[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    ep[i] = dot3seq(oP[3 * i], pe0, oP[3 * i + 1], pe1, oP[3 * i + 2], pe2);
+    en[i] = dot3seq(oN[3 * i], ne0, oN[3 * i + 1], ne1, oN[3 * i + 2], ne2);
+  }
+  const float localError = dot3seq(pe0, ep[0], pe1, ep[1], pe2, ep[2]) + dot3seq(ne0, en[0], ne1, en[1], ne2, en[2]);
+  float kscale = 1.f;
+  if (localError > maxChi2) {
+    if (robust) kscale = sqrtf(maxChi2 / localError);
+    else return false;
+  }
+  const float ptx = 2 * rp.x, pty = 2 * rp.y, ptz = 2 * rp.z;
+  const float ntx = 2 * rn.x, nty = 2 * rn.y, ntz = 2 * rn.z;
+  float t1[9], A[9], B[9], oPS[9];
+  mul_skew(oP, ptx, pty, ptz, oPS);                 // Htr term: omegaP * Sp
+  skewT_mul(ptx, pty, ptz, oP, t1); mul_skew(t1, ptx, pty, ptz, A);     // Sp^T omegaP Sp
+  skewT_mul(ntx, nty, ntz, oN, t1); mul_skew(t1, ntx, nty, ntz, B);     // Sn^T omegaN Sn
+  // Sp^T ep + Sn^T en
+  const float s0 = ((-ptz) * ep[1] + pty * ep[2]) + ((-ntz) * en[1] + nty * en[2]);
+  const float s1 = (ptz * ep[0] + (-ptx) * ep[2]) + (ntz * en[0] + (-ntx) * en[2]);
+  const float s2 = ((-pty) * ep[0] + ptx * ep[1]) + ((-nty) * en[0] + ntx * en[1]);
+  // accumulators are column-major 3x3 blocks: acc[i + 3*j]
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      acc[0 + i + 3 * j]  += oP[3 * i + j];
+      acc[9 + i + 3 * j]  += oPS[3 * i + j];
+      acc[18 + i + 3 * j] += A[3 * i + j] + B[3 * i + j];
+    }
+  acc[27] += kscale * ep[0]; acc[28] += kscale * ep[1]; acc[29] += kscale * ep[2];
+  acc[30] += kscale * s0; acc[31] += kscale * s1; acc[32] += kscale * s2;
+  acc[33] += kscale * localError;
+  acc[34] += 1.f;
+  return true;
+}
+__device__ __forceinline__ void load_omegas(const CloudDev& cur, int ci, int cls, float* oP, float* oN) {
+  const size_t cap = (size_t)cur.capacity;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) oP[k] = cur.Om[k * cap + ci];
+  if (cur.OmN) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) oN[k] = cur.OmN[k * cap + ci];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) oN[k] = (cls == 1) ? cur.omN[0][k] : ((cls == 2) ? cur.omN[1][k] : 0.f);
+  }
+}
+__device__ __forceinline__ float3 iso_point(const Mat4& T, const float4 p) {
+  float3 r;
+  r.x = dot4seq(T(0,0), p.x, T(0,1), p.y, T(0,2), p.z, T(0,3), 1.0f);
+  r.y = dot4seq(T(1,0), p.x, T(1,1), p.y, T(1,2), p.z, T(1,3), 1.0f);
+  r.z = dot4seq(T(2,0), p.x, T(2,1), p.y, T(2,2), p.z, T(2,3), 1.0f);
+  return r;
+}
+__device__ __forceinline__ float3 iso_normal(const Mat4& T, const float4 n) {
+  float3 r;
+  r.x = dot4seq(T(0,0), n.x, T(0,1), n.y, T(0,2), n.z, T(0,3), 0.0f);
+  r.y = dot4seq(T(1,0), n.x, T(1,1), n.y, T(1,2), n.z, T(1,3), 0.0f);
+  r.z = dot4seq(T(2,0), n.x, T(2,1), n.y, T(2,2), n.z, T(2,3), 0.0f);
+  return r;
+}
+// CorrespondenceFinder::compute acceptance tests (pwn_core/correspondencefinder.cpp:60-99) for one pixel.
+__device__ __forceinline__ bool correspondence_test(const AlignParams& ap, const Mat4& Tc, const float4 rP, const float4 rN,
+                                                    const float4 cP, const float4 cN) {
+  if (dot4seq(cN.x, cN.x, cN.y, cN.y, cN.z, cN.z, 0.f, 0.f) == 0.0f || dot4seq(rN.x, rN.x, rN.y, rN.y, rN.z, rN.z, 0.f, 0.f) == 0.0f)
+    return false;
+  const float3 rp = iso_point(Tc, rP);
+  const float3 rn = iso_normal(Tc, rN);
+  if (dot4seq(cN.x, rn.x, cN.y, rn.y, cN.z, rn.z, 0.f, 0.f) < ap.normalThr) return false;
+  const float dx = cP.x - rp.x, dy = cP.y - rp.y, dz = cP.z - rp.z;
+  if (dot4seq(dx, dx, dy, dy, dz, dz, 0.f, 0.f) > ap.sqDist) return false;
+  float rc = rP.w, cc = cP.w;
+  if (rc < ap.flatThr) rc = ap.flatThr;
+  if (cc < ap.flatThr) cc = ap.flatThr;
+  const float ratio = (float)(((double)rc + 1e-5) / ((double)cc + 1e-5));
+  if (ratio < ap.minRatio || ratio > ap.maxRatio) return false;
+  return true;
+}
+
+// block-level reduction of kAccN fp32 accumulators -> fp64 partial record of the block
+__device__ __forceinline__ void block_reduce_store(float* acc, double* out) {
+  __shared__ float red[kAlignBlock / 64][kAccN];
+#pragma unroll
+  for (int k = 0; k < kAccN; ++k) {
+    const float v = wave_sum(acc[k]);
+    if (lane_id() == 0) red[threadIdx.x >> 6][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < kAccN) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < kAlignBlock / 64; ++w) s += (double)red[w][threadIdx.x];
+    out[threadIdx.x] = s;
+  }
+}
+
+// Fused CorrespondenceFinder::compute + Linearizer::update (correspondencefinder.cpp:45-106, linearizer.cpp:33-90):
+// one pass over the pixels, no correspondence list is materialised.  The reference z-buffer word is consumed and
+// (unless keepZ) reset to "empty" so the next iteration's projection needs no separate clear pass.
+// grid = (ceil(N / (256*4)), pairs), block = 256.
+__global__ void __launch_bounds__(kAlignBlock) k_corr_linearize(const PairDesc* __restrict__ pairs, AlignParams ap, int keepZ) {
+  const PairDesc& pd = pairs[blockIdx.y];
+  const int N = ap.rows * ap.cols;
+  const Mat4 Tc = pd.state->invTcorr;
+  const Mat4 Tl = pd.state->invT;
+  float acc[kAccN];
+#pragma unroll
+  for (int k = 0; k < kAccN; ++k) acc[k] = 0.f;
+  const int nref = min(*pd.ref.count, pd.ref.capacity), ncur = min(*pd.cur.count, pd.cur.capacity);
+#pragma unroll
+  for (int j = 0; j < kPixPerThread; ++j) {
+    const int pix = (blockIdx.x * kPixPerThread + j) * kAlignBlock + threadIdx.x;
+    if (pix >= N) continue;
+    const unsigned long long zr = pd.zref[pix];
+    if (!keepZ && zr != kZEmpty) pd.zref[pix] = kZEmpty;
+    const int ri = (int)(unsigned int)(zr & 0xffffffffu);
+    const int ci = (int)(unsigned int)(pd.zcur[pix] & 0xffffffffu);
+    if (ri < 0 || ci < 0 || ri >= nref || ci >= ncur) continue;
+    acc[36] += 1.f;
+    const float4 rP = pd.ref.P[ri], rN = pd.ref.Nm[ri], cP = pd.cur.P[ci], cN = pd.cur.Nm[ci];
+    if (!correspondence_test(ap, Tc, rP, rN, cP, cN)) continue;
+    acc[35] += 1.f;
+    float oP[9], oN[9];
+    load_omegas(pd.cur, ci, __float_as_int(cN.w), oP, oN);
+    const float3 rp = iso_point(Tl, rP), rn = iso_normal(Tl, rN);
+    linearize_term(rp, rn, make_float3(cP.x, cP.y, cP.z), make_float3(cN.x, cN.y, cN.z), oP, oN, ap.maxChi2, ap.robust, acc);
+  }
+  block_reduce_store(acc, pd.partials + (size_t)blockIdx.x * kAccN);
+}
+
+// CorrespondenceFinder::compute as a per-pixel pair image (compacted on the host in row-major order).
+__global__ void __launch_bounds__(256) k_correspondence_image(CloudDev ref, CloudDev cur, const int* __restrict__ refIndex,
+                                                              const int* __restrict__ curIndex, AlignParams ap, Mat4 Tc,
+                                                              int2* __restrict__ out, int* __restrict__ counters) {
+  const int N = ap.rows * ap.cols;
+  const int pix = blockIdx.x * 256 + threadIdx.x;
+  if (pix >= N) return;
+  int2 res = make_int2(-1, -1);
+  const int ri = refIndex[pix], ci = curIndex[pix];
+  const int nref = min(*ref.count, ref.capacity), ncur = min(*cur.count, cur.capacity);
+  if (ri >= 0 && ci >= 0 && ri < nref && ci < ncur) {
+    atomicAdd(&counters[0], 1);
+    if (correspondence_test(ap, Tc, ref.P[ri], ref.Nm[ri], cur.P[ci], cur.Nm[ci])) res = make_int2(ri, ci);
+  }
+  out[pix] = res;
+}
+// Linearizer::update on an explicit list.  grid = ceil(C/(256*4)), block 256.
+__global__ void __launch_bounds__(kAlignBlock) k_linearize_list(CloudDev ref, CloudDev cur, const int2* __restrict__ corr, int C,
+                                                                AlignParams ap, Mat4 Tl, double* __restrict__ partials) {
+  float acc[kAccN];
+#pragma unroll
+  for (int k = 0; k < kAccN; ++k) acc[k] = 0.f;
+  const int nref = min(*ref.count, ref.capacity), ncur = min(*cur.count, cur.capacity);
+#pragma unroll
+  for (int j = 0; j < kPixPerThread; ++j) {
+    const int i = (blockIdx.x * kPixPerThread + j) * kAlignBlock + threadIdx.x;
+    if (i >= C) continue;
+    const int2 c = corr[i];
+    if (c.x < 0 || c.y < 0 || c.x >= nref || c.y >= ncur) continue;
+    acc[35] += 1.f;
+    const float4 rP = ref.P[c.x], rN = ref.Nm[c.x], cP = cur.P[c.y], cN = cur.Nm[c.y];
+    float oP[9], oN[9];
+    load_omegas(cur, c.y, __float_as_int(cN.w), oP, oN);
+    const float3 rp = iso_point(Tl, rP), rn = iso_normal(Tl, rN);
+    linearize_term(rp, rn, make_float3(cP.x, cP.y, cP.z), make_float3(cN.x, cN.y, cN.z), oP, oN, ap.maxChi2, ap.robust, acc);
+  }
+  block_reduce_store(acc, partials + (size_t)blockIdx.x * kAccN);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Deterministic final reduction (fixed block order, fp64) + the Gauss-Newton step of Aligner::align
+// (pwn_core/aligner.cpp:86-117): H = H_lin + I + 1000 I, dx = ldlt(H) \ (-b), invT = v2t(dx) * invT, and at the
+// end of an outer iteration _T = v2t(t2v(invT^-1)) plus the projector matrix of the next reference projection.
+// grid = pairs, block = 64.
+struct SolveOut { float H[36]; float b[6]; float chi2; int inliers, ncorr, ncand; };
+__device__ __forceinline__ void reduce_partials(const double* partials, int nblocks, double* sums /*shared[kAccN]*/) {
+  if (threadIdx.x < kAccN) {
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * kAccN + threadIdx.x];
+    sums[threadIdx.x] = s;
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void assemble_Hb(const double* s, float* H, float* b) {
+  // Linearizer.cpp:109-114
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 3; ++j) {
+      H[i + 6 * j] = (float)s[0 + i + 3 * j];
+      H[i + 6 * (j + 3)] = (float)s[9 + i + 3 * j];
+      H[(i + 3) + 6 * (j + 3)] = (float)s[18 + i + 3 * j];
+    }
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) H[(i + 3) + 6 * j] = H[j + 6 * (i + 3)];
+  for (int i = 0; i < 3; ++i) { b[i] = (float)s[27 + i]; b[i + 3] = (float)s[30 + i]; }
+}
+__global__ void __launch_bounds__(64) k_solve_update(const PairDesc* __restrict__ pairs, AlignParams ap, int nblocks, int outerEnd) {
+  const PairDesc& pd = pairs[blockIdx.x];
+  __shared__ double sums[kAccN];
+  reduce_partials(pd.partials, nblocks, sums);
+  if (threadIdx.x != 0) return;
+  PairState& st = *pd.state;
+  float H[36], b[6];
+  assemble_Hb(sums, H, b);
+  const int it = st.it;
+  if (it < kMaxIter) {
+    st.chi2[it] = (float)sums[33];
+    st.inliers[it] = (int)sums[34];
+    st.ncorr[it] = (int)sums[35];
+    st.ncand[it] = (int)sums[36];
+  }
+  st.it = it + 1;
+  for (int d = 0; d < 6; ++d) H[d + 6 * d] = H[d + 6 * d] + 1.0f;        // aligner.cpp:92
+  for (int d = 0; d < 6; ++d) H[d + 6 * d] = H[d + 6 * d] + 1000.0f;     // aligner.cpp:94
+  float nb[6], dx[6];
+  for (int d = 0; d < 6; ++d) nb[d] = -b[d];
+  ldlt_solve6(H, nb, dx);
+  Mat4 invT = st.invT;
+  set_last_row(invT);
+  invT = iso_mul(v2t(dx), invT);
+  if (outerEnd) {
+    Mat4 T = iso_inverse(invT);
+    float v[6];
+    t2v(T, v);
+    T = v2t(v);
+    set_last_row(T);
+    st.T = T;
+    const Mat4 Tinv = iso_inverse(T);
+    st.invTcorr = Tinv;
+    invT = Tinv;
+    Mat4 KRt, iKRt; Mat3 iK;
+    projector_matrices(ap.K, iso_mul(T, ap.refOffset), KRt, iKRt, iK);
+    st.KRt = KRt;
+  }
+  set_last_row(invT);
+  st.invT = invT;
+}
+// reduction only (pwn_hip_linearize)
+__global__ void __launch_bounds__(64) k_reduce_only(const double* __restrict__ partials, int nblocks, SolveOut* __restrict__ out) {
+  __shared__ double sums[kAccN];
+  reduce_partials(partials, nblocks, sums);
+  if (threadIdx.x != 0) return;
+  assemble_Hb(sums, out->H, out->b);
+  out->chi2 = (float)sums[33]; out->inliers = (int)sums[34]; out->ncorr = (int)sums[35]; out->ncand = (int)sums[36];
+}
+
+}  // namespace pwnhip

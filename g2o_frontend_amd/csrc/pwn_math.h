@@ -1,0 +1,318 @@
+// pwn_math.h -- small fixed-size fp32 math shared by host code and gfx950 kernels.
+//
+// The reference does this math with Eigen (fixed-size Matrix3f/Matrix4f/Isometry3f, Quaternionf,
+// SelfAdjointEigenSolver<Matrix3f>::computeDirect, Matrix6f::ldlt()).  Eigen is not a dependency
+// here; the routines below reproduce its evaluation order (inner products left to right, no FMA:
+// this file must be compiled with -ffp-contract=off) so that host and device agree bit for bit
+// and both agree with the CPU path they replace.  Matrices are column-major like Eigen's.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include <math.h>
+
+#define PWN_HD __host__ __device__ __forceinline__
+
+namespace pwnhip {
+
+struct Mat3 {
+  float m[9];
+  PWN_HD float& operator()(int r, int c) { return m[r + 3 * c]; }
+  PWN_HD float operator()(int r, int c) const { return m[r + 3 * c]; }
+};
+struct Mat4 {
+  float m[16];
+  PWN_HD float& operator()(int r, int c) { return m[r + 4 * c]; }
+  PWN_HD float operator()(int r, int c) const { return m[r + 4 * c]; }
+};
+struct Vec3 { float x, y, z; };
+
+PWN_HD Mat4 mat4_identity() {
+  Mat4 r;
+  for (int i = 0; i < 16; ++i) r.m[i] = 0.f;
+  r.m[0] = r.m[5] = r.m[10] = r.m[15] = 1.f;
+  return r;
+}
+PWN_HD Mat4 mat4_from(const float* p) { Mat4 r; for (int i = 0; i < 16; ++i) r.m[i] = p[i]; return r; }
+PWN_HD Mat3 mat3_from(const float* p) { Mat3 r; for (int i = 0; i < 9; ++i) r.m[i] = p[i]; return r; }
+PWN_HD void set_last_row(Mat4& T) { T(3,0) = 0.f; T(3,1) = 0.f; T(3,2) = 0.f; T(3,3) = 1.f; }
+
+// 3-term / 4-term inner products, strictly left to right
+PWN_HD float dot3seq(float a0, float b0, float a1, float b1, float a2, float b2) {
+  float s = a0 * b0; s = s + a1 * b1; s = s + a2 * b2; return s;
+}
+PWN_HD float dot4seq(float a0, float b0, float a1, float b1, float a2, float b2, float a3, float b3) {
+  float s = a0 * b0; s = s + a1 * b1; s = s + a2 * b2; s = s + a3 * b3; return s;
+}
+
+PWN_HD Mat3 mat3_mul(const Mat3& A, const Mat3& B) {
+  Mat3 R;
+  for (int j = 0; j < 3; ++j)
+    for (int i = 0; i < 3; ++i) R(i,j) = dot3seq(A(i,0), B(0,j), A(i,1), B(1,j), A(i,2), B(2,j));
+  return R;
+}
+PWN_HD Vec3 mat3_mul_vec(const Mat3& A, const Vec3& v) {
+  Vec3 r;
+  r.x = dot3seq(A(0,0), v.x, A(0,1), v.y, A(0,2), v.z);
+  r.y = dot3seq(A(1,0), v.x, A(1,1), v.y, A(1,2), v.z);
+  r.z = dot3seq(A(2,0), v.x, A(2,1), v.y, A(2,2), v.z);
+  return r;
+}
+PWN_HD Mat4 mat4_mul(const Mat4& A, const Mat4& B) {
+  Mat4 R;
+  for (int j = 0; j < 4; ++j)
+    for (int i = 0; i < 4; ++i) R(i,j) = dot4seq(A(i,0), B(0,j), A(i,1), B(1,j), A(i,2), B(2,j), A(i,3), B(3,j));
+  return R;
+}
+PWN_HD Mat3 iso_linear(const Mat4& T) { Mat3 R; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R(i,j) = T(i,j); return R; }
+PWN_HD Mat4 iso_make(const Mat3& R, const Vec3& t) {
+  Mat4 T;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) T(i,j) = R(i,j);
+  T(0,3) = t.x; T(1,3) = t.y; T(2,3) = t.z;
+  set_last_row(T);
+  return T;
+}
+// Isometry3f::inverse(): linear = R^T, translation = (-R^T) * t
+PWN_HD Mat4 iso_inverse(const Mat4& T) {
+  Mat3 Rt, nRt;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { Rt(i,j) = T(j,i); nRt(i,j) = -T(j,i); }
+  Vec3 t = { T(0,3), T(1,3), T(2,3) };
+  return iso_make(Rt, mat3_mul_vec(nRt, t));
+}
+// Isometry3f * Isometry3f: linear = Ra*Rb, translation = Ra*tb + ta
+PWN_HD Mat4 iso_mul(const Mat4& A, const Mat4& B) {
+  Mat3 Ra = iso_linear(A);
+  Mat3 R = mat3_mul(Ra, iso_linear(B));
+  Vec3 tb = { B(0,3), B(1,3), B(2,3) };
+  Vec3 t = mat3_mul_vec(Ra, tb);
+  t.x = t.x + A(0,3); t.y = t.y + A(1,3); t.z = t.z + A(2,3);
+  return iso_make(R, t);
+}
+PWN_HD float cof3(const Mat3& m, int i, int j) {
+  const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+  return m(i1,j1) * m(i2,j2) - m(i1,j2) * m(i2,j1);
+}
+// Matrix3f::inverse(): cofactor expansion, determinant along column 0
+PWN_HD Mat3 mat3_inverse(const Mat3& m) {
+  const float c00 = cof3(m,0,0), c10 = cof3(m,1,0), c20 = cof3(m,2,0);
+  const float invdet = 1.0f / dot3seq(c00, m(0,0), c10, m(1,0), c20, m(2,0));
+  Mat3 r;
+  r(0,0) = c00 * invdet; r(0,1) = c10 * invdet; r(0,2) = c20 * invdet;
+  r(1,0) = cof3(m,0,1) * invdet; r(1,1) = cof3(m,1,1) * invdet; r(1,2) = cof3(m,2,1) * invdet;
+  r(2,0) = cof3(m,0,2) * invdet; r(2,1) = cof3(m,1,2) * invdet; r(2,2) = cof3(m,2,2) * invdet;
+  return r;
+}
+
+// PinholePointProjector::_updateMatrices (reference pwn_core/pinholepointprojector.cpp:17-31)
+PWN_HD void projector_matrices(const Mat3& K, const Mat4& T, Mat4& KRt, Mat4& iKRt, Mat3& iK) {
+  Mat4 t = iso_inverse(T);
+  set_last_row(t);
+  iK = mat3_inverse(K);
+  const Mat3 KR = mat3_mul(K, iso_linear(t));
+  const Vec3 tt = { t(0,3), t(1,3), t(2,3) };
+  const Vec3 Kt = mat3_mul_vec(K, tt);
+  const Mat3 iKR = mat3_mul(iso_linear(T), iK);
+  KRt = mat4_identity(); iKRt = mat4_identity();
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { KRt(i,j) = KR(i,j); iKRt(i,j) = iKR(i,j); }
+  KRt(0,3) = Kt.x; KRt(1,3) = Kt.y; KRt(2,3) = Kt.z;
+  iKRt(0,3) = T(0,3); iKRt(1,3) = T(1,3); iKRt(2,3) = T(2,3);
+}
+
+// pwn_core/bm_se3.h:9-22
+PWN_HD Mat3 quat2mat(float qx, float qy, float qz) {
+  const float qw = sqrtf(1.f - dot3seq(qx, qx, qy, qy, qz, qz));
+  Mat3 R;
+  R(0,0) = qw*qw + qx*qx - qy*qy - qz*qz; R(0,1) = 2*(qx*qy - qw*qz);            R(0,2) = 2*(qx*qz + qw*qy);
+  R(1,0) = 2*(qx*qy + qz*qw);             R(1,1) = qw*qw - qx*qx + qy*qy - qz*qz; R(1,2) = 2*(qy*qz - qx*qw);
+  R(2,0) = 2*(qx*qz - qy*qw);             R(2,1) = 2*(qy*qz + qx*qw);             R(2,2) = qw*qw - qx*qx - qy*qy + qz*qz;
+  return R;
+}
+// Quaternionf(Matrix3f) + normalize() + sign fix (pwn_core/bm_se3.h:25-35)
+PWN_HD Vec3 mat2quat(const Mat3& R) {
+  float q[4];  // x y z w
+  float t = (R(0,0) + R(1,1)) + R(2,2);
+  if (t > 0.f) {
+    t = sqrtf(t + 1.0f);
+    q[3] = 0.5f * t;
+    t = 0.5f / t;
+    q[0] = (R(2,1) - R(1,2)) * t;
+    q[1] = (R(0,2) - R(2,0)) * t;
+    q[2] = (R(1,0) - R(0,1)) * t;
+  } else {
+    int i = 0;
+    if (R(1,1) > R(0,0)) i = 1;
+    if (R(2,2) > R(i,i)) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrtf(R(i,i) - R(j,j) - R(k,k) + 1.0f);
+    q[i] = 0.5f * t;
+    t = 0.5f / t;
+    q[3] = (R(k,j) - R(j,k)) * t;
+    q[j] = (R(j,i) + R(i,j)) * t;
+    q[k] = (R(k,i) + R(i,k)) * t;
+  }
+  const float n = sqrtf((q[0]*q[0] + q[1]*q[1]) + (q[2]*q[2] + q[3]*q[3]));
+  for (int a = 0; a < 4; ++a) q[a] = q[a] / n;
+  Vec3 r = { q[0], q[1], q[2] };
+  if (q[3] < 0.f) { r.x = -r.x; r.y = -r.y; r.z = -r.z; }
+  return r;
+}
+// pwn_core/bm_se3.h:37-43
+PWN_HD Mat4 v2t(const float x[6]) {
+  const Vec3 t = { x[0], x[1], x[2] };
+  return iso_make(quat2mat(x[3], x[4], x[5]), t);
+}
+// pwn_core/bm_se3.h:45-52
+PWN_HD void t2v(const Mat4& T, float v[6]) {
+  v[0] = T(0,3); v[1] = T(1,3); v[2] = T(2,3);
+  const Vec3 q = mat2quat(iso_linear(T));
+  v[3] = q.x; v[4] = q.y; v[5] = q.z;
+}
+
+// ---- SelfAdjointEigenSolver<Matrix3f>::computeDirect(A, ComputeEigenvectors) -------------------------
+// (closed-form roots of the characteristic polynomial on the shifted+scaled matrix, eigenvectors by
+// kernel extraction with cross products).  Reads the lower triangle.  evals ascending.
+PWN_HD Vec3 cross3(const Vec3& a, const Vec3& b) {
+  Vec3 r; r.x = a.y*b.z - a.z*b.y; r.y = a.z*b.x - a.x*b.z; r.z = a.x*b.y - a.y*b.x; return r;
+}
+PWN_HD float sqn3(const Vec3& a) { return dot3seq(a.x, a.x, a.y, a.y, a.z, a.z); }
+PWN_HD Vec3 col3(const Mat3& m, int c) { Vec3 r = { m(0,c), m(1,c), m(2,c) }; return r; }
+
+PWN_HD void eig3_kernel(const Mat3& mat, Vec3& res, Vec3& representative) {
+  int i0 = 0; float best = fabsf(mat(0,0));
+  if (fabsf(mat(1,1)) > best) { best = fabsf(mat(1,1)); i0 = 1; }
+  if (fabsf(mat(2,2)) > best) { i0 = 2; }
+  // columns selected without dynamic indexing
+  const Vec3 a0 = col3(mat, 0), a1 = col3(mat, 1), a2 = col3(mat, 2);
+  const Vec3 rep = (i0 == 0) ? a0 : (i0 == 1 ? a1 : a2);
+  const Vec3 n1 = (i0 == 0) ? a1 : (i0 == 1 ? a2 : a0);
+  const Vec3 n2 = (i0 == 0) ? a2 : (i0 == 1 ? a0 : a1);
+  representative = rep;
+  const Vec3 c0 = cross3(rep, n1), c1 = cross3(rep, n2);
+  const float s0 = sqn3(c0), s1 = sqn3(c1);
+  if (s0 > s1) { const float s = sqrtf(s0); res.x = c0.x / s; res.y = c0.y / s; res.z = c0.z / s; }
+  else         { const float s = sqrtf(s1); res.x = c1.x / s; res.y = c1.y / s; res.z = c1.z / s; }
+}
+
+// a00..a22: lower triangle of the symmetric input (a10 = A(1,0) ...). Outputs eigenvalues e[3] and
+// eigenvectors v0,v1,v2 (columns).
+PWN_HD void eig3_direct(float a00, float a10, float a20, float a11, float a21, float a22,
+                        float e[3], Vec3& v0, Vec3& v1, Vec3& v2) {
+  const float eps = FLT_EPSILON;
+  const float shift = ((a00 + a11) + a22) / 3.0f;
+  Mat3 S;
+  S(0,0) = a00 - shift; S(1,1) = a11 - shift; S(2,2) = a22 - shift;
+  S(1,0) = a10; S(0,1) = a10; S(2,0) = a20; S(0,2) = a20; S(2,1) = a21; S(1,2) = a21;
+  float scale = 0.f;
+  for (int k = 0; k < 9; ++k) scale = fmaxf(scale, fabsf(S.m[k]));
+  if (scale > 0.f) for (int k = 0; k < 9; ++k) S.m[k] = S.m[k] / scale;
+  {  // roots
+    const float s_inv3 = 1.0f / 3.0f;
+    const float s_sqrt3 = sqrtf(3.0f);
+    const float m00 = S(0,0), m11 = S(1,1), m22 = S(2,2), m10 = S(1,0), m20 = S(2,0), m21 = S(2,1);
+    const float c0 = m00*m11*m22 + 2.0f*m10*m20*m21 - m00*m21*m21 - m11*m20*m20 - m22*m10*m10;
+    const float c1 = m00*m11 - m10*m10 + m00*m22 - m20*m20 + m11*m22 - m21*m21;
+    const float c2 = m00 + m11 + m22;
+    const float c2_over_3 = c2 * s_inv3;
+    float a_over_3 = (c2 * c2_over_3 - c1) * s_inv3;
+    a_over_3 = fmaxf(a_over_3, 0.0f);
+    const float half_b = 0.5f * (c0 + c2_over_3 * (2.0f * c2_over_3 * c2_over_3 - c1));
+    float q = a_over_3 * a_over_3 * a_over_3 - half_b * half_b;
+    q = fmaxf(q, 0.0f);
+    const float rho = sqrtf(a_over_3);
+    const float theta = atan2f(sqrtf(q), half_b) * s_inv3;
+    const float cos_theta = cosf(theta);
+    const float sin_theta = sinf(theta);
+    e[0] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
+    e[1] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
+    e[2] = c2_over_3 + 2.0f * rho * cos_theta;
+  }
+  if ((e[2] - e[0]) <= eps) {
+    v0.x = 1.f; v0.y = 0.f; v0.z = 0.f; v1.x = 0.f; v1.y = 1.f; v1.z = 0.f; v2.x = 0.f; v2.y = 0.f; v2.z = 1.f;
+  } else {
+    float d0 = e[2] - e[1];
+    const float d1 = e[1] - e[0];
+    const bool swapped = d0 > d1;        // k = swapped ? 2 : 0 ; l = swapped ? 0 : 2
+    if (swapped) d0 = d1;
+    const float ek = swapped ? e[2] : e[0], el = swapped ? e[0] : e[2];
+    Mat3 tmp = S;
+    tmp(0,0) = tmp(0,0) - ek; tmp(1,1) = tmp(1,1) - ek; tmp(2,2) = tmp(2,2) - ek;
+    Vec3 vk, vl;
+    eig3_kernel(tmp, vk, vl);
+    if (d0 <= 2 * eps * d1) {
+      const float d = dot3seq(vk.x, vl.x, vk.y, vl.y, vk.z, vl.z);
+      vl.x = vl.x - d * vl.x; vl.y = vl.y - d * vl.y; vl.z = vl.z - d * vl.z;
+      const float n = sqrtf(sqn3(vl));
+      vl.x = vl.x / n; vl.y = vl.y / n; vl.z = vl.z / n;
+    } else {
+      tmp = S;
+      tmp(0,0) = tmp(0,0) - el; tmp(1,1) = tmp(1,1) - el; tmp(2,2) = tmp(2,2) - el;
+      Vec3 dummy;
+      eig3_kernel(tmp, vl, dummy);
+    }
+    v0 = swapped ? vl : vk;
+    v2 = swapped ? vk : vl;
+    v1 = cross3(v2, v0);
+    const float z = sqn3(v1);
+    if (z > 0.f) { const float n = sqrtf(z); v1.x = v1.x / n; v1.y = v1.y / n; v1.z = v1.z / n; }
+  }
+  for (int i = 0; i < 3; ++i) { e[i] = e[i] * scale; e[i] = e[i] + shift; }
+}
+
+// ---- Matrix6f::ldlt().solve(b): pivoted (largest |diagonal|) LDL^T, fp32 -------------------------------
+PWN_HD void ldlt_solve6(const float Hin[36], const float bin[6], float x[6]) {
+  const int n = 6;
+  float A[36];
+  for (int i = 0; i < 36; ++i) A[i] = Hin[i];
+#define PWN_A(r, c) A[(r) + 6 * (c)]
+  int tr[6]; float temp[6];
+  for (int i = 0; i < 6; ++i) { tr[i] = i; temp[i] = 0.f; }
+  float cutoff = 0.f;
+  for (int k = 0; k < n; ++k) {
+    int p = k; float big = fabsf(PWN_A(k,k));
+    for (int i = k + 1; i < n; ++i) if (fabsf(PWN_A(i,i)) > big) { big = fabsf(PWN_A(i,i)); p = i; }
+    if (k == 0) cutoff = fabsf(FLT_EPSILON * big);
+    if (big < cutoff) { for (int i = k; i < n; ++i) tr[i] = i; break; }
+    tr[k] = p;
+    if (k != p) {
+      for (int j = 0; j < k; ++j) { const float t = PWN_A(k,j); PWN_A(k,j) = PWN_A(p,j); PWN_A(p,j) = t; }
+      for (int i = p + 1; i < n; ++i) { const float t = PWN_A(i,k); PWN_A(i,k) = PWN_A(i,p); PWN_A(i,p) = t; }
+      { const float t = PWN_A(k,k); PWN_A(k,k) = PWN_A(p,p); PWN_A(p,p) = t; }
+      for (int i = k + 1; i < p; ++i) { const float t = PWN_A(i,k); PWN_A(i,k) = PWN_A(p,i); PWN_A(p,i) = t; }
+    }
+    if (k > 0) {
+      for (int j = 0; j < k; ++j) temp[j] = PWN_A(j,j) * PWN_A(k,j);
+      float d = PWN_A(k,0) * temp[0];
+      for (int j = 1; j < k; ++j) d = d + PWN_A(k,j) * temp[j];
+      PWN_A(k,k) = PWN_A(k,k) - d;
+      for (int i = k + 1; i < n; ++i) {
+        float s = PWN_A(i,0) * temp[0];
+        for (int j = 1; j < k; ++j) s = s + PWN_A(i,j) * temp[j];
+        PWN_A(i,k) = PWN_A(i,k) - s;
+      }
+    }
+    if (k + 1 < n && fabsf(PWN_A(k,k)) > cutoff)
+      for (int i = k + 1; i < n; ++i) PWN_A(i,k) = PWN_A(i,k) / PWN_A(k,k);
+  }
+  float d[6];
+  for (int i = 0; i < 6; ++i) d[i] = bin[i];
+  for (int k = 0; k < n; ++k) if (tr[k] != k) { const float t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
+  for (int i = 1; i < n; ++i) {
+    float s = PWN_A(i,0) * d[0];
+    for (int j = 1; j < i; ++j) s = s + PWN_A(i,j) * d[j];
+    d[i] = d[i] - s;
+  }
+  float dmax = 0.f;
+  for (int i = 0; i < n; ++i) dmax = fmaxf(dmax, fabsf(PWN_A(i,i)));
+  const float tol = fmaxf(dmax * FLT_EPSILON, 1.0f / FLT_MAX);
+  for (int i = 0; i < n; ++i) { if (fabsf(PWN_A(i,i)) > tol) d[i] = d[i] / PWN_A(i,i); else d[i] = 0.f; }
+  for (int i = n - 2; i >= 0; --i) {
+    float s = PWN_A(i+1,i) * d[i+1];
+    for (int j = i + 2; j < n; ++j) s = s + PWN_A(j,i) * d[j];
+    d[i] = d[i] - s;
+  }
+  for (int k = n - 1; k >= 0; --k) if (tr[k] != k) { const float t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
+  for (int i = 0; i < 6; ++i) x[i] = d[i];
+#undef PWN_A
+}
+
+}  // namespace pwnhip

@@ -1,0 +1,219 @@
+/*
+ * pwn_hip.h -- C-ABI of the MI355X (gfx950) PWN dense-registration path.
+ *
+ * This is the drop-in boundary behind the reference's pwn_core C++ API
+ * (grisetti/g2o_frontend, g2o_frontend/pwn_core/).  Every entry point names the reference
+ * method it replaces (file:line relative to g2o_frontend/pwn_core/ unless a directory is given).
+ * The in-tree precedent for a C-style device boundary is pwn_cuda/cudaaligner.h:59-80
+ * (createContext / initComputation / simpleIteration / getHb); the shape below follows it:
+ * opaque context, plain pointers and sizes, int status codes, nothing thrown across the ABI.
+ *
+ * Conventions
+ *   - matrices: COLUMN-MAJOR float (Eigen default, as pwn_cuda/cualigner.cpp:56-67 passes them);
+ *     3x3 = 9 floats, 4x4 isometries = 16 floats, 6x6 = 36 floats.
+ *   - images: row-major [rows][cols]; index images are int32 (-1 = empty), depth images float32
+ *     metres (pwn_typedefs.h:57-62).
+ *   - data pointers may be HOST or DEVICE memory; the library detects which
+ *     (hipPointerGetAttributes) and copies accordingly.  Parameter structs, result structs and
+ *     handle arrays are always host memory.
+ *   - a context is bound to one GPU; calls on one context must be serialised by the caller
+ *     (the reference objects are not re-entrant either: aligner.cpp:60-76 mutates the shared
+ *     projector).  Use one context per (GPU, host thread).
+ *   - all calls are synchronous with respect to the host unless noted: outputs are valid on return.
+ *   - status: 0 = ok; otherwise one of pwn_hip_status; pwn_hip_last_error_string() gives detail.
+ */
+#ifndef PWN_HIP_H
+#define PWN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PWN_HIP_MAX_ITERATIONS 64
+
+typedef enum pwn_hip_status {
+  PWN_HIP_OK = 0,
+  PWN_HIP_ERR_INVALID_ARGUMENT = 1,
+  PWN_HIP_ERR_NO_DEVICE = 2,
+  PWN_HIP_ERR_ALLOCATION = 3,      /* cf. pwn_cuda Operation::Allocation      (cudaaligner.h:11) */
+  PWN_HIP_ERR_COPY = 4,            /* cf. CopyToDevice / CopyFromDevice        (:13-14) */
+  PWN_HIP_ERR_LAUNCH = 5,          /* cf. KernelLaunch                          (:15) */
+  PWN_HIP_ERR_CAPACITY = 6         /* image / batch / cloud larger than the context or handle allows */
+} pwn_hip_status;
+
+typedef struct pwn_hip_ctx pwn_hip_ctx;       /* one per (GPU, host thread) */
+typedef struct pwn_hip_cloud pwn_hip_cloud;   /* device-resident pwn::Cloud (cloud.h:20-187) */
+
+/* Parameters of DepthImageConverterIntegralImage and its four collaborators
+ * (depthimageconverter.h:29-32).  Defaults = the class defaults of the reference. */
+typedef struct pwn_hip_converter_params {
+  float K[9];                            /* PinholePointProjector::setCameraMatrix (pinholepointprojector.h:51) */
+  float min_distance;                    /* PointProjector::setMinDistance (pointprojector.h:62), default 0.01 (pointprojector.cpp:9) */
+  float max_distance;                    /* setMaxDistance (:76), default 6.0 (pointprojector.cpp:10) */
+  float world_radius;                    /* StatsCalculatorIntegralImage::setWorldRadius, 0.1 (statscalculatorintegralimage.cpp:7) */
+  int   min_image_radius;                /* setMinImageRadius, 10 (:9) */
+  int   max_image_radius;                /* setMaxImageRadius, 30 (:8) */
+  int   min_points;                      /* setMinPoints, 50 (:10) */
+  float stats_curvature_threshold;       /* setCurvatureThreshold, 0.02 (:11) */
+  float point_info_curvature_threshold;  /* PointInformationMatrixCalculator::setCurvatureThreshold, 0.02 (informationmatrixcalculator.h:109) */
+  float normal_info_curvature_threshold; /* NormalInformationMatrixCalculator, 0.02 (informationmatrixcalculator.h:144) */
+  float point_flat_diag[3];              /* diag(1000,1,1) (informationmatrixcalculator.h:107) */
+  float point_nonflat_diag[3];           /* diag(1,1,1) (:108); replaced by 1/eigenvalues at use (.cpp:27-29) */
+  float normal_flat_diag[3];             /* diag(100,100,100) (:142) */
+  float normal_nonflat_diag[3];          /* diag(1,1,1) (:143) */
+  float sensor_offset[16];               /* third argument of DepthImageConverter::compute (depthimageconverter.h:47) */
+} pwn_hip_converter_params;
+
+/* Parameters of PinholePointProjector + CorrespondenceFinder + Linearizer + Aligner as the
+ * callers set them before Aligner::align() (pwn_simple_aligner.cpp:214-269, pwn_matcher_base.cpp:107-135). */
+typedef struct pwn_hip_aligner_params {
+  float K[9];                             /* projector camera matrix */
+  float min_distance, max_distance;       /* projector range */
+  int   rows, cols;                       /* PointProjector::setImageSize / CorrespondenceFinder::setImageSize (correspondencefinder.h:211-218) */
+  float inlier_distance_threshold;        /* 0.5  (correspondencefinder.cpp:10) */
+  float inlier_normal_angular_threshold;  /* cos(pi/6) (:12) */
+  float flat_curvature_threshold;         /* 0.02 (:13) */
+  float inlier_curvature_ratio_threshold; /* 1.3  (:14) */
+  float inlier_max_chi2;                  /* 9e3  (linearizer.cpp:13) */
+  int   robust_kernel;                    /* 1    (linearizer.cpp:14) */
+  int   outer_iterations;                 /* 10   (aligner.cpp:19) */
+  int   inner_iterations;                 /* 1    (aligner.cpp:20) */
+  float reference_sensor_offset[16];      /* Aligner::setReferenceSensorOffset (aligner.h:168-171) */
+  float current_sensor_offset[16];        /* Aligner::setCurrentSensorOffset (aligner.h:187-190) */
+  float initial_guess[16];                /* Aligner::setInitialGuess (aligner.h:130-133) */
+} pwn_hip_aligner_params;
+
+/* What Aligner exposes after align(): T() (aligner.h:115), error() (:320), inliers() (:326),
+ * totalTime() (:332), plus the per-iteration counters SURVEY.md §8(d) asks the kernels to emit. */
+typedef struct pwn_hip_align_result {
+  float T[16];                                 /* Aligner::T(): current -> reference frame */
+  float error;                                 /* value of the LAST in-loop Linearizer::update (aligner.cpp:124) */
+  int   inliers;                               /* aligner.cpp:125 */
+  int   iterations;                            /* outer*inner linearizer updates executed */
+  float total_time_ms;                         /* GPU time of this alignment (batch: batch time / n) */
+  float chi2[PWN_HIP_MAX_ITERATIONS];          /* Linearizer::error() after each update */
+  int   iter_inliers[PWN_HIP_MAX_ITERATIONS];  /* Linearizer::inliers() */
+  int   iter_correspondences[PWN_HIP_MAX_ITERATIONS]; /* C_i: CorrespondenceFinder::numCorrespondences() */
+  int   iter_candidates[PWN_HIP_MAX_ITERATIONS];      /* K_i: pixels with both index images >= 0 */
+  int   n_reference, n_current;                /* M_r, M_c */
+} pwn_hip_align_result;
+
+/* ------------------------------------------------------------------ context ------------------ */
+/* cf. pwn_cuda createContext(AlignerContext**, maxRef, maxCur, rows, cols) (cudaaligner.h:59).
+ * max_batch = largest number of frames (convert_batch) / pairs (align_batch) per call. */
+int pwn_hip_ctx_create(pwn_hip_ctx** ctx, int device, int max_rows, int max_cols, int max_batch);
+int pwn_hip_ctx_destroy(pwn_hip_ctx* ctx);                       /* cf. destroyContext (cudaaligner.h:61) */
+/* hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the context's own stream */
+int pwn_hip_ctx_set_stream(pwn_hip_ctx* ctx, void* hip_stream);
+int pwn_hip_ctx_synchronize(pwn_hip_ctx* ctx);
+/* Batch calls are executed in sub-batches of this many frames / pairs so that the per-item temporaries
+ * (integral image, z-buffers) stay resident in the 256 MiB Infinity Cache.  Results do not depend on it. */
+int pwn_hip_ctx_set_subbatch(pwn_hip_ctx* ctx, int frames, int pairs);
+/* ctx may be NULL (errors of ctx_create). Never returns NULL. cf. AlignerStatus::toString (cudaaligner.h:54) */
+const char* pwn_hip_last_error_string(const pwn_hip_ctx* ctx);
+/* number of HIP devices visible; does not initialise a device */
+int pwn_hip_device_count(void);
+
+void pwn_hip_default_converter_params(pwn_hip_converter_params* p);
+void pwn_hip_default_aligner_params(pwn_hip_aligner_params* p);
+
+/* ------------------------------------------------------------------ clouds ------------------- */
+/* capacity = maximum number of points (rows*cols of the images it will be converted from) */
+int pwn_hip_cloud_create(pwn_hip_ctx* ctx, int capacity, pwn_hip_cloud** cloud);
+int pwn_hip_cloud_destroy(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud);
+int pwn_hip_cloud_size(pwn_hip_ctx* ctx, const pwn_hip_cloud* cloud, int* n);    /* Cloud::points().size() */
+/* Upload a host/device pwn::Cloud: points/normals n*4 floats (Point/Normal, homogeneousvector4f.h:78-93),
+ * curvature n floats (Stats::curvature(), stats.h:98-103), omega_p/omega_n n*16 floats
+ * (InformationMatrix 4x4, informationmatrix.h:13).  cf. pwn_cuda initComputation (cudaaligner.h:63-75). */
+int pwn_hip_cloud_upload(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud, int n, const float* points, const float* normals,
+                         const float* curvature, const float* omega_p, const float* omega_n);
+/* Any output may be NULL.  Same layouts as upload. */
+int pwn_hip_cloud_download(pwn_hip_ctx* ctx, const pwn_hip_cloud* cloud, float* points, float* normals,
+                           float* curvature, float* omega_p, float* omega_n);
+/* Stats of the last convert of this cloud (only if the convert ran with keep_stats != 0): per point
+ * eigenvectors+mean as a column-major 4x4 (Stats, stats.h:13), eigenvalues[3], n (stats.h:30). */
+int pwn_hip_cloud_download_stats(pwn_hip_ctx* ctx, const pwn_hip_cloud* cloud, float* stats, float* eigenvalues, int* npoints);
+/* Cloud::transformInPlace (cloud.cpp:173-186) */
+int pwn_hip_cloud_transform_in_place(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud, const float T[16]);
+
+/* ------------------------------------------------------------------ input conditioning ------- */
+/* DepthImage_convert_16UC1_to_32FC1 (pwn_static.cpp:54-68) */
+int pwn_hip_depth_u16_to_f32(pwn_hip_ctx* ctx, const uint16_t* src, float* dst, int n, float scale);
+/* DepthImage_convert_32FC1_to_16UC1 (pwn_static.cpp:38-52) */
+int pwn_hip_depth_f32_to_u16(pwn_hip_ctx* ctx, const float* src, uint16_t* dst, int n, float scale);
+/* DepthImage_scale (pwn_static.cpp:5-36); dst holds (rows/step)*(cols/step) floats */
+int pwn_hip_depth_scale(pwn_hip_ctx* ctx, const float* src, int rows, int cols, int step, float max_depth_cov, float* dst);
+
+/* ------------------------------------------------------------------ converter stages --------- */
+/* PinholePointProjector::unProject(points, gaussians, indexImage, depthImage) (pinholepointprojector.cpp:93-133)
+ * with the projector transform T (identity inside the converter).  Fills cloud points (normals etc. are
+ * reset to "invalid").  The per-point sensor Gaussians are not produced (only Merger consumes them). */
+int pwn_hip_unproject(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float T[16], const float* depth,
+                      int rows, int cols, pwn_hip_cloud* cloud, int* index_image);
+/* PinholePointProjector::projectIntervals (pinholepointprojector.cpp:135-147) */
+int pwn_hip_project_intervals(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float* depth, int rows, int cols,
+                              int* interval_image);
+/* PointIntegralImage::compute (pointintegralimage.cpp:7-44): the 10 unique channels
+ * (x,y,z,n,xx,xy,xz,yy,yz,zz) as planes out[10][rows][cols]. Diagnostic / parity entry point. */
+int pwn_hip_integral_image(pwn_hip_ctx* ctx, const int* index_image, const pwn_hip_cloud* cloud, int rows, int cols, float* out);
+/* DepthImageConverterIntegralImage::compute(cloud, depthImage, sensorOffset)
+ * (depthimageconverterintegralimage.cpp:15-55).  index_image / interval_image: optional outputs
+ * (DepthImageConverter::indexImage(), depthimageconverter.h:111). keep_stats: also keep per-point Stats. */
+int pwn_hip_convert(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float* depth, int rows, int cols,
+                    pwn_hip_cloud* cloud, int* index_image, int* interval_image, int keep_stats);
+/* n independent frames of equal size in one call.  depth[i] -> clouds[i].
+ * depth_frames: n pointers (host array) to rows*cols floats each (each host or device). */
+int pwn_hip_convert_batch(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float* const* depth_frames,
+                          int n, int rows, int cols, pwn_hip_cloud* const* clouds);
+/* Same, from raw uint16 millimetre frames: fuses DepthImage_convert_16UC1_to_32FC1 (scale) in front. */
+int pwn_hip_convert_batch_u16(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const uint16_t* const* raw_frames,
+                              float depth_scale, int n, int rows, int cols, pwn_hip_cloud* const* clouds);
+
+/* ------------------------------------------------------------------ aligner stages ----------- */
+/* PinholePointProjector::project(indexImage, depthImage, points) (pinholepointprojector.cpp:33-66) with
+ * projector transform T.  Untouched depth pixels are FLT_MAX, index -1; ties keep the lowest index. */
+int pwn_hip_project(pwn_hip_ctx* ctx, const float K[9], const float T[16], float min_distance, float max_distance,
+                    int rows, int cols, const pwn_hip_cloud* cloud, int* index_image, float* depth_image);
+/* CorrespondenceFinder::compute (correspondencefinder.cpp:20-118, single-thread canonical order).
+ * correspondences: rows*cols pairs (referenceIndex,currentIndex) -- the first *n_correspondences are
+ * valid, in row-major pixel order, the rest are (-1,-1) (correspondencefinder.cpp:116-117). */
+int pwn_hip_correspondences(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, const pwn_hip_cloud* reference,
+                            const pwn_hip_cloud* current, const int* reference_index_image, const int* current_index_image,
+                            const float T[16], int* correspondences, int* n_correspondences, int* n_candidates);
+/* Linearizer::update (linearizer.cpp:17-115) on an explicit correspondence list with transform T (= invT).
+ * H: column-major 6x6 (Linearizer::H()), b: 6 (Linearizer::b()). cf. pwn_cuda getHb (cudaaligner.h:79). */
+int pwn_hip_linearize(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, const pwn_hip_cloud* reference,
+                      const pwn_hip_cloud* current, const int* correspondences, int n_correspondences, const float T[16],
+                      float* H, float* b, float* error, int* inliers);
+/* Aligner::align (aligner.cpp:49-125): project current once, then outer x inner Gauss-Newton
+ * iterations of {project reference, find correspondences, linearize, damped LDLT solve, update}.
+ * The whole loop runs on the device without host round trips. Priors and _computeStatistics
+ * (aligner.cpp:96-108,127) are not part of this entry point. */
+int pwn_hip_align(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, const pwn_hip_cloud* reference,
+                  const pwn_hip_cloud* current, pwn_hip_align_result* result);
+/* CorrespondenceFinder::{reference,current}{Index,Depth}Image() after the last pwn_hip_align
+ * (correspondencefinder.h:99-117; read by pwn_tracker/pwn_matcher_base.cpp:153-155). Any may be NULL. */
+int pwn_hip_align_images(pwn_hip_ctx* ctx, int* reference_index, float* reference_depth, int* current_index, float* current_depth);
+/* n independent alignments (the loop-closure candidate batch, pwn_tracker/pwn_closer.cpp:92-111).
+ * p is shared by all pairs; initial_guesses: n*16 floats or NULL (= p->initial_guess for all). */
+int pwn_hip_align_batch(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* references,
+                        pwn_hip_cloud* const* currents, const float* initial_guesses, pwn_hip_align_result* results);
+
+/* ------------------------------------------------------------------ helpers ------------------ */
+/* PinholePointProjector::_updateMatrices (pinholepointprojector.cpp:17-31): KRt, iKRt (4x4), iK (3x3) */
+void pwn_hip_projector_matrices(const float K[9], const float T[16], float KRt[16], float iKRt[16], float iK[9]);
+/* bm_se3.h:37-52 */
+void pwn_hip_v2t(const float v[6], float T[16]);
+void pwn_hip_t2v(const float T[16], float v[6]);
+/* per-kernel device time (ms) of the stages of the last batch/single call, for bench.py:
+ * names: "unproject","integral_rows","integral_cols","stats","project","corr_linearize","solve" */
+int pwn_hip_last_stage_ms(pwn_hip_ctx* ctx, const char* stage, float* ms, int* launches);
+/* enable/disable hipEvent timing around every kernel launch (adds host overhead; default off) */
+int pwn_hip_set_profiling(pwn_hip_ctx* ctx, int enabled);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
