@@ -1,0 +1,258 @@
+#!/usr/bin/env python3
+"""Headline benchmark: depth-pair alignments/second (640x480, 10 Gauss-Newton iterations) on N MI355X.
+
+Workload (BASELINE.json configs[3] sharded as SURVEY.md §8(e) prescribes; at N=8 it is exactly the
+1024-pair loop-closure batch, at N=1 it is one GPU's 128-pair shard): every rank owns `--pairs`
+independent synthetic VGA depth pairs, resident in HBM as uint16 millimetre frames when the timed region
+starts.  One step = for every pair: DepthImage_convert_16UC1_to_32FC1 + DepthImageConverterIntegralImage::compute
+on both frames, then Aligner::align (10 outer x 1 inner iterations), then (N>1) an RCCL all-gather of the
+4x4 poses.  Nothing is cached between steps.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, live hipEvent
+timing inside the timed region) and `cpu_baseline` (the CPU oracle = a port of the reference path, timed on
+this box's host cores on a bounded sample of the same workload).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=128, help="depth pairs per GPU (weak scaling)")
+    ap.add_argument("--rows", type=int, default=480)
+    ap.add_argument("--cols", type=int, default=640)
+    ap.add_argument("--sub-frames", type=int, default=int(os.environ.get("PWN_SUB_FRAMES", 8)))
+    ap.add_argument("--sub-pairs", type=int, default=int(os.environ.get("PWN_SUB_PAIRS", 8)))
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-latency", action="store_true")
+    ap.add_argument("--align-only", action="store_true", help="also time align-only (clouds resident)")
+    ap.add_argument("--no-profile", action="store_true", help="no per-kernel hipEvent timing in the timed region (roofline fields become 0)")
+    return ap.parse_args()
+
+
+def conf(rows, cols):
+    from g2o_frontend_amd import synth
+    from oracle import oracle as O   # parameter tables only (the oracle is the checker / cpu_baseline, never the product path)
+    if (rows, cols) == (960, 1280):
+        K = synth.K_1280
+        conv = dict(O.VGA_CONF_CONVERTER, min_image_radius=20, max_image_radius=60, min_points=200)
+    else:
+        K = synth.K_VGA if (rows, cols) == (480, 640) else synth.scaled_K(synth.K_VGA, 640 // cols)
+        conv = dict(O.VGA_CONF_CONVERTER)
+    return K, conv, dict(O.VGA_CONF_ALIGNER)
+
+
+def build_objects(ctx, rows, cols, K, conv, alig):
+    from g2o_frontend_amd import api
+    proj = api.PinholePointProjector()
+    proj.setCameraMatrix([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]])
+    proj.setMinDistance(conv["min_distance"]); proj.setMaxDistance(conv["max_distance"]); proj.setImageSize(rows, cols)
+    st = api.StatsCalculatorIntegralImage()
+    st.setWorldRadius(conv["world_radius"]); st.setMinImageRadius(conv["min_image_radius"]); st.setMaxImageRadius(conv["max_image_radius"])
+    st.setMinPoints(conv["min_points"]); st.setCurvatureThreshold(conv["stats_curvature_threshold"])
+    pi, ni = api.PointInformationMatrixCalculator(), api.NormalInformationMatrixCalculator()
+    pi.setCurvatureThreshold(conv["point_info_curvature_threshold"]); ni.setCurvatureThreshold(conv["normal_info_curvature_threshold"])
+    converter = api.DepthImageConverterIntegralImage(proj, st, pi, ni)
+    f = api.CorrespondenceFinder()
+    f.setInlierDistanceThreshold(alig["inlier_distance_threshold"]); f.setInlierNormalAngularThreshold(alig["inlier_normal_angular_threshold"])
+    f.setFlatCurvatureThreshold(alig["flat_curvature_threshold"]); f.setInlierCurvatureRatioThreshold(alig["inlier_curvature_ratio_threshold"])
+    f.setImageSize(rows, cols)
+    lin = api.Linearizer(); lin.setInlierMaxChi2(alig["inlier_max_chi2"]); lin.setRobustKernel(alig["robust_kernel"])
+    al = api.Aligner(ctx)
+    al.setProjector(proj); al.setLinearizer(lin); al.setCorrespondenceFinder(f)
+    al.setOuterIterations(alig["outer_iterations"]); al.setInnerIterations(alig["inner_iterations"])
+    return converter, al
+
+
+def cpu_baseline(rows, cols, K, conv, alig, seeds, budget_s):
+    """The CPU oracle (port of the reference CPU path) on a bounded sample of the same workload, one thread."""
+    from g2o_frontend_amd import synth
+    from oracle import oracle as O
+    O.set_num_threads(1)
+    cp = O.converter_params(K=K, **conv)
+    apar = O.aligner_params(rows, cols, K=K, **alig)
+    done, t_conv, t_align, t0 = 0, 0.0, 0.0, time.perf_counter()
+    for s in seeds:
+        ref_mm, cur_mm, _ = synth.make_pair(s, rows, cols, K)
+        a = time.perf_counter()
+        ref = O.convert_16u_to_32f(ref_mm); cur = O.convert_16u_to_32f(cur_mm)
+        cr, _, _ = O.convert(cp, ref); cc, _, _ = O.convert(cp, cur)
+        b = time.perf_counter()
+        O.align(apar, cr, cc)
+        c = time.perf_counter()
+        t_conv += b - a; t_align += c - b; done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    tot = t_conv + t_align
+    return {"value": done / tot, "unit": "alignments/s", "cores": 1, "kind": "port",
+            "sample": f"{done} of the benchmark's {rows}x{cols} pairs (convert 2 frames + align, 10 GN iterations), "
+                      f"single thread, {tot:.1f} s CPU ({t_conv / done * 1e3:.0f} ms convert + {t_align / done * 1e3:.0f} ms align per pair)",
+            "align_only_value": done / t_align}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
+    rows, cols, P = args.rows, args.cols, args.pairs
+    N = rows * cols
+    K, conv, alig = conf(rows, cols)
+    n_it = alig["outer_iterations"] * alig["inner_iterations"]
+
+    # CPU baseline first (rank 0 only), before anything touches the GPU
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(rows, cols, K, conv, alig, list(range(0, 64)), args.cpu_seconds)
+
+    import torch
+    import torch.distributed as dist
+    from g2o_frontend_amd import api, synth
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+
+    slots = max(args.sub_frames, args.sub_pairs, 1)
+    ctx = api.Context(device=local, max_rows=rows, max_cols=cols, max_batch=slots)
+    ctx.set_subbatch(args.sub_frames, args.sub_pairs)
+    converter, aligner = build_objects(ctx, rows, cols, K, conv, alig)
+
+    # synthetic inputs of this rank's shard, uploaded to HBM (uint16 mm frames)
+    seeds = [rank * P + i for i in range(P)]
+    ref_dev, cur_dev = [], []
+    for s in seeds:
+        ref_mm, cur_mm, _ = synth.make_pair(s, rows, cols, K)
+        ref_dev.append(torch.from_numpy(ref_mm.view(np.int16)).cuda())
+        cur_dev.append(torch.from_numpy(cur_mm.view(np.int16)).cuda())
+    refs = [api.Cloud(ctx, N) for _ in range(P)]
+    curs = [api.Cloud(ctx, N) for _ in range(P)]
+    poses = torch.empty((P, 16), dtype=torch.float32, device="cuda")
+    gathered = torch.empty((world * P, 16), dtype=torch.float32, device="cuda") if world > 1 else None
+
+    stage_names = ["u16_to_f32", "unproject", "integral_rows", "integral_cols", "stats", "project", "corr_linearize", "solve"]
+    stage_ms = {k: 0.0 for k in stage_names}
+    stage_n = {k: 0 for k in stage_names}
+    last = {}
+
+    def step(profile):
+        converter.computeBatch(refs + curs, ref_dev + cur_dev, raw_scale=0.001)
+        if profile:
+            for k in stage_names[:5]:
+                ms, n = ctx.stage_ms(k); stage_ms[k] += ms; stage_n[k] += n
+        res = aligner.alignBatch(refs, curs)
+        if profile:
+            for k in stage_names[5:]:
+                ms, n = ctx.stage_ms(k); stage_ms[k] += ms; stage_n[k] += n
+        T = np.stack([r["T"].T.reshape(-1) for r in res]).astype(np.float32)
+        poses.copy_(torch.from_numpy(T), non_blocking=False)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, poses)      # RCCL: the only collective of the path
+        last["res"] = res
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    ctx.set_profiling(not args.no_profile)      # hipEvent pairs around every kernel stage, on the library's stream
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    res = last["res"]
+    # measured counters of SURVEY.md §8(d): M_r, M_c, K_i, C_i -> algorithmic bytes
+    Mr = np.array([r["n_reference"] for r in res], np.float64); Mc = np.array([r["n_current"] for r in res], np.float64)
+    Ks = np.array([r["K"].sum() for r in res], np.float64); Cs = np.array([r["C"].sum() for r in res], np.float64)
+    bytes_convert = 2 * 8.0 * N + 64.0 * (Mr + Mc)                                   # two frames: 8N + 64M each
+    bytes_fused = n_it * 8.0 * N + 72.0 * Ks + 28.0 * Cs                              # per pair, all iterations
+    bytes_project = 16.0 * Mc + 4.0 * N + n_it * (16.0 * Mr + 4.0 * N)
+    bytes_align = bytes_project + bytes_fused + 8.0 * N
+    total_bytes_step = float((bytes_convert + bytes_align).sum())
+
+    extra = {}
+    if args.align_only:
+        barrier(); a = time.perf_counter()
+        for _ in range(args.steps):
+            aligner.alignBatch(refs, curs)
+        barrier(); extra["align_only_alignments_per_s"] = world * P * args.steps / (time.perf_counter() - a)
+    if not args.no_latency and rank == 0:
+        ctx.set_profiling(False)
+        lat = []
+        for _ in range(5):
+            torch.cuda.synchronize(); a = time.perf_counter()
+            converter.computeBatch([refs[0], curs[0]], [ref_dev[0], cur_dev[0]], raw_scale=0.001)
+            aligner.alignBatch([refs[0]], [curs[0]])
+            lat.append((time.perf_counter() - a) * 1e3)
+        extra["single_pair_latency_ms"] = float(np.median(lat))
+
+    if rank == 0:
+        value = world * P * args.steps / dt
+        launches = max(stage_n["corr_linearize"], 1)
+        dom = max(stage_names, key=lambda k: stage_ms[k])
+        # dominant kernel: the fused correspondence+linearize pass (one launch = one iteration of one sub-batch)
+        k_ms = stage_ms["corr_linearize"] / launches
+        k_bytes = float(bytes_fused.sum()) * args.steps / launches
+        achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get("k_corr_linearize_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "depth-pair alignments/sec (640x480, 10 GN iters)", "value": value, "unit": "alignments/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"loop-closure batch: {P} independent {cols}x{rows} depth pairs per GPU "
+                                   f"(u16 mm frames resident in HBM; per pair: convert 2 frames + Aligner::align, "
+                                   f"{alig['outer_iterations']}x{alig['inner_iterations']} GN iterations); BASELINE configs[3] shard",
+                       "pairs_per_gpu": P, "rows": rows, "cols": cols, "sub_frames": args.sub_frames, "sub_pairs": args.sub_pairs,
+                       "parallelism": f"independent pairs sharded over {world} GPU(s), RCCL all-gather of poses only"},
+            "roofline": {"bound": "hbm", "kernel": "k_corr_linearize", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "bytes_per_launch_algorithmic": k_bytes, "avg_launch_ms": k_ms, "launches": stage_n["corr_linearize"],
+                         "dominant_by_time": dom},
+            "cpu_baseline": cpu,
+            "path_roofline": {"algorithmic_bytes_per_pair": total_bytes_step / P, "achieved_GBps": total_bytes_step * args.steps / dt / 1e9,
+                              "frac_of_peak": total_bytes_step * args.steps / dt / 1e9 / HBM_PEAK_GBS},
+            "stage_ms_per_step": {k: stage_ms[k] / args.steps for k in stage_names},
+            "stage_launches_per_step": {k: stage_n[k] / args.steps for k in stage_names},
+            "counters_mean": {"M_ref": float(Mr.mean()), "M_cur": float(Mc.mean()), "K_sum": float(Ks.mean()), "C_sum": float(Cs.mean()),
+                              "chi2_final": float(np.mean([r["error"] for r in res])), "inliers_final": float(np.mean([r["inliers"] for r in res]))},
+        }
+        out.update(extra)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

@@ -45,11 +45,12 @@ struct pwn_hip_ctx {
   float* depth_ws = nullptr; int* index_ws = nullptr; int* interval_ws = nullptr; float* integral_ws = nullptr; int* rowoff_ws = nullptr;
   uint16_t* raw_ws = nullptr;
   // align workspaces (per slot)
-  unsigned long long* zref_ws = nullptr; unsigned long long* zcur_ws = nullptr; double* partials_ws = nullptr; PairState* state_ws = nullptr;
+  unsigned long long* zref_ws = nullptr; unsigned long long* zcur_ws = nullptr; int* curidx_ws = nullptr; double* partials_ws = nullptr; PairState* state_ws = nullptr;
   int nblocks_max = 0;
-  // descriptors
-  FrameDesc* frames_dev = nullptr; PairDesc* pairs_dev = nullptr; RawDesc* raw_dev = nullptr;
-  FrameDesc* frames_host = nullptr; PairDesc* pairs_host = nullptr; RawDesc* raw_host = nullptr; PairState* state_host = nullptr;
+  // descriptors (one entry per frame / pair of a batch call; grown on demand)
+  int desc_cap = 0;
+  FrameDesc* frames_dev = nullptr; PairDesc* pairs_dev = nullptr; RawDesc* raw_dev = nullptr; int* counts_dev = nullptr;
+  FrameDesc* frames_host = nullptr; PairDesc* pairs_host = nullptr; RawDesc* raw_host = nullptr; PairState* state_host = nullptr; int* counts_host = nullptr;
   // misc scratch
   SolveOut* solve_dev = nullptr; int* counters_dev = nullptr; int2* corr_ws = nullptr; int* scratch_count = nullptr;
   float* io_ws = nullptr;   // N*16 floats staging for cloud up/download
@@ -90,7 +91,8 @@ hipError_t copy_any(void* dst, const void* src, size_t bytes, hipStream_t s) {
 
 hipEvent_t get_event(pwn_hip_ctx* ctx) {
   if (!ctx->event_pool.empty()) { hipEvent_t e = ctx->event_pool.back(); ctx->event_pool.pop_back(); return e; }
-  hipEvent_t e; (void)hipEventCreate(&e); return e;
+  // timing-only events: no system-scope fence (no cache write-back / invalidate between the kernels they bracket)
+  hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableSystemFence); return e;
 }
 struct StageTimer {
   pwn_hip_ctx* ctx; EventRec rec; bool on;
@@ -170,24 +172,50 @@ int check_image(pwn_hip_ctx* ctx, int rows, int cols) {
 }
 int align_nblocks(int N) { return (N + kAlignBlock * kPixPerThread - 1) / (kAlignBlock * kPixPerThread); }
 
-// launch sequence of the converter for frames [0, n) described in ctx->frames_host
-int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int n) {
-  HIPCHK(ctx, hipMemcpyAsync(ctx->frames_dev, ctx->frames_host, sizeof(FrameDesc) * n, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
+// descriptor / state arrays for a batch of n items
+int ensure_desc(pwn_hip_ctx* ctx, int n) {
+  if (n <= ctx->desc_cap) return PWN_HIP_OK;
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+  void* dev[] = { ctx->frames_dev, ctx->pairs_dev, ctx->raw_dev, ctx->counts_dev, ctx->state_ws };
+  for (void* p : dev) if (p) (void)hipFree(p);
+  void* host[] = { ctx->frames_host, ctx->pairs_host, ctx->raw_host, ctx->state_host, ctx->counts_host };
+  for (void* p : host) if (p) (void)hipHostFree(p);
+  ctx->frames_dev = nullptr; ctx->pairs_dev = nullptr; ctx->raw_dev = nullptr; ctx->counts_dev = nullptr; ctx->state_ws = nullptr;
+  ctx->frames_host = nullptr; ctx->pairs_host = nullptr; ctx->raw_host = nullptr; ctx->state_host = nullptr; ctx->counts_host = nullptr;
+  ctx->desc_cap = 0;
+  const size_t B = (size_t)std::max(n, 16);
+  HIPCHK(ctx, hipMalloc((void**)&ctx->frames_dev, B * sizeof(FrameDesc)), PWN_HIP_ERR_ALLOCATION);
+  HIPCHK(ctx, hipMalloc((void**)&ctx->pairs_dev, B * sizeof(PairDesc)), PWN_HIP_ERR_ALLOCATION);
+  HIPCHK(ctx, hipMalloc((void**)&ctx->raw_dev, B * sizeof(RawDesc)), PWN_HIP_ERR_ALLOCATION);
+  HIPCHK(ctx, hipMalloc((void**)&ctx->counts_dev, B * sizeof(int)), PWN_HIP_ERR_ALLOCATION);
+  HIPCHK(ctx, hipMalloc((void**)&ctx->state_ws, B * sizeof(PairState)), PWN_HIP_ERR_ALLOCATION);
+  HIPCHK(ctx, hipHostMalloc((void**)&ctx->frames_host, B * sizeof(FrameDesc)), PWN_HIP_ERR_ALLOCATION);
+  HIPCHK(ctx, hipHostMalloc((void**)&ctx->pairs_host, B * sizeof(PairDesc)), PWN_HIP_ERR_ALLOCATION);
+  HIPCHK(ctx, hipHostMalloc((void**)&ctx->raw_host, B * sizeof(RawDesc)), PWN_HIP_ERR_ALLOCATION);
+  HIPCHK(ctx, hipHostMalloc((void**)&ctx->state_host, B * sizeof(PairState)), PWN_HIP_ERR_ALLOCATION);
+  HIPCHK(ctx, hipHostMalloc((void**)&ctx->counts_host, B * sizeof(int)), PWN_HIP_ERR_ALLOCATION);
+  ctx->desc_cap = (int)B;
+  return PWN_HIP_OK;
+}
+
+// launch sequence of the converter for the frames [base, base+n) of the uploaded descriptor array
+int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n) {
+  const FrameDesc* fr = ctx->frames_dev + base;
   { StageTimer t(ctx, "unproject");
-    hipLaunchKernelGGL(k_row_count, dim3(cp.rows, n), dim3(256), 0, ctx->stream, ctx->frames_dev, cp);
-    hipLaunchKernelGGL(k_row_offsets, dim3(n), dim3(1024), 0, ctx->stream, ctx->frames_dev, cp.rows);
-    hipLaunchKernelGGL(k_unproject, dim3(cp.rows, n), dim3(256), 0, ctx->stream, ctx->frames_dev, cp); }
+    hipLaunchKernelGGL(k_row_count, dim3(cp.rows, n), dim3(256), 0, ctx->stream, fr, cp);
+    hipLaunchKernelGGL(k_row_offsets, dim3(n), dim3(1024), 0, ctx->stream, fr, cp.rows);
+    hipLaunchKernelGGL(k_unproject, dim3(cp.rows, n), dim3(256), 0, ctx->stream, fr, cp); }
   { StageTimer t(ctx, "integral_rows");
-    hipLaunchKernelGGL(k_integral_rows, dim3((cp.rows + kIR_Rows - 1) / kIR_Rows, n), dim3(256), 0, ctx->stream, ctx->frames_dev, cp.rows, cp.cols); }
+    hipLaunchKernelGGL(k_integral_rows, dim3((cp.rows + kIR_Rows - 1) / kIR_Rows, n), dim3(256), 0, ctx->stream, fr, cp.rows, cp.cols); }
   { StageTimer t(ctx, "integral_cols");
-    hipLaunchKernelGGL(k_integral_cols, dim3((cp.cols + 255) / 256, kIntegralChannels, n), dim3(256), 0, ctx->stream, ctx->frames_dev, cp.rows, cp.cols); }
+    hipLaunchKernelGGL(k_integral_cols, dim3((cp.cols + 255) / 256, kIntegralChannels, n), dim3(256), 0, ctx->stream, fr, cp.rows, cp.cols); }
   { StageTimer t(ctx, "stats");
-    hipLaunchKernelGGL(k_stats, dim3((cp.cols + 255) / 256, cp.rows, n), dim3(256), 0, ctx->stream, ctx->frames_dev, cp); }
+    hipLaunchKernelGGL(k_stats, dim3((cp.cols + 255) / 256, cp.rows, n), dim3(256), 0, ctx->stream, fr, cp); }
   HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
   return PWN_HIP_OK;
 }
-void fill_frame(pwn_hip_ctx* ctx, int slot, const float* depth_dev, const CloudDev& cl, int rows) {
-  FrameDesc& f = ctx->frames_host[slot];
+void fill_frame(pwn_hip_ctx* ctx, int entry, int slot, const float* depth_dev, const CloudDev& cl, int rows) {
+  FrameDesc& f = ctx->frames_host[entry];
   f.depth = depth_dev;
   f.index = ctx->index_ws + (size_t)slot * ctx->N;
   f.interval = ctx->interval_ws + (size_t)slot * ctx->N;
@@ -201,14 +229,17 @@ int ensure_stats(pwn_hip_ctx* ctx, pwn_hip_cloud* c) {
   return PWN_HIP_OK;
 }
 int sync_and_counts(pwn_hip_ctx* ctx, pwn_hip_cloud* const* clouds, int n) {
-  std::vector<int> counts(n);
-  for (int i = 0; i < n; ++i) HIPCHK(ctx, hipMemcpyAsync(&counts[i], clouds[i]->d.count, sizeof(int), hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
-  HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
-  for (int i = 0; i < n; ++i) {
-    if (counts[i] > clouds[i]->d.capacity) return fail(ctx, PWN_HIP_ERR_CAPACITY, "cloud capacity smaller than the number of valid depth pixels");
-    clouds[i]->n_host = counts[i];
+  // frames_dev[0..n) must describe clouds[0..n)
+  if (n > 0) {
+    hipLaunchKernelGGL(k_gather_counts, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->frames_dev, n, ctx->counts_dev);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->counts_host, ctx->counts_dev, sizeof(int) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
   }
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
   collect_stage_times(ctx);
+  for (int i = 0; i < n; ++i) {
+    if (ctx->counts_host[i] > clouds[i]->d.capacity) return fail(ctx, PWN_HIP_ERR_CAPACITY, "cloud capacity smaller than the number of valid depth pixels");
+    clouds[i]->n_host = ctx->counts_host[i];
+  }
   return PWN_HIP_OK;
 }
 
@@ -221,46 +252,52 @@ int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, cons
   ctx->stages.clear();
   const ConvertParams cp = make_convert_params(p, nullptr, rows, cols, keep_stats);
   const int sub = std::max(1, std::min(ctx->sub_frames, ctx->max_batch));
+  if (int rc = ensure_desc(ctx, n)) return rc;
+  const bool raw = std::is_same<SRC, uint16_t>::value;
+  // every frame gets a descriptor; workspace slots are reused round-robin (stream order serialises the reuse)
+  for (int i = 0; i < n; ++i) {
+    pwn_hip_cloud* c = clouds[i];
+    if (!c || !frames[i]) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null frame or cloud");
+    if (keep_stats) { if (int rc = ensure_stats(ctx, c)) return rc; }
+    c->has_stats = keep_stats != 0;
+    if (c->d.OmN) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH); (void)hipFree(c->d.OmN); c->d.OmN = nullptr; }
+    make_omega_n_classes(p, c->d);
+    const int slot = i % sub;
+    const float* depth_dev = nullptr;
+    if (raw) {
+      const uint16_t* src = reinterpret_cast<const uint16_t*>(frames[i]);
+      ctx->raw_host[i].src = src;                                   // patched below if it is a host pointer
+      ctx->raw_host[i].dst = ctx->depth_ws + (size_t)slot * ctx->N;
+      depth_dev = ctx->raw_host[i].dst;
+    } else {
+      depth_dev = reinterpret_cast<const float*>(frames[i]);         // patched below if it is a host pointer
+    }
+    fill_frame(ctx, i, slot, depth_dev, c->d, rows);
+  }
+  // host inputs are staged per sub-batch; device inputs are used in place
+  const bool host_input = !is_device_ptr(frames[0]);
+  if (host_input) {
+    for (int i = 0; i < n; ++i) {
+      const int slot = i % sub;
+      if (raw) ctx->raw_host[i].src = ctx->raw_ws + (size_t)slot * ctx->N;
+      else ctx->frames_host[i].depth = ctx->depth_ws + (size_t)slot * ctx->N;
+    }
+  }
+  HIPCHK(ctx, hipMemcpyAsync(ctx->frames_dev, ctx->frames_host, sizeof(FrameDesc) * n, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
+  if (raw) HIPCHK(ctx, hipMemcpyAsync(ctx->raw_dev, ctx->raw_host, sizeof(RawDesc) * n, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
   for (int base = 0; base < n; base += sub) {
     const int m = std::min(sub, n - base);
-    if (base > 0) HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);   // descriptors are reused
-    for (int i = 0; i < m; ++i) {
-      pwn_hip_cloud* c = clouds[base + i];
-      if (!c || !frames[base + i]) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null frame or cloud");
-      if ((size_t)c->d.capacity < 1) return fail(ctx, PWN_HIP_ERR_CAPACITY, "cloud has zero capacity");
-      if (keep_stats) { if (int rc = ensure_stats(ctx, c)) return rc; }
-      c->has_stats = keep_stats != 0;
-      if (c->d.OmN) { (void)hipFree(c->d.OmN); c->d.OmN = nullptr; }
-      make_omega_n_classes(p, c->d);
-      const float* depth_dev = nullptr;
-      if (std::is_same<SRC, uint16_t>::value) {
-        const uint16_t* src = reinterpret_cast<const uint16_t*>(frames[base + i]);
-        const uint16_t* src_dev = src;
-        if (!is_device_ptr(src)) {
-          uint16_t* dst = ctx->raw_ws + (size_t)i * ctx->N;
-          HIPCHK(ctx, hipMemcpyAsync(dst, src, N * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
-          src_dev = dst;
-        }
-        ctx->raw_host[i].src = src_dev;
-        ctx->raw_host[i].dst = ctx->depth_ws + (size_t)i * ctx->N;
-        depth_dev = ctx->raw_host[i].dst;
-      } else {
-        const float* src = reinterpret_cast<const float*>(frames[base + i]);
-        if (is_device_ptr(src)) depth_dev = src;
-        else {
-          float* dst = ctx->depth_ws + (size_t)i * ctx->N;
-          HIPCHK(ctx, hipMemcpyAsync(dst, src, N * sizeof(float), hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
-          depth_dev = dst;
-        }
+    if (host_input) {
+      for (int i = 0; i < m; ++i) {
+        if (raw) HIPCHK(ctx, hipMemcpyAsync(ctx->raw_ws + (size_t)i * ctx->N, frames[base + i], N * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
+        else HIPCHK(ctx, hipMemcpyAsync(ctx->depth_ws + (size_t)i * ctx->N, frames[base + i], N * sizeof(float), hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
       }
-      fill_frame(ctx, i, depth_dev, c->d, rows);
     }
-    if (std::is_same<SRC, uint16_t>::value) {
-      HIPCHK(ctx, hipMemcpyAsync(ctx->raw_dev, ctx->raw_host, sizeof(RawDesc) * m, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
+    if (raw) {
       StageTimer t(ctx, "u16_to_f32");
-      hipLaunchKernelGGL(k_u16_to_f32, dim3(std::min<size_t>((N + 255) / 256, 1024), m), dim3(256), 0, ctx->stream, ctx->raw_dev, (int)N, depth_scale);
+      hipLaunchKernelGGL(k_u16_to_f32, dim3((unsigned)std::min<size_t>((N + 255) / 256, 1024), m), dim3(256), 0, ctx->stream, ctx->raw_dev + base, (int)N, depth_scale);
     }
-    if (int rc = launch_convert(ctx, cp, m)) return rc;
+    if (int rc = launch_convert(ctx, cp, base, m)) return rc;
   }
   return sync_and_counts(ctx, clouds, n);
 }
@@ -329,23 +366,17 @@ int pwn_hip_ctx_create(pwn_hip_ctx** out, int device, int max_rows, int max_cols
   ALLOC(ctx->rowoff_ws, B * (size_t)std::max(max_rows, max_cols) * sizeof(int) + 64);
   ALLOC(ctx->zref_ws, B * N * sizeof(unsigned long long));
   ALLOC(ctx->zcur_ws, B * N * sizeof(unsigned long long));
+  ALLOC(ctx->curidx_ws, B * N * sizeof(int));
   ALLOC(ctx->partials_ws, B * (size_t)ctx->nblocks_max * kAccN * sizeof(double));
-  ALLOC(ctx->state_ws, B * sizeof(PairState));
-  ALLOC(ctx->frames_dev, B * sizeof(FrameDesc));
-  ALLOC(ctx->pairs_dev, B * sizeof(PairDesc));
-  ALLOC(ctx->raw_dev, B * sizeof(RawDesc));
   ALLOC(ctx->solve_dev, sizeof(SolveOut));
   ALLOC(ctx->counters_dev, 16 * sizeof(int));
   ALLOC(ctx->corr_ws, N * sizeof(int2));
   ALLOC(ctx->scratch_count, sizeof(int));
   ALLOC(ctx->io_ws, N * 16 * sizeof(float));
-  HALLOC(ctx->frames_host, B * sizeof(FrameDesc));
-  HALLOC(ctx->pairs_host, B * sizeof(PairDesc));
-  HALLOC(ctx->raw_host, B * sizeof(RawDesc));
-  HALLOC(ctx->state_host, B * sizeof(PairState));
 #undef ALLOC
 #undef HALLOC
-  (void)hipEventCreate(&ctx->t0); (void)hipEventCreate(&ctx->t1);
+  (void)hipEventCreateWithFlags(&ctx->t0, hipEventDisableSystemFence); (void)hipEventCreateWithFlags(&ctx->t1, hipEventDisableSystemFence);
+  if (int rc = ensure_desc(ctx, std::max(16, max_batch))) { std::string m = ctx->err; pwn_hip_ctx_destroy(ctx); return fail(nullptr, rc, m); }
   *out = ctx;
   return PWN_HIP_OK;
 }
@@ -353,11 +384,11 @@ int pwn_hip_ctx_destroy(pwn_hip_ctx* ctx) {
   if (!ctx) return PWN_HIP_OK;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  void* dev[] = { ctx->depth_ws, ctx->raw_ws, ctx->index_ws, ctx->interval_ws, ctx->integral_ws, ctx->rowoff_ws, ctx->zref_ws, ctx->zcur_ws,
-                  ctx->partials_ws, ctx->state_ws, ctx->frames_dev, ctx->pairs_dev, ctx->raw_dev, ctx->solve_dev, ctx->counters_dev,
+  void* dev[] = { ctx->depth_ws, ctx->raw_ws, ctx->index_ws, ctx->interval_ws, ctx->integral_ws, ctx->rowoff_ws, ctx->zref_ws, ctx->zcur_ws, ctx->curidx_ws,
+                  ctx->partials_ws, ctx->state_ws, ctx->frames_dev, ctx->pairs_dev, ctx->raw_dev, ctx->counts_dev, ctx->solve_dev, ctx->counters_dev,
                   ctx->corr_ws, ctx->scratch_count, ctx->io_ws };
   for (void* p : dev) if (p) (void)hipFree(p);
-  void* host[] = { ctx->frames_host, ctx->pairs_host, ctx->raw_host, ctx->state_host };
+  void* host[] = { ctx->frames_host, ctx->pairs_host, ctx->raw_host, ctx->state_host, ctx->counts_host };
   for (void* p : host) if (p) (void)hipHostFree(p);
   collect_stage_times(ctx);
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
@@ -599,7 +630,7 @@ int pwn_hip_unproject(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const
   if (int rc = stage_depth(ctx, depth, N, &d)) return rc;
   HIPCHK(ctx, hipMemsetAsync(cloud->d.Nm, 0, sizeof(float4) * (size_t)cloud->d.capacity, ctx->stream), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipMemsetAsync(cloud->d.Om, 0, sizeof(float) * 9 * (size_t)cloud->d.capacity, ctx->stream), PWN_HIP_ERR_COPY);
-  fill_frame(ctx, 0, d, cloud->d, rows);
+  fill_frame(ctx, 0, 0, d, cloud->d, rows);
   HIPCHK(ctx, hipMemcpyAsync(ctx->frames_dev, ctx->frames_host, sizeof(FrameDesc), hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
   hipLaunchKernelGGL(k_row_count, dim3(rows, 1), dim3(256), 0, ctx->stream, ctx->frames_dev, cp);
   hipLaunchKernelGGL(k_row_offsets, dim3(1), dim3(1024), 0, ctx->stream, ctx->frames_dev, rows);
@@ -618,7 +649,7 @@ int pwn_hip_project_intervals(pwn_hip_ctx* ctx, const pwn_hip_converter_params* 
   const float* d = nullptr;
   if (int rc = stage_depth(ctx, depth, N, &d)) return rc;
   CloudDev none; std::memset(&none, 0, sizeof(none)); none.count = ctx->scratch_count; none.capacity = 0;
-  fill_frame(ctx, 0, d, none, rows);
+  fill_frame(ctx, 0, 0, d, none, rows);
   HIPCHK(ctx, hipMemcpyAsync(ctx->frames_dev, ctx->frames_host, sizeof(FrameDesc), hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
   hipLaunchKernelGGL(k_row_count, dim3(rows, 1), dim3(256), 0, ctx->stream, ctx->frames_dev, cp);
   hipLaunchKernelGGL(k_row_offsets, dim3(1), dim3(1024), 0, ctx->stream, ctx->frames_dev, rows);
@@ -632,7 +663,7 @@ int pwn_hip_integral_image(pwn_hip_ctx* ctx, const int* index_image, const pwn_h
   if (!ctx || !index_image || !cloud || !out) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if (int rc = check_image(ctx, rows, cols)) return rc;
   const size_t N = (size_t)rows * cols;
-  fill_frame(ctx, 0, nullptr, cloud->d, rows);
+  fill_frame(ctx, 0, 0, nullptr, cloud->d, rows);
   HIPCHK(ctx, copy_any(ctx->frames_host[0].index, index_image, N * 4, ctx->stream), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipMemcpyAsync(ctx->frames_dev, ctx->frames_host, sizeof(FrameDesc), hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
   hipLaunchKernelGGL(k_integral_rows, dim3((rows + kIR_Rows - 1) / kIR_Rows, 1), dim3(256), 0, ctx->stream, ctx->frames_dev, rows, cols);
@@ -716,7 +747,7 @@ int pwn_hip_linearize(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, const p
   const int nb = std::max(1, align_nblocks(C));
   { StageTimer t(ctx, "corr_linearize");
     hipLaunchKernelGGL(k_linearize_list, dim3(nb), dim3(kAlignBlock), 0, ctx->stream, ref->d, cur->d, ctx->corr_ws, C, ap, forced(T), ctx->partials_ws); }
-  hipLaunchKernelGGL(k_reduce_only, dim3(1), dim3(64), 0, ctx->stream, ctx->partials_ws, nb, ctx->solve_dev);
+  hipLaunchKernelGGL(k_reduce_only, dim3(1), dim3(256), 0, ctx->stream, ctx->partials_ws, nb, ctx->solve_dev);
   HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
   SolveOut so;
   HIPCHK(ctx, hipMemcpyAsync(&so, ctx->solve_dev, sizeof(so), hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
@@ -741,71 +772,77 @@ int pwn_hip_align_batch(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n
   const int nb = align_nblocks(N);
   ctx->stages.clear();
   const int sub = std::max(1, std::min(ctx->sub_pairs, ctx->max_batch));
+  if (int rc = ensure_desc(ctx, n)) return rc;
   HIPCHK(ctx, hipEventRecord(ctx->t0, ctx->stream), PWN_HIP_ERR_LAUNCH);
-  int maxcap_ref = 0, maxcap_cur = 0;
+  // descriptors + initial states of all pairs; workspace slots are reused round-robin across sub-batches
+  for (int i = 0; i < n; ++i) {
+    const pwn_hip_cloud* r = refs[i]; const pwn_hip_cloud* c = curs[i];
+    if (!r || !c) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null cloud in batch");
+    const int slot = i % sub;
+    PairDesc& pd = ctx->pairs_host[i];
+    pd.ref = r->d; pd.cur = c->d;
+    pd.zref = ctx->zref_ws + (size_t)slot * ctx->N;
+    pd.zcur = ctx->zcur_ws + (size_t)slot * ctx->N;
+    pd.curidx = ctx->curidx_ws + (size_t)slot * ctx->N;
+    pd.partials = ctx->partials_ws + (size_t)slot * ctx->nblocks_max * kAccN;
+    pd.state = ctx->state_ws + i;
+    // initial state: aligner.cpp:60-64,72-73,79,84
+    PairState& st = ctx->state_host[i];
+    std::memset(&st, 0, sizeof(st));
+    Mat4 T = mat4_from(guesses ? guesses + 16 * (size_t)i : p->initial_guess);
+    set_last_row(T);
+    st.T = T;
+    st.invTcorr = iso_inverse(T);
+    st.invT = st.invTcorr; set_last_row(st.invT);
+    Mat4 iKRt; Mat3 iK;
+    projector_matrices(ap.K, iso_mul(T, ap.refOffset), st.KRt, iKRt, iK);
+    projector_matrices(ap.K, mat4_from(p->current_sensor_offset), st.KRtCur, iKRt, iK);
+    st.it = 0;
+  }
+  if (n > 0) {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->pairs_dev, ctx->pairs_host, sizeof(PairDesc) * n, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->state_ws, ctx->state_host, sizeof(PairState) * n, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
+  }
   for (int base = 0; base < n; base += sub) {
     const int m = std::min(sub, n - base);
-    if (base > 0) HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);   // descriptor / state staging buffers are reused
-    maxcap_ref = 0; maxcap_cur = 0;
-    for (int i = 0; i < m; ++i) {
-      const pwn_hip_cloud* r = refs[base + i]; const pwn_hip_cloud* c = curs[base + i];
-      if (!r || !c) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null cloud in batch");
-      PairDesc& pd = ctx->pairs_host[i];
-      pd.ref = r->d; pd.cur = c->d;
-      pd.zref = ctx->zref_ws + (size_t)i * ctx->N;
-      pd.zcur = ctx->zcur_ws + (size_t)i * ctx->N;
-      pd.partials = ctx->partials_ws + (size_t)i * ctx->nblocks_max * kAccN;
-      pd.state = ctx->state_ws + i;
-      maxcap_ref = std::max(maxcap_ref, r->d.capacity); maxcap_cur = std::max(maxcap_cur, c->d.capacity);
-      // initial state: aligner.cpp:60-64,72-73,79,84
-      PairState& st = ctx->state_host[i];
-      std::memset(&st, 0, sizeof(st));
-      Mat4 T = mat4_from(guesses ? guesses + 16 * (size_t)(base + i) : p->initial_guess);
-      set_last_row(T);
-      st.T = T;
-      st.invTcorr = iso_inverse(T);
-      st.invT = st.invTcorr; set_last_row(st.invT);
-      Mat4 iKRt; Mat3 iK;
-      projector_matrices(ap.K, iso_mul(T, ap.refOffset), st.KRt, iKRt, iK);
-      projector_matrices(ap.K, mat4_from(p->current_sensor_offset), st.KRtCur, iKRt, iK);
-      st.it = 0;
-    }
-    HIPCHK(ctx, hipMemcpyAsync(ctx->pairs_dev, ctx->pairs_host, sizeof(PairDesc) * m, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
-    HIPCHK(ctx, hipMemcpyAsync(ctx->state_ws, ctx->state_host, sizeof(PairState) * m, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
+    const PairDesc* pr = ctx->pairs_dev + base;
+    int maxcap_ref = 0, maxcap_cur = 0;
+    for (int i = 0; i < m; ++i) { maxcap_ref = std::max(maxcap_ref, refs[base + i]->d.capacity); maxcap_cur = std::max(maxcap_cur, curs[base + i]->d.capacity); }
     // z-buffers start empty; slots are contiguous
     HIPCHK(ctx, hipMemsetAsync(ctx->zref_ws, 0xFF, (size_t)m * ctx->N * 8, ctx->stream), PWN_HIP_ERR_COPY);
     HIPCHK(ctx, hipMemsetAsync(ctx->zcur_ws, 0xFF, (size_t)m * ctx->N * 8, ctx->stream), PWN_HIP_ERR_COPY);
     { StageTimer t(ctx, "project");
-      hipLaunchKernelGGL(k_project, dim3((maxcap_cur + 255) / 256, m), dim3(256), 0, ctx->stream, ctx->pairs_dev, ap, 1); }
+      hipLaunchKernelGGL(k_project, dim3((maxcap_cur + 255) / 256, m), dim3(256), 0, ctx->stream, pr, ap, 1);
+      hipLaunchKernelGGL(k_resolve_cur, dim3(std::min((N + 255) / 256, 1024), m), dim3(256), 0, ctx->stream, pr, N); }
     for (int i = 0; i < p->outer_iterations; ++i) {
       { StageTimer t(ctx, "project");
-        hipLaunchKernelGGL(k_project, dim3((maxcap_ref + 255) / 256, m), dim3(256), 0, ctx->stream, ctx->pairs_dev, ap, 0); }
+        hipLaunchKernelGGL(k_project, dim3((maxcap_ref + 255) / 256, m), dim3(256), 0, ctx->stream, pr, ap, 0); }
       for (int k = 0; k < p->inner_iterations; ++k) {
         const bool lastInner = (k == p->inner_iterations - 1);
         const bool lastOuter = (i == p->outer_iterations - 1);
         // the reference z-buffer is consumed (reset) by the last inner pass of every outer iteration but the final one
         const int keepZ = (!lastInner || lastOuter) ? 1 : 0;
         { StageTimer t(ctx, "corr_linearize");
-          hipLaunchKernelGGL(k_corr_linearize, dim3(nb, m), dim3(kAlignBlock), 0, ctx->stream, ctx->pairs_dev, ap, keepZ); }
+          hipLaunchKernelGGL(k_corr_linearize, dim3(nb, m), dim3(kAlignBlock), 0, ctx->stream, pr, ap, keepZ); }
         { StageTimer t(ctx, "solve");
-          hipLaunchKernelGGL(k_solve_update, dim3(m), dim3(64), 0, ctx->stream, ctx->pairs_dev, ap, nb, lastInner ? 1 : 0); }
+          hipLaunchKernelGGL(k_solve_update, dim3(m), dim3(256), 0, ctx->stream, pr, ap, nb, lastInner ? 1 : 0); }
       }
     }
     HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
-    HIPCHK(ctx, hipMemcpyAsync(ctx->state_host, ctx->state_ws, sizeof(PairState) * m, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
-    for (int i = 0; i < m; ++i) {
-      const PairState& st = ctx->state_host[i];
-      pwn_hip_align_result& r = results[base + i];
-      std::memset(&r, 0, sizeof(r));
-      std::memcpy(r.T, st.T.m, sizeof(r.T));
-      r.iterations = st.it;
-      for (int k = 0; k < st.it && k < PWN_HIP_MAX_ITERATIONS; ++k) {
-        r.chi2[k] = st.chi2[k]; r.iter_inliers[k] = st.inliers[k]; r.iter_correspondences[k] = st.ncorr[k]; r.iter_candidates[k] = st.ncand[k];
-      }
-      if (st.it > 0) { r.error = st.chi2[st.it - 1]; r.inliers = st.inliers[st.it - 1]; }
-      r.n_reference = refs[base + i]->n_host; r.n_current = curs[base + i]->n_host;
+  }
+  if (n > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->state_host, ctx->state_ws, sizeof(PairState) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+  for (int i = 0; i < n; ++i) {
+    const PairState& st = ctx->state_host[i];
+    pwn_hip_align_result& r = results[i];
+    std::memset(&r, 0, sizeof(r));
+    std::memcpy(r.T, st.T.m, sizeof(r.T));
+    r.iterations = st.it;
+    for (int k = 0; k < st.it && k < PWN_HIP_MAX_ITERATIONS; ++k) {
+      r.chi2[k] = st.chi2[k]; r.iter_inliers[k] = st.inliers[k]; r.iter_correspondences[k] = st.ncorr[k]; r.iter_candidates[k] = st.ncand[k];
     }
+    if (st.it > 0) { r.error = st.chi2[st.it - 1]; r.inliers = st.inliers[st.it - 1]; }
+    r.n_reference = refs[i]->n_host; r.n_current = curs[i]->n_host;
   }
   HIPCHK(ctx, hipEventRecord(ctx->t1, ctx->stream), PWN_HIP_ERR_LAUNCH);
   HIPCHK(ctx, hipEventSynchronize(ctx->t1), PWN_HIP_ERR_LAUNCH);

@@ -78,6 +78,7 @@ struct PairDesc {
   CloudDev ref, cur;
   unsigned long long* zref;
   unsigned long long* zcur;
+  int* curidx;             // index image of the current cloud (resolved once from zcur)
   double* partials;        // [nblocks][kAccN]
   PairState* state;
 };
@@ -100,6 +101,17 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// force a wave-uniform value into a scalar register
+__device__ __forceinline__ float uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+__device__ __forceinline__ Mat4 uniform_iso(const Mat4& T) {
+  Mat4 r;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    r(0,c) = uniform(T(0,c)); r(1,c) = uniform(T(1,c)); r(2,c) = uniform(T(2,c));
+  }
+  r(3,0) = 0.f; r(3,1) = 0.f; r(3,2) = 0.f; r(3,3) = 1.f;
+  return r;
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // DepthImage_convert_16UC1_to_32FC1 (pwn_core/pwn_static.cpp:54-68).  grid.y = frame
@@ -185,6 +197,11 @@ __global__ void __launch_bounds__(1024) k_row_offsets(const FrameDesc* __restric
     __syncthreads();
   }
   if (threadIdx.x == 0) *f.cloud.count = carry;
+}
+// per-frame point counts -> one contiguous array (single D2H copy per batch)
+__global__ void k_gather_counts(const FrameDesc* __restrict__ frames, int n, int* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = *frames[i].cloud.count;
 }
 // step 3: PinholePointProjector::unProject (pwn_core/pinholepointprojector.cpp:93-133) + projectIntervals (:135-147).
 // Point index = row-major rank of the valid pixel.  grid = (rows, frames), block = 256.
@@ -512,6 +529,12 @@ __global__ void __launch_bounds__(256) k_project(const PairDesc* __restrict__ pa
   const Mat4 KRt = which ? pd.state->KRtCur : pd.state->KRt;
   project_point(KRt, ap.minD, ap.maxD, ap.rows, ap.cols, cl.P[i], i, which ? pd.zcur : pd.zref);
 }
+// current-cloud z-buffer -> int index image, once per alignment.  grid = (blocks, pairs)
+__global__ void k_resolve_cur(const PairDesc* __restrict__ pairs, int n) {
+  const PairDesc& pd = pairs[blockIdx.y];
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    pd.curidx[i] = (int)(unsigned int)(pd.zcur[i] & 0xffffffffu);
+}
 // stand-alone projection with an explicit matrix (pwn_hip_project)
 __global__ void __launch_bounds__(256) k_project_single(CloudDev cl, Mat4 KRt, float minD, float maxD, int rows, int cols,
                                                         unsigned long long* z) {
@@ -570,23 +593,35 @@ __device__ __forceinline__ bool linearize_term(const float3 rp, const float3 rn,
   }
   const float ptx = 2 * rp.x, pty = 2 * rp.y, ptz = 2 * rp.z;
   const float ntx = 2 * rn.x, nty = 2 * rn.y, ntz = 2 * rn.z;
-  float t1[9], A[9], B[9], oPS[9];
-  mul_skew(oP, ptx, pty, ptz, oPS);                 // Htr term: omegaP * Sp
-  skewT_mul(ptx, pty, ptz, oP, t1); mul_skew(t1, ptx, pty, ptz, A);     // Sp^T omegaP Sp
-  skewT_mul(ntx, nty, ntz, oN, t1); mul_skew(t1, ntx, nty, ntz, B);     // Sn^T omegaN Sn
   // Sp^T ep + Sn^T en
   const float s0 = ((-ptz) * ep[1] + pty * ep[2]) + ((-ntz) * en[1] + nty * en[2]);
   const float s1 = (ptz * ep[0] + (-ptx) * ep[2]) + (ntz * en[0] + (-ntx) * en[2]);
   const float s2 = ((-pty) * ep[0] + ptx * ep[1]) + ((-nty) * en[0] + ntx * en[1]);
-  // accumulators are column-major 3x3 blocks: acc[i + 3*j]
+  // Row by row (keeps few values live): Htt += omegaP ; Htr += omegaP*Sp ; Hrr += (Sp^T omegaP Sp + Sn^T omegaN Sn).
+  // accumulators are column-major 3x3 blocks: acc[base + i + 3*j]
 #pragma unroll
-  for (int i = 0; i < 3; ++i)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      acc[0 + i + 3 * j]  += oP[3 * i + j];
-      acc[9 + i + 3 * j]  += oPS[3 * i + j];
-      acc[18 + i + 3 * j] += A[3 * i + j] + B[3 * i + j];
+  for (int i = 0; i < 3; ++i) {
+    const float a0 = oP[3 * i], a1 = oP[3 * i + 1], a2 = oP[3 * i + 2];
+    acc[0 + i] += a0; acc[0 + i + 3] += a1; acc[0 + i + 6] += a2;
+    acc[9 + i]     += a1 * (-ptz) + a2 * pty;                    // (omegaP * Sp)(i, 0..2)
+    acc[9 + i + 3] += a0 * ptz + a2 * (-ptx);
+    acc[9 + i + 6] += a0 * (-pty) + a1 * ptx;
+    // row i of Sp^T*omegaP and of Sn^T*omegaN
+    float p0, p1, p2, q0, q1, q2;
+    if (i == 0) {
+      p0 = (-ptz) * oP[3] + pty * oP[6]; p1 = (-ptz) * oP[4] + pty * oP[7]; p2 = (-ptz) * oP[5] + pty * oP[8];
+      q0 = (-ntz) * oN[3] + nty * oN[6]; q1 = (-ntz) * oN[4] + nty * oN[7]; q2 = (-ntz) * oN[5] + nty * oN[8];
+    } else if (i == 1) {
+      p0 = ptz * oP[0] + (-ptx) * oP[6]; p1 = ptz * oP[1] + (-ptx) * oP[7]; p2 = ptz * oP[2] + (-ptx) * oP[8];
+      q0 = ntz * oN[0] + (-ntx) * oN[6]; q1 = ntz * oN[1] + (-ntx) * oN[7]; q2 = ntz * oN[2] + (-ntx) * oN[8];
+    } else {
+      p0 = (-pty) * oP[0] + ptx * oP[3]; p1 = (-pty) * oP[1] + ptx * oP[4]; p2 = (-pty) * oP[2] + ptx * oP[5];
+      q0 = (-nty) * oN[0] + ntx * oN[3]; q1 = (-nty) * oN[1] + ntx * oN[4]; q2 = (-nty) * oN[2] + ntx * oN[5];
     }
+    acc[18 + i]     += (p1 * (-ptz) + p2 * pty) + (q1 * (-ntz) + q2 * nty);
+    acc[18 + i + 3] += (p0 * ptz + p2 * (-ptx)) + (q0 * ntz + q2 * (-ntx));
+    acc[18 + i + 6] += (p0 * (-pty) + p1 * ptx) + (q0 * (-nty) + q1 * ntx);
+  }
   acc[27] += kscale * ep[0]; acc[28] += kscale * ep[1]; acc[29] += kscale * ep[2];
   acc[30] += kscale * s0; acc[31] += kscale * s1; acc[32] += kscale * s2;
   acc[33] += kscale * localError;
@@ -661,20 +696,20 @@ __device__ __forceinline__ void block_reduce_store(float* acc, double* out) {
 __global__ void __launch_bounds__(kAlignBlock) k_corr_linearize(const PairDesc* __restrict__ pairs, AlignParams ap, int keepZ) {
   const PairDesc& pd = pairs[blockIdx.y];
   const int N = ap.rows * ap.cols;
-  const Mat4 Tc = pd.state->invTcorr;
-  const Mat4 Tl = pd.state->invT;
+  const Mat4 Tc = uniform_iso(pd.state->invTcorr);
+  const Mat4 Tl = uniform_iso(pd.state->invT);
   float acc[kAccN];
 #pragma unroll
   for (int k = 0; k < kAccN; ++k) acc[k] = 0.f;
   const int nref = min(*pd.ref.count, pd.ref.capacity), ncur = min(*pd.cur.count, pd.cur.capacity);
-#pragma unroll
+#pragma unroll 1
   for (int j = 0; j < kPixPerThread; ++j) {
     const int pix = (blockIdx.x * kPixPerThread + j) * kAlignBlock + threadIdx.x;
     if (pix >= N) continue;
     const unsigned long long zr = pd.zref[pix];
     if (!keepZ && zr != kZEmpty) pd.zref[pix] = kZEmpty;
     const int ri = (int)(unsigned int)(zr & 0xffffffffu);
-    const int ci = (int)(unsigned int)(pd.zcur[pix] & 0xffffffffu);
+    const int ci = pd.curidx[pix];
     if (ri < 0 || ci < 0 || ri >= nref || ci >= ncur) continue;
     acc[36] += 1.f;
     const float4 rP = pd.ref.P[ri], rN = pd.ref.Nm[ri], cP = pd.cur.P[ci], cN = pd.cur.Nm[ci];
@@ -731,14 +766,21 @@ __global__ void __launch_bounds__(kAlignBlock) k_linearize_list(CloudDev ref, Cl
 // Deterministic final reduction (fixed block order, fp64) + the Gauss-Newton step of Aligner::align
 // (pwn_core/aligner.cpp:86-117): H = H_lin + I + 1000 I, dx = ldlt(H) \ (-b), invT = v2t(dx) * invT, and at the
 // end of an outer iteration _T = v2t(t2v(invT^-1)) plus the projector matrix of the next reference projection.
-// grid = pairs, block = 64.
+// grid = pairs, block = 256.
 struct SolveOut { float H[36]; float b[6]; float chi2; int inliers, ncorr, ncand; };
+// fixed partition: lane c < kAccN of wave s sums blocks s, s+4, s+8, ... in order; the four wave sums are
+// combined in a fixed order -> bitwise reproducible.  blockDim.x must be 256.
 __device__ __forceinline__ void reduce_partials(const double* partials, int nblocks, double* sums /*shared[kAccN]*/) {
-  if (threadIdx.x < kAccN) {
-    double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partials[(size_t)b * kAccN + threadIdx.x];
-    sums[threadIdx.x] = s;
+  __shared__ double part[4][kAccN];
+  const int c = threadIdx.x & 63, s = threadIdx.x >> 6;
+  if (c < kAccN) {
+    double acc = 0.0;
+#pragma unroll 4
+    for (int b = s; b < nblocks; b += 4) acc += partials[(size_t)b * kAccN + c];
+    part[s][c] = acc;
   }
+  __syncthreads();
+  if (threadIdx.x < kAccN) sums[threadIdx.x] = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
   __syncthreads();
 }
 __device__ __forceinline__ void assemble_Hb(const double* s, float* H, float* b) {
@@ -752,13 +794,14 @@ __device__ __forceinline__ void assemble_Hb(const double* s, float* H, float* b)
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) H[(i + 3) + 6 * j] = H[j + 6 * (i + 3)];
   for (int i = 0; i < 3; ++i) { b[i] = (float)s[27 + i]; b[i + 3] = (float)s[30 + i]; }
 }
-__global__ void __launch_bounds__(64) k_solve_update(const PairDesc* __restrict__ pairs, AlignParams ap, int nblocks, int outerEnd) {
+__global__ void __launch_bounds__(256) k_solve_update(const PairDesc* __restrict__ pairs, AlignParams ap, int nblocks, int outerEnd) {
   const PairDesc& pd = pairs[blockIdx.x];
   __shared__ double sums[kAccN];
+  __shared__ float Hs[36], bs[6], ws[54];
   reduce_partials(pd.partials, nblocks, sums);
   if (threadIdx.x != 0) return;
   PairState& st = *pd.state;
-  float H[36], b[6];
+  float* H = Hs; float* b = bs;
   assemble_Hb(sums, H, b);
   const int it = st.it;
   if (it < kMaxIter) {
@@ -772,7 +815,7 @@ __global__ void __launch_bounds__(64) k_solve_update(const PairDesc* __restrict_
   for (int d = 0; d < 6; ++d) H[d + 6 * d] = H[d + 6 * d] + 1000.0f;     // aligner.cpp:94
   float nb[6], dx[6];
   for (int d = 0; d < 6; ++d) nb[d] = -b[d];
-  ldlt_solve6(H, nb, dx);
+  ldlt_solve6_ws(H, nb, dx, ws);
   Mat4 invT = st.invT;
   set_last_row(invT);
   invT = iso_mul(v2t(dx), invT);
@@ -794,7 +837,7 @@ __global__ void __launch_bounds__(64) k_solve_update(const PairDesc* __restrict_
   st.invT = invT;
 }
 // reduction only (pwn_hip_linearize)
-__global__ void __launch_bounds__(64) k_reduce_only(const double* __restrict__ partials, int nblocks, SolveOut* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_reduce_only(const double* __restrict__ partials, int nblocks, SolveOut* __restrict__ out) {
   __shared__ double sums[kAccN];
   reduce_partials(partials, nblocks, sums);
   if (threadIdx.x != 0) return;

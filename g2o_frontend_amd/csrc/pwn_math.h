@@ -219,9 +219,11 @@ PWN_HD void eig3_direct(float a00, float a10, float a20, float a11, float a21, f
     float q = a_over_3 * a_over_3 * a_over_3 - half_b * half_b;
     q = fmaxf(q, 0.0f);
     const float rho = sqrtf(a_over_3);
-    const float theta = atan2f(sqrtf(q), half_b) * s_inv3;
-    const float cos_theta = cosf(theta);
-    const float sin_theta = sinf(theta);
+    // The three trig calls are evaluated correctly rounded (double precision rounded once to float) so
+    // that host libm and device ocml give the same bits; fp64 is cheap on gfx950 and this is 3 calls/pixel.
+    const float theta = (float)atan2((double)sqrtf(q), (double)half_b) * s_inv3;
+    const float cos_theta = (float)cos((double)theta);
+    const float sin_theta = (float)sin((double)theta);
     e[0] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
     e[1] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
     e[2] = c2_over_3 + 2.0f * rho * cos_theta;
@@ -259,20 +261,25 @@ PWN_HD void eig3_direct(float a00, float a10, float a20, float a11, float a21, f
 }
 
 // ---- Matrix6f::ldlt().solve(b): pivoted (largest |diagonal|) LDL^T, fp32 -------------------------------
-PWN_HD void ldlt_solve6(const float Hin[36], const float bin[6], float x[6]) {
+// ws: caller-provided workspace of >= 54 floats (on the device: LDS, so that the dynamically indexed
+// factorisation does not live in scratch memory)
+PWN_HD void ldlt_solve6_ws(const float Hin[36], const float bin[6], float x[6], float* ws) {
   const int n = 6;
-  float A[36];
+  float* A = ws;            // 36
+  float* temp = ws + 36;    // 6
+  float* d = ws + 42;       // 6
+  float* trf = ws + 48;     // 6 (transposition indices stored as floats)
   for (int i = 0; i < 36; ++i) A[i] = Hin[i];
 #define PWN_A(r, c) A[(r) + 6 * (c)]
-  int tr[6]; float temp[6];
-  for (int i = 0; i < 6; ++i) { tr[i] = i; temp[i] = 0.f; }
+#define tr_get(k) ((int)trf[k])
+  for (int i = 0; i < 6; ++i) { trf[i] = (float)i; temp[i] = 0.f; }
   float cutoff = 0.f;
   for (int k = 0; k < n; ++k) {
     int p = k; float big = fabsf(PWN_A(k,k));
     for (int i = k + 1; i < n; ++i) if (fabsf(PWN_A(i,i)) > big) { big = fabsf(PWN_A(i,i)); p = i; }
     if (k == 0) cutoff = fabsf(FLT_EPSILON * big);
-    if (big < cutoff) { for (int i = k; i < n; ++i) tr[i] = i; break; }
-    tr[k] = p;
+    if (big < cutoff) { for (int i = k; i < n; ++i) trf[i] = (float)i; break; }
+    trf[k] = (float)p;
     if (k != p) {
       for (int j = 0; j < k; ++j) { const float t = PWN_A(k,j); PWN_A(k,j) = PWN_A(p,j); PWN_A(p,j) = t; }
       for (int i = p + 1; i < n; ++i) { const float t = PWN_A(i,k); PWN_A(i,k) = PWN_A(i,p); PWN_A(i,p) = t; }
@@ -293,9 +300,8 @@ PWN_HD void ldlt_solve6(const float Hin[36], const float bin[6], float x[6]) {
     if (k + 1 < n && fabsf(PWN_A(k,k)) > cutoff)
       for (int i = k + 1; i < n; ++i) PWN_A(i,k) = PWN_A(i,k) / PWN_A(k,k);
   }
-  float d[6];
   for (int i = 0; i < 6; ++i) d[i] = bin[i];
-  for (int k = 0; k < n; ++k) if (tr[k] != k) { const float t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
+  for (int k = 0; k < n; ++k) if (tr_get(k) != k) { const float t = d[k]; d[k] = d[tr_get(k)]; d[tr_get(k)] = t; }
   for (int i = 1; i < n; ++i) {
     float s = PWN_A(i,0) * d[0];
     for (int j = 1; j < i; ++j) s = s + PWN_A(i,j) * d[j];
@@ -310,9 +316,14 @@ PWN_HD void ldlt_solve6(const float Hin[36], const float bin[6], float x[6]) {
     for (int j = i + 2; j < n; ++j) s = s + PWN_A(j,i) * d[j];
     d[i] = d[i] - s;
   }
-  for (int k = n - 1; k >= 0; --k) if (tr[k] != k) { const float t = d[k]; d[k] = d[tr[k]]; d[tr[k]] = t; }
+  for (int k = n - 1; k >= 0; --k) if (tr_get(k) != k) { const float t = d[k]; d[k] = d[tr_get(k)]; d[tr_get(k)] = t; }
   for (int i = 0; i < 6; ++i) x[i] = d[i];
 #undef PWN_A
+#undef tr_get
+}
+PWN_HD void ldlt_solve6(const float Hin[36], const float bin[6], float x[6]) {
+  float ws[54];
+  ldlt_solve6_ws(Hin, bin, x, ws);
 }
 
 }  // namespace pwnhip

@@ -84,6 +84,8 @@ def lib():
         L.orc_eigen3.argtypes = [C.c_void_p] * 3
         L.orc_ldlt_solve6.argtypes = [C.c_void_p] * 3
         L.orc_num_threads.restype = C.c_int
+        L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_set_trig_mode.argtypes = [C.c_int]
         _lib = L
     return _lib
 
@@ -329,3 +331,11 @@ def ldlt_solve6(H, b):
 
 def num_threads():
     return lib().orc_num_threads()
+
+
+def set_trig_mode(literal_float_libm: bool):
+    lib().orc_set_trig_mode(1 if literal_float_libm else 0)
+
+
+def set_num_threads(n):
+    lib().orc_set_num_threads(int(n))

@@ -201,6 +201,14 @@ inline M4 skew4(const V4& v) {
 }
 
 /* --------------------------------------- Eigen SelfAdjointEigenSolver<Matrix3f>::computeDirect */
+/* The reference calls std::atan2/cos/sin on floats, i.e. the host libm's atan2f/cosf/sinf, whose last
+ * bit depends on the libm version.  Canonical mode 0 (default) evaluates them CORRECTLY ROUNDED
+ * (double-precision libm rounded once to float), which any platform can reproduce bit for bit;
+ * mode 1 calls the float libm literally.  tests/ quantify the difference between the two modes. */
+int g_trig_mode = 0;
+inline float trig_atan2(float y, float x) { return g_trig_mode ? std::atan2(y, x) : (float)std::atan2((double)y, (double)x); }
+inline float trig_cos(float x) { return g_trig_mode ? std::cos(x) : (float)std::cos((double)x); }
+inline float trig_sin(float x) { return g_trig_mode ? std::sin(x) : (float)std::sin((double)x); }
 inline void cross3(const float a[3], const float b[3], float r[3]) {
   r[0] = a[1]*b[2] - a[2]*b[1];
   r[1] = a[2]*b[0] - a[0]*b[2];
@@ -219,9 +227,9 @@ inline void eig3_roots(const M3& m, float roots[3]) {
   float q = a_over_3 * a_over_3 * a_over_3 - half_b * half_b;
   q = std::max(q, 0.0f);
   float rho = std::sqrt(a_over_3);
-  float theta = std::atan2(std::sqrt(q), half_b) * s_inv3;
-  float cos_theta = std::cos(theta);
-  float sin_theta = std::sin(theta);
+  float theta = trig_atan2(std::sqrt(q), half_b) * s_inv3;
+  float cos_theta = trig_cos(theta);
+  float sin_theta = trig_sin(theta);
   roots[0] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
   roots[1] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
   roots[2] = c2_over_3 + 2.0f * rho * cos_theta;
@@ -856,6 +864,14 @@ void orc_eigen3(const float A[9], float evals[3], float evecs[9]) {
   M3 a; std::memcpy(a.m, A, sizeof(a.m)); M3 U; eig3_direct(a, evals, U); std::memcpy(evecs, U.m, sizeof(U.m));
 }
 void orc_ldlt_solve6(const float H[36], const float b[6], float x[6]) { ldlt_solve6(H, b, x); }
+void orc_set_trig_mode(int literal_float_libm) { g_trig_mode = literal_float_libm ? 1 : 0; }
+void orc_set_num_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n > 0 ? n : 1);
+#else
+  (void)n;
+#endif
+}
 int orc_num_threads(void) {
 #ifdef _OPENMP
   return omp_get_max_threads();

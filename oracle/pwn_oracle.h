@@ -148,6 +148,10 @@ void orc_ldlt_solve6(const float H[36], const float b[6], float x[6]);
 
 /* number of OpenMP threads the parallel (results-identical) loops will use */
 int  orc_num_threads(void);
+void orc_set_num_threads(int n);
+/* eigensolver trig: 0 (default) = correctly rounded via double libm (platform-independent bits);
+ * 1 = literal float libm calls as the reference makes them (last bit depends on the libm version) */
+void orc_set_trig_mode(int literal_float_libm);
 
 #ifdef __cplusplus
 }

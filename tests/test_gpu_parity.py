@@ -3,8 +3,13 @@
 Bars (BASELINE.json north_star):
   * integer / index outputs (index images, interval images, correspondence lists, counts): bit-exact;
   * unprojected points, integral image, projected depth images: bit-exact (same fp32 op order, no FMA);
-  * normals / eigenvalues / information matrices: differ only through libm-vs-ocml trig (tolerances below);
-  * per-iteration chi2: |d|/chi2 <= 1e-5 against the oracle's fp64-accumulated value;
+  * normals / curvature / eigenvalues / Stats / both information matrices: bit-exact as well (the eigensolver's
+    three trig calls are evaluated correctly rounded on both sides, see oracle/pwn_oracle.cpp g_trig_mode);
+  * per-iteration chi2 at the SAME iterate (teacher-forced with the oracle's T_i): |d|/chi2 <= 1e-5 against the
+    oracle's fp64-accumulated value, counters K_i / C_i / inliers_i exact;
+  * free-running chi2 trace: the iterates differ in the last bits (summation order of H, b), which can move a
+    projected point across a pixel boundary; one correspondence entering/leaving changes chi2 by ~chi2/C, so the
+    bar is max(1e-5, 3/C_i) (= 1.5e-5 at VGA, 2.4e-4 at 120x160);
   * final SE(3): translation <= 1e-5 m, rotation matrix entries <= 1e-5.
 """
 import numpy as np
@@ -123,27 +128,15 @@ def test_integral_image_bit_exact(ctx, oracle, name, seed):
 
 
 def _compare_clouds(o, g, name):
+    """Every field of the converted cloud must carry the oracle's bits."""
     assert len(o["points"]) == len(g["points"])
-    assert np.array_equal(o["points"].view(np.uint32), g["points"].view(np.uint32)), "points must be bit-exact"
-    ovalid = np.abs(o["normals"][:, :3]).sum(1) > 0
-    gvalid = np.abs(g["normals"][:, :3]).sum(1) > 0
-    n = len(ovalid)
-    flips = int((ovalid != gvalid).sum())
-    assert flips <= max(2, n // 50000), f"{flips} normal-validity flips"
-    both = ovalid & gvalid
-    # eigen-solver trig differs by ulps between glibc and ocml: |dn| ~ 1e-6 typical; ill-conditioned
-    # (near-degenerate eigen-gap) pixels amplify it, so the bar is a quantile + a loose max
-    dn = np.abs(o["normals"][both] - g["normals"][both]).max(1)
-    assert np.quantile(dn, 0.999) < 1e-4, np.quantile(dn, 0.999)
-    assert dn.max() < 5e-2, dn.max()
-    dc = np.abs(o["curvature"][both] - g["curvature"][both])
-    assert np.quantile(dc, 0.999) < 1e-5 and dc.max() < 1e-3, (np.quantile(dc, 0.999), dc.max())
-    scale = np.abs(o["omega_p"][both]).max(1) + 1e-12
-    dop = np.abs(o["omega_p"][both] - g["omega_p"][both]).max(1) / scale
-    assert np.quantile(dop, 0.999) < 1e-3, np.quantile(dop, 0.999)
-    # class of the normal information matrix must agree wherever both are valid (rare threshold flips allowed)
-    cls_mismatch = int((np.abs(o["omega_n"][both] - g["omega_n"][both]).max(1) > 0).sum())
-    assert cls_mismatch <= max(2, n // 50000), cls_mismatch
+    for k in ("points", "normals", "curvature", "omega_p", "omega_n"):
+        a, b = o[k].reshape(len(o[k]), -1), g[k].reshape(len(g[k]), -1)
+        # +0 / -0 are the same number (zero rows of the information matrices are built differently)
+        same = (a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0))
+        bad = int((~same).any(1).sum())
+        assert bad == 0, f"{k}: {bad} of {len(a)} points differ, max |d| = {np.abs(a - b).max():.3e}"
+    assert (np.abs(o["normals"][:, :3]).sum(1) > 0).mean() > 0.5, "degenerate test input: no normals"
 
 
 @pytest.mark.parametrize("name,seed", [("small", 1), ("vga", 0)])
@@ -160,11 +153,11 @@ def test_convert_matches_oracle(ctx, oracle, name, seed):
     assert np.array_equal(oitv, converter.intervalImage())
     o, g = oc.arrays(stats=True), cloud.arrays(stats=True)
     _compare_clouds(o, g, name)
-    # Stats: n (integer, exact) and eigenvalues (trig-limited)
+    # Stats: n, eigenvalues, eigenvectors + mean
     assert np.array_equal(o["npoints"], g["npoints"])
+    assert np.array_equal(o["eigenvalues"].view(np.uint32), g["eigenvalues"].view(np.uint32))
     ok = o["npoints"] > 0
-    de = np.abs(o["eigenvalues"][ok] - g["eigenvalues"][ok]) / (np.abs(o["eigenvalues"][ok]).max(1, keepdims=True) + 1e-20)
-    assert np.quantile(de, 0.999) < 1e-4, np.quantile(de, 0.999)
+    assert np.array_equal(o["stats"][ok].view(np.uint32), g["stats"][ok].view(np.uint32))
 
 
 def test_convert_with_sensor_offset(ctx, oracle):
@@ -293,14 +286,37 @@ def test_linearize_matches_oracle(ctx, oracle, aligned_inputs, name):
     assert e["inliers"] == 0 and e["chi2"] == 0 and not e["H"].any()
 
 
-def _check_alignment(o, g):
+def _check_alignment(o, g, flips=3):
     n = len(o["iterations"])
     assert g["iterations"] == n
     for i, it in enumerate(o["iterations"]):
         rel = abs(float(g["chi2"][i]) - it["chi2_fp64"]) / it["chi2_fp64"]
-        assert rel <= CHI2_RTOL, (i, rel, float(g["chi2"][i]), it["chi2_fp64"])
+        tol = max(CHI2_RTOL, flips / max(it["C"], 1))
+        assert rel <= tol, (i, rel, tol, float(g["chi2"][i]), it["chi2_fp64"])
+        assert abs(int(g["C"][i]) - it["C"]) <= flips and abs(int(g["K"][i]) - it["K"]) <= 4 * flips
     assert np.abs(g["T"][:3, 3] - o["T"][:3, 3]).max() <= POSE_TTOL
     assert np.abs(g["T"][:3, :3] - o["T"][:3, :3]).max() <= POSE_RTOL
+
+
+@pytest.mark.parametrize("name", ["small", "vga"])
+def test_per_iteration_chi2_teacher_forced(ctx, oracle, aligned_inputs, name):
+    """Every iteration of the oracle's trace re-run on the GPU from the oracle's own iterate T_i:
+    K_i, C_i, inliers_i exact; chi2_i within 1e-5 (strict, no flip allowance); H and b within 1e-5."""
+    d = aligned_inputs[name]
+    _, ap = oracle_params(oracle, name, accumulate_fp64=1)
+    o = oracle.align(ap, d["oref"], d["ocur"])
+    _, _, aligner = gpu_objects(ctx, name)
+    aligner.setReferenceCloud(d["gref"]); aligner.setCurrentCloud(d["gcur"])
+    aligner.setOuterIterations(1)
+    worst = 0.0
+    for i, it in enumerate(o["iterations"]):
+        aligner.setInitialGuess(it["T_before"])
+        g = aligner.align()
+        assert (int(g["K"][0]), int(g["C"][0]), int(g["iter_inliers"][0])) == (it["K"], it["C"], it["inliers"]), i
+        rel = abs(float(g["chi2"][0]) - it["chi2_fp64"]) / it["chi2_fp64"]
+        worst = max(worst, rel)
+        assert rel <= CHI2_RTOL, (i, rel)
+    print(f"{name}: worst per-iteration chi2 rel diff {worst:.2e}")
 
 
 @pytest.mark.parametrize("name", ["small", "vga"])
