@@ -37,8 +37,8 @@ def parse():
     ap.add_argument("--pairs", type=int, default=128, help="depth pairs per GPU (weak scaling)")
     ap.add_argument("--rows", type=int, default=480)
     ap.add_argument("--cols", type=int, default=640)
-    ap.add_argument("--sub-frames", type=int, default=int(os.environ.get("PWN_SUB_FRAMES", 8)))
-    ap.add_argument("--sub-pairs", type=int, default=int(os.environ.get("PWN_SUB_PAIRS", 8)))
+    ap.add_argument("--sub-frames", type=int, default=int(os.environ.get("PWN_SUB_FRAMES", 64)))
+    ap.add_argument("--sub-pairs", type=int, default=int(os.environ.get("PWN_SUB_PAIRS", 64)))
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")

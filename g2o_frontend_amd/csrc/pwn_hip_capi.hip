@@ -40,7 +40,7 @@ struct pwn_hip_ctx {
   hipStream_t own_stream = nullptr;
   int max_rows = 0, max_cols = 0, max_batch = 0;
   size_t N = 0;
-  int sub_frames = 8, sub_pairs = 8;
+  int sub_frames = 64, sub_pairs = 64;
   // convert workspaces (per slot)
   float* depth_ws = nullptr; int* index_ws = nullptr; int* interval_ws = nullptr; float* integral_ws = nullptr; int* rowoff_ws = nullptr;
   uint16_t* raw_ws = nullptr;

@@ -23,7 +23,7 @@ namespace pwnhip {
 constexpr int kMaxIter = 64;
 constexpr int kIntegralChannels = 10;
 constexpr int kAccN = 37;              // Htt9 Htr9 Hrr9 bt3 br3 chi2 inliers C K
-constexpr int kPixPerThread = 4;
+constexpr int kPixPerThread = 8;
 constexpr int kAlignBlock = 256;
 constexpr unsigned long long kZEmpty = ~0ull;
 

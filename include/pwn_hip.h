@@ -108,8 +108,9 @@ int pwn_hip_ctx_destroy(pwn_hip_ctx* ctx);                       /* cf. destroyC
 /* hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the context's own stream */
 int pwn_hip_ctx_set_stream(pwn_hip_ctx* ctx, void* hip_stream);
 int pwn_hip_ctx_synchronize(pwn_hip_ctx* ctx);
-/* Batch calls are executed in sub-batches of this many frames / pairs so that the per-item temporaries
- * (integral image, z-buffers) stay resident in the 256 MiB Infinity Cache.  Results do not depend on it. */
+/* Batch calls are executed in sub-batches of at most this many frames / pairs (default 64, capped by
+ * max_batch), which bounds the workspace the temporaries (integral images, z-buffers) need.  Measured on
+ * MI355X: larger sub-batches are faster (fewer, fuller launches).  Results do not depend on it. */
 int pwn_hip_ctx_set_subbatch(pwn_hip_ctx* ctx, int frames, int pairs);
 /* ctx may be NULL (errors of ctx_create). Never returns NULL. cf. AlignerStatus::toString (cudaaligner.h:54) */
 const char* pwn_hip_last_error_string(const pwn_hip_ctx* ctx);

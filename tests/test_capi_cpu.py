@@ -1,0 +1,108 @@
+"""No-GPU checks of the product: the C-ABI library loads and exports every symbol include/pwn_hip.h declares,
+fails loudly without a device, the host-side parameter plumbing mirrors the reference defaults, and the product
+package never touches the oracle."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "pwn_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(pwn_hip_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    from g2o_frontend_amd import _lib
+    names = declared_symbols()
+    assert len(names) >= 30
+    L = C.CDLL(_lib.LIB_PATH)
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    # and the Python prototypes cover the header exactly
+    assert sorted(_lib.PROTOTYPES) == names
+    _lib.lib()
+
+
+def test_struct_layouts_match_header_sizes():
+    """ctypes mirrors of the parameter / result structs have the sizes the C compiler gives the header's structs."""
+    import subprocess, tempfile
+    from g2o_frontend_amd import _lib
+    prog = r'''
+#include <stdio.h>
+#include "pwn_hip.h"
+int main(void) { printf("%zu %zu %zu\n", sizeof(pwn_hip_converter_params), sizeof(pwn_hip_aligner_params), sizeof(pwn_hip_align_result)); return 0; }
+'''
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(prog)
+        subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), "-o", os.path.join(d, "t"), os.path.join(d, "t.c")])
+        out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
+    assert [int(x) for x in out] == [C.sizeof(_lib.ConverterParams), C.sizeof(_lib.AlignerParams), C.sizeof(_lib.AlignResult)]
+
+
+def test_defaults_are_the_reference_class_defaults():
+    from g2o_frontend_amd import _lib
+    L = _lib.lib()
+    cp = _lib.ConverterParams(); L.pwn_hip_default_converter_params(C.byref(cp))
+    ap = _lib.AlignerParams(); L.pwn_hip_default_aligner_params(C.byref(ap))
+    assert list(cp.K) == [1, 0, 0, 0, 1, 0, 0.5, 0.5, 1]                              # pinholepointprojector.cpp:6-9
+    assert (round(cp.min_distance, 6), cp.max_distance) == (0.01, 6.0)                 # pointprojector.cpp:9-10
+    assert (round(cp.world_radius, 6), cp.min_image_radius, cp.max_image_radius, cp.min_points) == (0.1, 10, 30, 50)
+    assert round(cp.stats_curvature_threshold, 6) == 0.02 and list(cp.point_flat_diag) == [1000, 1, 1] and list(cp.normal_flat_diag) == [100, 100, 100]
+    assert list(cp.sensor_offset) == list(np.eye(4).ravel())
+    assert (ap.inlier_distance_threshold, ap.inlier_curvature_ratio_threshold, ap.inlier_max_chi2) == (0.5, np.float32(1.3), 9000.0)
+    assert abs(ap.inlier_normal_angular_threshold - np.cos(np.pi / 6)) < 1e-7
+    assert (ap.robust_kernel, ap.outer_iterations, ap.inner_iterations) == (1, 10, 1)  # linearizer.cpp:14, aligner.cpp:19-20
+
+
+def test_helpers_run_on_the_host_and_match_the_oracle(oracle):
+    """The SE(3) / projector-matrix helpers are host code of the product; same bits as the oracle."""
+    from g2o_frontend_amd import api
+    rng = np.random.default_rng(0)
+    for _ in range(50):
+        v = np.concatenate([rng.normal(size=3), rng.uniform(-0.3, 0.3, size=3)]).astype(np.float32)
+        T = api.v2t(v)
+        assert np.array_equal(T, oracle.v2t(v)) and np.array_equal(api.t2v(T), oracle.t2v(T))
+        p = api.PinholePointProjector(); p.setCameraMatrix([[525, 0, 319.5], [0, 525, 239.5], [0, 0, 1]]); p.setTransform(T)
+        for a, b in zip(p.matrices(), oracle.projector_matrices((525, 525, 319.5, 239.5), T)):
+            assert np.array_equal(a, b)
+
+
+def test_host_mirror_parameter_plumbing():
+    from g2o_frontend_amd import api
+    p = api.PinholePointProjector(); p.setCameraMatrix([[525, 0, 319.5], [0, 525, 239.5], [0, 0, 1]]); p.setImageSize(480, 640)
+    p.scale(0.5)                                                                       # pinholepointprojector.cpp:149-154
+    assert p.imageRows() == 240 and p.imageCols() == 320 and p.cameraMatrix()[0, 0] == 262.5 and p.cameraMatrix()[2, 2] == 1
+    st = api.StatsCalculatorIntegralImage(); st.setMinImageRadius(3); st.setCurvatureThreshold(0.2)
+    conv = api.DepthImageConverterIntegralImage(p, st, api.PointInformationMatrixCalculator(), api.NormalInformationMatrixCalculator())
+    cp = conv.params(np.eye(4))
+    assert cp.min_image_radius == 3 and abs(cp.stats_curvature_threshold - 0.2) < 1e-7 and cp.K[0] == 262.5 and cp.K[6] == 159.75
+    al = api.Aligner.__new__(api.Aligner)
+    al.__dict__.update(ctx=None, _projector=None, _linearizer=None, _correspondenceFinder=None)
+    with pytest.raises(AssertionError):
+        al.params()                                                                    # aligner.cpp:50-52 asserts
+
+
+def test_no_device_fails_loudly():
+    from g2o_frontend_amd import _lib, api
+    if _lib.lib().pwn_hip_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.PwnHipError) as e:
+        api.Context()
+    assert e.value.code == 2 and "no CPU fallback" in str(e.value)
+
+
+def test_product_does_not_import_the_oracle():
+    """The oracle is test infrastructure: nothing under g2o_frontend_amd/ or include/ may reference it."""
+    pat = re.compile(r"(from\s+oracle|import\s+oracle|oracle\.|pwn_oracle|libpwn_oracle|orc_[a-z_]+\()")
+    for base in ("g2o_frontend_amd", "include"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, base)):
+            for f in files:
+                if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
+                    txt = open(os.path.join(dirpath, f)).read()
+                    assert not pat.search(txt), os.path.join(dirpath, f)

@@ -434,7 +434,7 @@ def test_batch_equals_single_and_is_deterministic(ctx, oracle):
             assert np.array_equal(s["T"].view(np.uint32), r["T"].view(np.uint32))
             assert np.array_equal(s["chi2"].view(np.uint32), r["chi2"].view(np.uint32))
             assert np.array_equal(s["C"], r["C"]) and np.array_equal(s["K"], r["K"])
-    ctx.set_subbatch(8, 8)
+    ctx.set_subbatch(64, 64)
 
 
 def test_batch_from_raw_u16(ctx, oracle):
