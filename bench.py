@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--align-only", action="store_true", help="also time align-only (clouds resident)")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run only the CPU baseline leg and print its JSON")
     ap.add_argument("--no-profile", action="store_true", help="no per-kernel hipEvent timing in the timed region (roofline fields become 0)")
     return ap.parse_args()
 
@@ -115,14 +116,24 @@ def main():
     K, conv, alig = conf(rows, cols)
     n_it = alig["outer_iterations"] * alig["inner_iterations"]
 
-    # CPU baseline first (rank 0 only), before anything touches the GPU
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline(rows, cols, K, conv, alig, list(range(0, 64)), args.cpu_seconds)))
+        return
+    # CPU baseline first (rank 0 only), in a child process started before anything touches the GPU: the process that
+    # drives the GPU never loads the oracle library
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(rows, cols, K, conv, alig, list(range(0, 64)), args.cpu_seconds)
+        import subprocess
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--rows", str(rows), "--cols", str(cols),
+                              "--cpu-seconds", str(args.cpu_seconds)], capture_output=True, text=True, timeout=600)
+        try:
+            cpu = json.loads(out.stdout.strip().splitlines()[-1])
+        except Exception:
+            cpu = {"error": (out.stderr or out.stdout)[-300:]}
 
     import torch
     import torch.distributed as dist
-    from g2o_frontend_amd import api, synth
+    from g2o_frontend_amd import api, shard, synth
     torch.cuda.set_device(local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -134,7 +145,8 @@ def main():
     converter, aligner = build_objects(ctx, rows, cols, K, conv, alig)
 
     # synthetic inputs of this rank's shard, uploaded to HBM (uint16 mm frames)
-    seeds = [rank * P + i for i in range(P)]
+    my_pairs = shard.shard_range(world * P, rank, world)          # contiguous shard of the global pair list
+    seeds = list(my_pairs)
     ref_dev, cur_dev = [], []
     for s in seeds:
         ref_mm, cur_mm, _ = synth.make_pair(s, rows, cols, K)
@@ -142,28 +154,33 @@ def main():
         cur_dev.append(torch.from_numpy(cur_mm.view(np.int16)).cuda())
     refs = [api.Cloud(ctx, N) for _ in range(P)]
     curs = [api.Cloud(ctx, N) for _ in range(P)]
-    poses = torch.empty((P, 16), dtype=torch.float32, device="cuda")
-    gathered = torch.empty((world * P, 16), dtype=torch.float32, device="cuda") if world > 1 else None
+    records = torch.empty((P, shard.RECORD_FLOATS), dtype=torch.float32, device="cuda")
 
     stage_names = ["u16_to_f32", "unproject", "integral_rows", "integral_cols", "stats", "project", "corr_linearize", "solve"]
     stage_ms = {k: 0.0 for k in stage_names}
     stage_n = {k: 0 for k in stage_names}
     last = {}
 
+    dbg = os.environ.get("PWN_BENCH_DEBUG")
+    tm = {"convert": 0.0, "align": 0.0, "gather": 0.0}
+
     def step(profile):
+        t_a = time.perf_counter()
         converter.computeBatch(refs + curs, ref_dev + cur_dev, raw_scale=0.001)
+        t_b = time.perf_counter()
         if profile:
             for k in stage_names[:5]:
                 ms, n = ctx.stage_ms(k); stage_ms[k] += ms; stage_n[k] += n
         res = aligner.alignBatch(refs, curs)
+        t_c = time.perf_counter()
         if profile:
             for k in stage_names[5:]:
                 ms, n = ctx.stage_ms(k); stage_ms[k] += ms; stage_n[k] += n
-        T = np.stack([r["T"].T.reshape(-1) for r in res]).astype(np.float32)
-        poses.copy_(torch.from_numpy(T), non_blocking=False)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, poses)      # RCCL: the only collective of the path
+        records.copy_(torch.from_numpy(shard.pack_results(res, seeds)), non_blocking=False)
+        last["gathered"] = shard.gather_records(records, world, P)      # RCCL all-gather: the only collective of the path
         last["res"] = res
+        if profile:
+            tm["convert"] += t_b - t_a; tm["align"] += t_c - t_b; tm["gather"] += time.perf_counter() - t_c
 
     def barrier():
         if world > 1:
@@ -184,7 +201,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    if dbg and rank == 0:
+        print("host wall per step (ms):", {k: round(v / args.steps * 1e3, 2) for k, v in tm.items()}, file=sys.stderr)
     res = last["res"]
+    if rank == 0:
+        allrec = shard.assemble(last["gathered"].cpu().numpy(), world * P)      # every pair of every rank arrived exactly once
+        assert allrec.shape[0] == world * P
     # measured counters of SURVEY.md §8(d): M_r, M_c, K_i, C_i -> algorithmic bytes
     Mr = np.array([r["n_reference"] for r in res], np.float64); Mc = np.array([r["n_current"] for r in res], np.float64)
     Ks = np.array([r["K"].sum() for r in res], np.float64); Cs = np.array([r["C"].sum() for r in res], np.float64)

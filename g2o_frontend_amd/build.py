@@ -25,5 +25,18 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return OUT
 
 
+def build_tools(force: bool = False) -> str:
+    """The C++ harness over the host mirror (tools/pwn_hip_simple_aligner.cpp); plain g++, links libpwn_hip.so."""
+    root = os.path.dirname(_HERE)
+    src = os.path.join(root, "tools", "pwn_hip_simple_aligner.cpp")
+    out = os.path.join(root, "tools", "pwn_hip_simple_aligner")
+    deps = [src, os.path.join(_HERE, "host", "pwn_hip.hpp"), HEADER, OUT]
+    if force or (not os.path.exists(out)) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", root, src, "-o", out, "-L", _HERE, "-lpwn_hip",
+                               "-Wl,-rpath,$ORIGIN/../g2o_frontend_amd"])
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_tools(force="--force" in sys.argv))
