@@ -244,7 +244,8 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
             try:
-                traffic = json.load(open(tfile)).get("k_corr_linearize_bytes_per_launch")
+                # measured per pair-iteration by the PMC passes (profiles/), scaled to the pairs one launch of this run covers
+                traffic = json.load(open(tfile)).get("k_corr_linearize_bytes_per_pair_iteration") * (P * n_it * args.steps / launches)
             except Exception:
                 traffic = None
         out = {

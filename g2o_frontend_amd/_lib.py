@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpwn_hip.so")
+LIB_PATH = os.environ.get("PWN_HIP_LIB", os.path.join(_HERE, "libpwn_hip.so"))   # override: kernel A/B experiments
 MAX_ITERATIONS = 64
 
 STATUS = {0: "OK", 1: "INVALID_ARGUMENT", 2: "NO_DEVICE", 3: "ALLOCATION", 4: "COPY", 5: "LAUNCH", 6: "CAPACITY"}

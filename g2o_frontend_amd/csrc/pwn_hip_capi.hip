@@ -55,7 +55,7 @@ struct pwn_hip_ctx {
   SolveOut* solve_dev = nullptr; int* counters_dev = nullptr; int2* corr_ws = nullptr; int* scratch_count = nullptr;
   float* io_ws = nullptr;   // N*16 floats staging for cloud up/download
   // images of the last single align
-  int img_rows = 0, img_cols = 0; bool img_valid = false;
+  int img_rows = 0, img_cols = 0; bool img_valid = false; unsigned img_ref_tag = kZTag0;
   std::string err;
   bool profiling = false;
   std::map<std::string, StageAcc> stages;
@@ -430,6 +430,7 @@ int pwn_hip_last_stage_ms(pwn_hip_ctx* ctx, const char* stage, float* ms, int* l
 // ---------------------------------------------------------------------------------------------------- clouds
 int pwn_hip_cloud_create(pwn_hip_ctx* ctx, int capacity, pwn_hip_cloud** out) {
   if (!ctx || !out || capacity <= 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "bad cloud_create argument");
+  if (capacity > kMaxCloudPoints) return fail(ctx, PWN_HIP_ERR_CAPACITY, "a cloud holds at most 2^21 points (z-buffer word layout)");
   HIPCHK(ctx, hipSetDevice(ctx->device), PWN_HIP_ERR_NO_DEVICE);
   pwn_hip_cloud* c = new pwn_hip_cloud();
   std::memset(&c->d, 0, sizeof(c->d));
@@ -696,16 +697,17 @@ int pwn_hip_convert_batch_u16(pwn_hip_ctx* ctx, const pwn_hip_converter_params* 
 int pwn_hip_project(pwn_hip_ctx* ctx, const float K[9], const float T[16], float min_distance, float max_distance, int rows, int cols,
                     const pwn_hip_cloud* cloud, int* index_image, float* depth_image) {
   if (!ctx || !K || !T || !cloud) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (min_distance < 0.f) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "min_distance must be >= 0");
   if (int rc = check_image(ctx, rows, cols)) return rc;
   const size_t N = (size_t)rows * cols;
   Mat4 KRt, iKRt; Mat3 iK;
   projector_matrices(mat3_from(K), mat4_from(T), KRt, iKRt, iK);
   HIPCHK(ctx, hipMemsetAsync(ctx->zref_ws, 0xFF, N * 8, ctx->stream), PWN_HIP_ERR_COPY);
   { StageTimer t(ctx, "project");
-    hipLaunchKernelGGL(k_project_single, dim3((cloud->d.capacity + 255) / 256), dim3(256), 0, ctx->stream, cloud->d, KRt, min_distance, max_distance, rows, cols, ctx->zref_ws); }
+    hipLaunchKernelGGL(k_project_single, dim3((cloud->d.capacity + 255) / 256), dim3(256), 0, ctx->stream, cloud->d, KRt, min_distance, max_distance, rows, cols, ctx->zref_ws, kZTag0); }
   int* di = index_image ? (is_device_ptr(index_image) ? index_image : ctx->index_ws) : nullptr;
   float* dd = depth_image ? (is_device_ptr(depth_image) ? depth_image : ctx->depth_ws) : nullptr;
-  hipLaunchKernelGGL(k_zbuf_resolve, dim3((unsigned)std::min<size_t>((N + 255) / 256, 2048)), dim3(256), 0, ctx->stream, ctx->zref_ws, (int)N, di, dd);
+  hipLaunchKernelGGL(k_zbuf_resolve, dim3((unsigned)std::min<size_t>((N + 255) / 256, 2048)), dim3(256), 0, ctx->stream, ctx->zref_ws, (int)N, di, dd, kZTag0);
   HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
   if (index_image && di != index_image) HIPCHK(ctx, hipMemcpyAsync(index_image, di, N * 4, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
   if (depth_image && dd != depth_image) HIPCHK(ctx, hipMemcpyAsync(depth_image, dd, N * 4, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
@@ -764,6 +766,7 @@ int pwn_hip_align_batch(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n
                         const float* guesses, pwn_hip_align_result* results) {
   if (!ctx || !p || !refs || !curs || !results || n < 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if (int rc = check_image(ctx, p->rows, p->cols)) return rc;
+  if (p->min_distance < 0.f) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "min_distance must be >= 0");
   const int nit = p->outer_iterations * p->inner_iterations;
   if (p->outer_iterations < 0 || p->inner_iterations < 0 || nit > PWN_HIP_MAX_ITERATIONS)
     return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "outer*inner iterations exceeds PWN_HIP_MAX_ITERATIONS");
@@ -812,18 +815,16 @@ int pwn_hip_align_batch(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n
     HIPCHK(ctx, hipMemsetAsync(ctx->zref_ws, 0xFF, (size_t)m * ctx->N * 8, ctx->stream), PWN_HIP_ERR_COPY);
     HIPCHK(ctx, hipMemsetAsync(ctx->zcur_ws, 0xFF, (size_t)m * ctx->N * 8, ctx->stream), PWN_HIP_ERR_COPY);
     { StageTimer t(ctx, "project");
-      hipLaunchKernelGGL(k_project, dim3((maxcap_cur + 255) / 256, m), dim3(256), 0, ctx->stream, pr, ap, 1);
-      hipLaunchKernelGGL(k_resolve_cur, dim3(std::min((N + 255) / 256, 1024), m), dim3(256), 0, ctx->stream, pr, N); }
+      hipLaunchKernelGGL(k_project, dim3((maxcap_cur + 255) / 256, m), dim3(256), 0, ctx->stream, pr, ap, 1, kZTag0);
+      hipLaunchKernelGGL(k_resolve_cur, dim3(std::min((N + 255) / 256, 1024), m), dim3(256), 0, ctx->stream, pr, N, kZTag0); }
     for (int i = 0; i < p->outer_iterations; ++i) {
+      const unsigned tag = kZTag0 - (unsigned)i;      // epoch of this outer iteration's reference projection
       { StageTimer t(ctx, "project");
-        hipLaunchKernelGGL(k_project, dim3((maxcap_ref + 255) / 256, m), dim3(256), 0, ctx->stream, pr, ap, 0); }
+        hipLaunchKernelGGL(k_project, dim3((maxcap_ref + 255) / 256, m), dim3(256), 0, ctx->stream, pr, ap, 0, tag); }
       for (int k = 0; k < p->inner_iterations; ++k) {
         const bool lastInner = (k == p->inner_iterations - 1);
-        const bool lastOuter = (i == p->outer_iterations - 1);
-        // the reference z-buffer is consumed (reset) by the last inner pass of every outer iteration but the final one
-        const int keepZ = (!lastInner || lastOuter) ? 1 : 0;
         { StageTimer t(ctx, "corr_linearize");
-          hipLaunchKernelGGL(k_corr_linearize, dim3(nb, m), dim3(kAlignBlock), 0, ctx->stream, pr, ap, keepZ); }
+          hipLaunchKernelGGL(k_corr_linearize, dim3(nb, m), dim3(kAlignBlock), 0, ctx->stream, pr, ap, tag); }
         { StageTimer t(ctx, "solve");
           hipLaunchKernelGGL(k_solve_update, dim3(m), dim3(256), 0, ctx->stream, pr, ap, nb, lastInner ? 1 : 0); }
       }
@@ -849,6 +850,7 @@ int pwn_hip_align_batch(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n
   float ms = 0.f; (void)hipEventElapsedTime(&ms, ctx->t0, ctx->t1);
   for (int i = 0; i < n; ++i) results[i].total_time_ms = n > 0 ? ms / n : 0.f;
   ctx->img_rows = p->rows; ctx->img_cols = p->cols; ctx->img_valid = n > 0;
+  ctx->img_ref_tag = kZTag0 - (unsigned)std::max(0, p->outer_iterations - 1);
   collect_stage_times(ctx);
   return PWN_HIP_OK;
 }
@@ -867,7 +869,8 @@ int pwn_hip_align_images(pwn_hip_ctx* ctx, int* ref_index, float* ref_depth, int
     const unsigned long long* z = pass == 0 ? ctx->zref_ws : ctx->zcur_ws;   // slot 0 = last pair of the last sub-batch... single align: the pair
     int* di = oi ? (is_device_ptr(oi) ? oi : ctx->index_ws) : nullptr;
     float* dd = od ? (is_device_ptr(od) ? od : ctx->depth_ws) : nullptr;
-    hipLaunchKernelGGL(k_zbuf_resolve, dim3((unsigned)std::min<size_t>((N + 255) / 256, 2048)), dim3(256), 0, ctx->stream, z, (int)N, di, dd);
+    hipLaunchKernelGGL(k_zbuf_resolve, dim3((unsigned)std::min<size_t>((N + 255) / 256, 2048)), dim3(256), 0, ctx->stream, z, (int)N, di, dd,
+                       pass == 0 ? ctx->img_ref_tag : kZTag0);
     HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
     if (oi && di != oi) HIPCHK(ctx, hipMemcpyAsync(oi, di, N * 4, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
     if (od && dd != od) HIPCHK(ctx, hipMemcpyAsync(od, dd, N * 4, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);

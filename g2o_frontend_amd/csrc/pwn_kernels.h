@@ -8,7 +8,7 @@
 //           Om[k*cap + i], k = 3*r + c                     (point information matrix, 9 planes)
 //   images: row-major int32 / float32, lanes along image x (row-coalesced loads)
 //   integral image: 10 planes [ch][rows][cols] (x y z n xx xy xz yy yz zz)
-//   z-buffer: uint64 per pixel = float_bits(depth) << 32 | point index; empty = ~0
+//   z-buffer: uint64 per pixel = epoch tag (12 b) | float_bits(depth) (31 b) | point index (21 b); empty = ~0
 // Arithmetic follows the reference's evaluation order (left-to-right inner products, no FMA:
 // compiled with -ffp-contract=off) so integer outputs are bit-exact and fp32 outputs differ from
 // the CPU path only through libm-vs-ocml trig and summation order of the H/b reduction.
@@ -26,6 +26,21 @@ constexpr int kAccN = 37;              // Htt9 Htr9 Hrr9 bt3 br3 chi2 inliers C 
 constexpr int kPixPerThread = 8;
 constexpr int kAlignBlock = 256;
 constexpr unsigned long long kZEmpty = ~0ull;
+// z-buffer word = epoch tag (12 bits) | depth bits (31, depth >= 0) | point index (21 bits).  Projection number j of an
+// alignment uses tag kZTag0 - j: a smaller tag wins atomicMin, so words left by earlier projections behave as "empty"
+// and the buffer needs neither a clear pass nor a reset store between Gauss-Newton iterations.
+constexpr unsigned kZTag0 = 0xFFEu;
+constexpr int kZIndexBits = 21;
+constexpr int kMaxCloudPoints = 1 << kZIndexBits;
+__host__ __device__ __forceinline__ unsigned long long zkey(unsigned tag, float d, int i) {
+  return ((unsigned long long)tag << 52) | ((unsigned long long)(__builtin_bit_cast(unsigned, d) & 0x7fffffffu) << kZIndexBits) | (unsigned)i;
+}
+__host__ __device__ __forceinline__ int zkey_index(unsigned long long k, unsigned tag) {
+  return ((unsigned)(k >> 52) == tag) ? (int)(k & ((1u << kZIndexBits) - 1u)) : -1;
+}
+__host__ __device__ __forceinline__ float zkey_depth(unsigned long long k, unsigned tag) {
+  return ((unsigned)(k >> 52) == tag) ? __builtin_bit_cast(float, (unsigned)((k >> kZIndexBits) & 0x7fffffffu)) : FLT_MAX;
+}
 
 struct CloudDev {
   float4* P;
@@ -507,7 +522,7 @@ __global__ void __launch_bounds__(256) k_cloud_transform(CloudDev cl, Mat4 m) {
 // (depth bits, point index): nearest point wins, ties keep the lowest index (the reference's strict '>' in a
 // sequential loop).  grid = (ceil(capacity/256), pairs), block = 256.  which: 0 = reference cloud, 1 = current.
 __device__ __forceinline__ void project_point(const Mat4& KRt, float minD, float maxD, int rows, int cols,
-                                              const float4 p, int i, unsigned long long* z) {
+                                              const float4 p, int i, unsigned long long* z, unsigned tag) {
   const float ix = dot4seq(KRt(0,0), p.x, KRt(0,1), p.y, KRt(0,2), p.z, KRt(0,3), 1.0f);
   const float iy = dot4seq(KRt(1,0), p.x, KRt(1,1), p.y, KRt(1,2), p.z, KRt(1,3), 1.0f);
   const float d  = dot4seq(KRt(2,0), p.x, KRt(2,1), p.y, KRt(2,2), p.z, KRt(2,3), 1.0f);
@@ -517,38 +532,37 @@ __device__ __forceinline__ void project_point(const Mat4& KRt, float minD, float
   // int conversion of out-of-range floats is undefined on the CPU; such points are rejected by the bounds test
   if (!(fx >= 0.f && fx < (float)cols && fy >= 0.f && fy < (float)rows)) return;
   const int x = (int)fx, y = (int)fy;
-  const unsigned long long key = ((unsigned long long)__float_as_uint(d) << 32) | (unsigned int)i;
-  atomicMin(&z[(size_t)y * cols + x], key);
+  atomicMin(&z[(size_t)y * cols + x], zkey(tag, d, i));
 }
-__global__ void __launch_bounds__(256) k_project(const PairDesc* __restrict__ pairs, AlignParams ap, int which) {
+__global__ void __launch_bounds__(256) k_project(const PairDesc* __restrict__ pairs, AlignParams ap, int which, unsigned tag) {
   const PairDesc& pd = pairs[blockIdx.y];
   const CloudDev& cl = which ? pd.cur : pd.ref;
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int n = min(*cl.count, cl.capacity);
   if (i >= n) return;
   const Mat4 KRt = which ? pd.state->KRtCur : pd.state->KRt;
-  project_point(KRt, ap.minD, ap.maxD, ap.rows, ap.cols, cl.P[i], i, which ? pd.zcur : pd.zref);
+  project_point(KRt, ap.minD, ap.maxD, ap.rows, ap.cols, cl.P[i], i, which ? pd.zcur : pd.zref, tag);
 }
 // current-cloud z-buffer -> int index image, once per alignment.  grid = (blocks, pairs)
-__global__ void k_resolve_cur(const PairDesc* __restrict__ pairs, int n) {
+__global__ void k_resolve_cur(const PairDesc* __restrict__ pairs, int n, unsigned tag) {
   const PairDesc& pd = pairs[blockIdx.y];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    pd.curidx[i] = (int)(unsigned int)(pd.zcur[i] & 0xffffffffu);
+    pd.curidx[i] = zkey_index(pd.zcur[i], tag);
 }
 // stand-alone projection with an explicit matrix (pwn_hip_project)
 __global__ void __launch_bounds__(256) k_project_single(CloudDev cl, Mat4 KRt, float minD, float maxD, int rows, int cols,
-                                                        unsigned long long* z) {
+                                                        unsigned long long* z, unsigned tag) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int n = min(*cl.count, cl.capacity);
   if (i >= n) return;
-  project_point(KRt, minD, maxD, rows, cols, cl.P[i], i, z);
+  project_point(KRt, minD, maxD, rows, cols, cl.P[i], i, z, tag);
 }
 // z-buffer -> (index image, depth image): empty pixels -1 / FLT_MAX (pinholepointprojector.cpp:41-42)
-__global__ void k_zbuf_resolve(const unsigned long long* __restrict__ z, int n, int* __restrict__ index, float* __restrict__ depth) {
+__global__ void k_zbuf_resolve(const unsigned long long* __restrict__ z, int n, int* __restrict__ index, float* __restrict__ depth, unsigned tag) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const unsigned long long k = z[i];
-    if (index) index[i] = (int)(unsigned int)(k & 0xffffffffu);
-    if (depth) depth[i] = (k == kZEmpty) ? FLT_MAX : __uint_as_float((unsigned int)(k >> 32));
+    if (index) index[i] = zkey_index(k, tag);
+    if (depth) depth[i] = zkey_depth(k, tag);
   }
 }
 
@@ -690,10 +704,68 @@ __device__ __forceinline__ void block_reduce_store(float* acc, double* out) {
 }
 
 // Fused CorrespondenceFinder::compute + Linearizer::update (correspondencefinder.cpp:45-106, linearizer.cpp:33-90):
-// one pass over the pixels, no correspondence list is materialised.  The reference z-buffer word is consumed and
-// (unless keepZ) reset to "empty" so the next iteration's projection needs no separate clear pass.
-// grid = (ceil(N / (256*4)), pairs), block = 256.
-__global__ void __launch_bounds__(kAlignBlock) k_corr_linearize(const PairDesc* __restrict__ pairs, AlignParams ap, int keepZ) {
+// one pass over the pixels, no correspondence list is materialised; the z-buffer is epoch-tagged, nothing is written back.
+// The kernel is latency-bound (index -> point/normal gathers -> information-matrix gathers are dependent loads), so it
+// is software-pipelined by hand as a rolling three-stage loop: indices of pixel j+2, point/normal gathers of pixel j+1,
+// tests + arithmetic of pixel j.  Measured on MI355X: prefetching the 9 information-matrix planes as well costs more
+// in occupancy (174 VGPRs -> 2 waves/SIMD) than it hides (PWN_OMEGA_PREFETCH=1: 13.2 ms vs 9.8 ms per 128x10 pair-iterations).
+// grid = (ceil(N / (256*kPixPerThread)), pairs), block = 256.
+#ifndef PWN_OMEGA_PREFETCH
+#define PWN_OMEGA_PREFETCH 0
+#endif
+#ifndef PWN_CL_WAVES
+#define PWN_CL_WAVES 1
+#endif
+struct Candidate {
+  float4 rP, rN, cP, cN;
+#if PWN_OMEGA_PREFETCH
+  float oP[9];
+#endif
+  int ci;
+  bool valid;
+};
+__device__ __forceinline__ void candidate_load(const PairDesc& pd, int ri, int ci, int nref, int ncur, Candidate& c) {
+  c.valid = !(ri < 0 || ci < 0 || ri >= nref || ci >= ncur);
+  c.ci = ci;
+  if (c.valid) {
+    c.rP = pd.ref.P[ri]; c.rN = pd.ref.Nm[ri]; c.cP = pd.cur.P[ci]; c.cN = pd.cur.Nm[ci];
+#if PWN_OMEGA_PREFETCH
+    const size_t cap = (size_t)pd.cur.capacity;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) c.oP[k] = pd.cur.Om[k * cap + ci];
+#endif
+  }
+}
+__device__ __forceinline__ void candidate_consume(const PairDesc& pd, const AlignParams& ap, const Mat4& Tc, const Mat4& Tl,
+                                                  const Candidate& c, float* acc) {
+  if (!c.valid) return;
+  acc[36] += 1.f;
+  if (!correspondence_test(ap, Tc, c.rP, c.rN, c.cP, c.cN)) return;
+  acc[35] += 1.f;
+  float oN[9];
+  const int cls = __float_as_int(c.cN.w);
+  if (pd.cur.OmN) {
+    const size_t cap = (size_t)pd.cur.capacity;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) oN[k] = pd.cur.OmN[k * cap + c.ci];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) oN[k] = (cls == 1) ? pd.cur.omN[0][k] : ((cls == 2) ? pd.cur.omN[1][k] : 0.f);
+  }
+  const float3 rp = iso_point(Tl, c.rP), rn = iso_normal(Tl, c.rN);
+#if PWN_OMEGA_PREFETCH
+  const float* oP = c.oP;
+#else
+  float oP[9];
+  {
+    const size_t cap = (size_t)pd.cur.capacity;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) oP[k] = pd.cur.Om[k * cap + c.ci];
+  }
+#endif
+  linearize_term(rp, rn, make_float3(c.cP.x, c.cP.y, c.cP.z), make_float3(c.cN.x, c.cN.y, c.cN.z), oP, oN, ap.maxChi2, ap.robust, acc);
+}
+__global__ void __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_corr_linearize(const PairDesc* __restrict__ pairs, AlignParams ap, unsigned tag) {
   const PairDesc& pd = pairs[blockIdx.y];
   const int N = ap.rows * ap.cols;
   const Mat4 Tc = uniform_iso(pd.state->invTcorr);
@@ -702,23 +774,23 @@ __global__ void __launch_bounds__(kAlignBlock) k_corr_linearize(const PairDesc* 
 #pragma unroll
   for (int k = 0; k < kAccN; ++k) acc[k] = 0.f;
   const int nref = min(*pd.ref.count, pd.ref.capacity), ncur = min(*pd.cur.count, pd.cur.capacity);
+  const int pix0 = blockIdx.x * kPixPerThread * kAlignBlock + threadIdx.x;
+  auto load_indices = [&](int j, int& ri, int& ci) {
+    const int pix = pix0 + j * kAlignBlock;
+    ri = -1; ci = -1;
+    if (j < kPixPerThread && pix < N) { ri = zkey_index(pd.zref[pix], tag); ci = pd.curidx[pix]; }
+  };
+  int ri1, ci1, ri2, ci2;
+  load_indices(0, ri1, ci1);
+  load_indices(1, ri2, ci2);
+  Candidate nxt;
+  candidate_load(pd, ri1, ci1, nref, ncur, nxt);
 #pragma unroll 1
   for (int j = 0; j < kPixPerThread; ++j) {
-    const int pix = (blockIdx.x * kPixPerThread + j) * kAlignBlock + threadIdx.x;
-    if (pix >= N) continue;
-    const unsigned long long zr = pd.zref[pix];
-    if (!keepZ && zr != kZEmpty) pd.zref[pix] = kZEmpty;
-    const int ri = (int)(unsigned int)(zr & 0xffffffffu);
-    const int ci = pd.curidx[pix];
-    if (ri < 0 || ci < 0 || ri >= nref || ci >= ncur) continue;
-    acc[36] += 1.f;
-    const float4 rP = pd.ref.P[ri], rN = pd.ref.Nm[ri], cP = pd.cur.P[ci], cN = pd.cur.Nm[ci];
-    if (!correspondence_test(ap, Tc, rP, rN, cP, cN)) continue;
-    acc[35] += 1.f;
-    float oP[9], oN[9];
-    load_omegas(pd.cur, ci, __float_as_int(cN.w), oP, oN);
-    const float3 rp = iso_point(Tl, rP), rn = iso_normal(Tl, rN);
-    linearize_term(rp, rn, make_float3(cP.x, cP.y, cP.z), make_float3(cN.x, cN.y, cN.z), oP, oN, ap.maxChi2, ap.robust, acc);
+    const Candidate cur = nxt;
+    candidate_load(pd, ri2, ci2, nref, ncur, nxt);       // gathers of pixel j+1: in flight during the arithmetic below
+    load_indices(j + 2, ri2, ci2);                        // indices of pixel j+2
+    candidate_consume(pd, ap, Tc, Tl, cur, acc);
   }
   block_reduce_store(acc, pd.partials + (size_t)blockIdx.x * kAccN);
 }
