@@ -824,7 +824,9 @@ int pwn_hip_align_batch(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n
       for (int k = 0; k < p->inner_iterations; ++k) {
         const bool lastInner = (k == p->inner_iterations - 1);
         { StageTimer t(ctx, "corr_linearize");
-          hipLaunchKernelGGL(k_corr_linearize, dim3(nb, m), dim3(kAlignBlock), 0, ctx->stream, pr, ap, tag); }
+          // first inner pass: the linearizer's transform is bitwise the finder's (aligner.cpp:79,84)
+          if (k == 0) hipLaunchKernelGGL(k_corr_linearize<true>, dim3(nb, m), dim3(kAlignBlock), 0, ctx->stream, pr, ap, tag);
+          else hipLaunchKernelGGL(k_corr_linearize<false>, dim3(nb, m), dim3(kAlignBlock), 0, ctx->stream, pr, ap, tag); }
         { StageTimer t(ctx, "solve");
           hipLaunchKernelGGL(k_solve_update, dim3(m), dim3(256), 0, ctx->stream, pr, ap, nb, lastInner ? 1 : 0); }
       }

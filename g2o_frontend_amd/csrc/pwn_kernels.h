@@ -669,18 +669,25 @@ __device__ __forceinline__ float3 iso_normal(const Mat4& T, const float4 n) {
   return r;
 }
 // CorrespondenceFinder::compute acceptance tests (pwn_core/correspondencefinder.cpp:60-99) for one pixel.
+// rp / rn return the reference point / normal remapped by Tc (reused by the linearizer when its transform is the same).
 __device__ __forceinline__ bool correspondence_test(const AlignParams& ap, const Mat4& Tc, const float4 rP, const float4 rN,
-                                                    const float4 cP, const float4 cN) {
+                                                    const float4 cP, const float4 cN, float3& rp, float3& rn) {
   if (dot4seq(cN.x, cN.x, cN.y, cN.y, cN.z, cN.z, 0.f, 0.f) == 0.0f || dot4seq(rN.x, rN.x, rN.y, rN.y, rN.z, rN.z, 0.f, 0.f) == 0.0f)
     return false;
-  const float3 rp = iso_point(Tc, rP);
-  const float3 rn = iso_normal(Tc, rN);
+  rp = iso_point(Tc, rP);
+  rn = iso_normal(Tc, rN);
   if (dot4seq(cN.x, rn.x, cN.y, rn.y, cN.z, rn.z, 0.f, 0.f) < ap.normalThr) return false;
   const float dx = cP.x - rp.x, dy = cP.y - rp.y, dz = cP.z - rp.z;
   if (dot4seq(dx, dx, dy, dy, dz, dz, 0.f, 0.f) > ap.sqDist) return false;
   float rc = rP.w, cc = cP.w;
   if (rc < ap.flatThr) rc = ap.flatThr;
   if (cc < ap.flatThr) cc = ap.flatThr;
+  // The reference evaluates (rc + 1e-5) / (cc + 1e-5) in double and compares the float-rounded ratio with the bounds
+  // (correspondencefinder.cpp:96-99).  An fp32 estimate (relative error < 1e-6) decides every case that is not within
+  // 1e-5 of a bound; only those run the exact double computation, so the decision is always the reference's.
+  const float est = (rc + 1e-5f) / (cc + 1e-5f);
+  if (est < ap.minRatio * (1.0f - 1e-5f) || est > ap.maxRatio * (1.0f + 1e-5f)) return false;
+  if (est > ap.minRatio * (1.0f + 1e-5f) && est < ap.maxRatio * (1.0f - 1e-5f)) return true;
   const float ratio = (float)(((double)rc + 1e-5) / ((double)cc + 1e-5));
   if (ratio < ap.minRatio || ratio > ap.maxRatio) return false;
   return true;
@@ -736,11 +743,13 @@ __device__ __forceinline__ void candidate_load(const PairDesc& pd, int ri, int c
 #endif
   }
 }
+template <bool SAME_T>
 __device__ __forceinline__ void candidate_consume(const PairDesc& pd, const AlignParams& ap, const Mat4& Tc, const Mat4& Tl,
                                                   const Candidate& c, float* acc) {
   if (!c.valid) return;
   acc[36] += 1.f;
-  if (!correspondence_test(ap, Tc, c.rP, c.rN, c.cP, c.cN)) return;
+  float3 rp, rn;
+  if (!correspondence_test(ap, Tc, c.rP, c.rN, c.cP, c.cN, rp, rn)) return;
   acc[35] += 1.f;
   float oN[9];
   const int cls = __float_as_int(c.cN.w);
@@ -752,7 +761,7 @@ __device__ __forceinline__ void candidate_consume(const PairDesc& pd, const Alig
 #pragma unroll
     for (int k = 0; k < 9; ++k) oN[k] = (cls == 1) ? pd.cur.omN[0][k] : ((cls == 2) ? pd.cur.omN[1][k] : 0.f);
   }
-  const float3 rp = iso_point(Tl, c.rP), rn = iso_normal(Tl, c.rN);
+  if (!SAME_T) { rp = iso_point(Tl, c.rP); rn = iso_normal(Tl, c.rN); }   // inner iterations > 0: the linearizer's transform moved on
 #if PWN_OMEGA_PREFETCH
   const float* oP = c.oP;
 #else
@@ -765,6 +774,7 @@ __device__ __forceinline__ void candidate_consume(const PairDesc& pd, const Alig
 #endif
   linearize_term(rp, rn, make_float3(c.cP.x, c.cP.y, c.cP.z), make_float3(c.cN.x, c.cN.y, c.cN.z), oP, oN, ap.maxChi2, ap.robust, acc);
 }
+template <bool SAME_T>
 __global__ void __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_corr_linearize(const PairDesc* __restrict__ pairs, AlignParams ap, unsigned tag) {
   const PairDesc& pd = pairs[blockIdx.y];
   const int N = ap.rows * ap.cols;
@@ -790,7 +800,7 @@ __global__ void __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_corr_linearize(co
     const Candidate cur = nxt;
     candidate_load(pd, ri2, ci2, nref, ncur, nxt);       // gathers of pixel j+1: in flight during the arithmetic below
     load_indices(j + 2, ri2, ci2);                        // indices of pixel j+2
-    candidate_consume(pd, ap, Tc, Tl, cur, acc);
+    candidate_consume<SAME_T>(pd, ap, Tc, Tl, cur, acc);
   }
   block_reduce_store(acc, pd.partials + (size_t)blockIdx.x * kAccN);
 }
@@ -807,7 +817,8 @@ __global__ void __launch_bounds__(256) k_correspondence_image(CloudDev ref, Clou
   const int nref = min(*ref.count, ref.capacity), ncur = min(*cur.count, cur.capacity);
   if (ri >= 0 && ci >= 0 && ri < nref && ci < ncur) {
     atomicAdd(&counters[0], 1);
-    if (correspondence_test(ap, Tc, ref.P[ri], ref.Nm[ri], cur.P[ci], cur.Nm[ci])) res = make_int2(ri, ci);
+    float3 rp, rn;
+    if (correspondence_test(ap, Tc, ref.P[ri], ref.Nm[ri], cur.P[ci], cur.Nm[ci], rp, rn)) res = make_int2(ri, ci);
   }
   out[pix] = res;
 }
