@@ -49,6 +49,11 @@ class AlignResult(C.Structure):
                 ("iter_candidates", C.c_int * MAX_ITERATIONS), ("n_reference", C.c_int), ("n_current", C.c_int)]
 
 
+class MatchResult(C.Structure):
+    _fields_ = [("image_non_zeros", C.c_int), ("image_outliers", C.c_int), ("image_inliers", C.c_int),
+                ("image_reprojection_distance", C.c_float)]
+
+
 # name -> (restype, argtypes); every symbol include/pwn_hip.h declares
 _VP, _I, _F = C.c_void_p, C.c_int, C.c_float
 PROTOTYPES = {
@@ -83,6 +88,8 @@ PROTOTYPES = {
     "pwn_hip_align": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "pwn_hip_align_images": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "pwn_hip_align_batch": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP]),
+    "pwn_hip_match_score": (_I, [_VP, _F, _VP]),
+    "pwn_hip_match_batch": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _F, _VP, _VP]),
     "pwn_hip_projector_matrices": (None, [_VP, _VP, _VP, _VP, _VP]),
     "pwn_hip_v2t": (None, [_VP, _VP]),
     "pwn_hip_t2v": (None, [_VP, _VP]),

@@ -15,7 +15,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import AlignerParams, AlignResult, ConverterParams, PwnHipError
+from ._lib import AlignerParams, AlignResult, ConverterParams, MatchResult, PwnHipError
 
 
 def _ptr(x):
@@ -505,6 +505,96 @@ class Aligner:
         l = self._linearizer
         l._H, l._b, l._error, l._inliers = H.reshape(6, 6).T.copy(), b, err.value, inl.value
         return dict(H=l._H, b=b, chi2=err.value, inliers=inl.value)
+
+
+class PwnMatcherBase:
+    """pwn_tracker/pwn_matcher_base.{h,cpp}: the caller-side boundary of the path -- makeCloud (depth image -> cloud at
+    1/scale resolution) and matchClouds (align + depth-agreement score), with the reference's quirks kept:
+    the initial guess' z translation is zeroed (.cpp:114), the aligner's projector is re-configured and scaled on every
+    call (.cpp:117-119), the returned information matrix is the 100*I hack (.cpp:147-148)."""
+
+    def __init__(self, aligner: "Aligner", converter: DepthImageConverterIntegralImage):
+        self._aligner, self._converter = aligner, converter
+        self._scale = 2                              # pwn_matcher_base.cpp:12
+        self._frameInlierDepthThreshold = 50.0       # :13
+        self.numCalls = 0
+
+    def scale(self): return self._scale
+    def setScale(self, s): self._scale = int(s)
+    def aligner(self): return self._aligner
+    def converter(self): return self._converter
+
+    def makeCloud(self, cameraMatrix, sensorOffset, depthImage, ctx: Context = None):
+        """pwn_matcher_base.cpp:57-86 -> (cloud, r, c, scaledCameraMatrix)"""
+        ctx = ctx or self._aligner.ctx
+        projector = self._converter.projector()
+        invScale = np.float32(1.0) / np.float32(self._scale)
+        scaled = (np.asarray(cameraMatrix, np.float32).reshape(3, 3) * invScale).astype(np.float32)
+        scaled[2, 2] = 1.0
+        projector.setCameraMatrix(scaled)
+        depth = np.ascontiguousarray(depthImage, np.float32)
+        projector.setImageSize(depth.shape[0] // self._scale, depth.shape[1] // self._scale)
+        scaledImage = ctx.DepthImage_scale(depth, self._scale)                       # :72
+        cloud = Cloud(ctx, max(1, scaledImage.size))
+        self._converter.compute(cloud, scaledImage, sensorOffset, images=False)     # :79
+        self.numCalls += 1
+        return cloud, projector.imageRows(), projector.imageCols(), projector.cameraMatrix().copy()
+
+    def _configure(self, fromOffset, toOffset, toCameraMatrix, toRows, toCols, initialGuess):
+        a = self._aligner
+        projector = a.projector()
+        a.setReferenceSensorOffset(fromOffset); a.setCurrentSensorOffset(toOffset)
+        ig = np.asarray(np.eye(4) if initialGuess is None else initialGuess, np.float64).astype(np.float32)   # convertScalar d -> f (.h:66-71)
+        ig[2, 3] = 0                                                                 # :114
+        a.setInitialGuess(ig)
+        projector.setCameraMatrix(toCameraMatrix); projector.setImageSize(toRows, toCols)
+        projector.scale(np.float32(1.0 / self._scale))                               # :117-119 (float argument of scale())
+        a.correspondenceFinder().setImageSize(projector.imageRows(), projector.imageCols())   # :128-133
+
+    @staticmethod
+    def _result(r, m: MatchResult):
+        omega = np.eye(6) * 100.0                                                    # :147-148 HACK kept
+        return dict(transform=r["T"].astype(np.float64), informationMatrix=omega, cloud_inliers=r["inliers"],
+                    image_nonZeros=m.image_non_zeros, image_outliers=m.image_outliers, image_inliers=m.image_inliers,
+                    image_reprojectionDistance=m.image_reprojection_distance, align=r)
+
+    def matchClouds(self, fromCloud, toCloud, fromOffset, toOffset, toCameraMatrix, toRows, toCols, initialGuess=None):
+        """pwn_matcher_base.cpp:88-183 -> MatcherResult as a dict"""
+        a = self._aligner
+        self._configure(fromOffset, toOffset, toCameraMatrix, toRows, toCols, initialGuess)
+        a.setReferenceCloud(fromCloud); a.setCurrentCloud(toCloud)
+        r = a.align()                                                                # :136
+        m = MatchResult()
+        a.ctx.check(a.ctx._L.pwn_hip_match_score(a.ctx.h, self._frameInlierDepthThreshold, C.byref(m)))    # :153-182
+        return self._result(r, m)
+
+    def matchCloudsBatch(self, fromClouds, toClouds, fromOffset, toOffset, toCameraMatrix, toRows, toCols, initialGuesses=None):
+        """The candidate loop of PwnCloser::processPartition (pwn_tracker/pwn_closer.cpp:92-111) as one batched call."""
+        a = self._aligner
+        n = len(fromClouds)
+        self._configure(fromOffset, toOffset, toCameraMatrix, toRows, toCols, None)
+        p = a.params()
+        res, sc = (AlignResult * n)(), (MatchResult * n)()
+        refs = (C.c_void_p * n)(*[c.h for c in fromClouds]); curs = (C.c_void_p * n)(*[c.h for c in toClouds])
+        gl = []
+        for i in range(n):
+            ig = np.asarray(np.eye(4) if initialGuesses is None else initialGuesses[i], np.float64).astype(np.float32)
+            ig[2, 3] = 0; ig[3] = (0, 0, 0, 1)
+            gl.append(_colmajor(ig, 4))
+        g = np.ascontiguousarray(np.stack(gl), np.float32)
+        a.ctx.check(a.ctx._L.pwn_hip_match_batch(a.ctx.h, C.byref(p), n, refs, curs, _ptr(g), self._frameInlierDepthThreshold, res, sc))
+        return [self._result(Aligner._unpack(r), m) for r, m in zip(res, sc)]
+
+
+class PwnCloserAcceptance:
+    """Acceptance rule of PwnCloser::matchFrames (pwn_tracker/pwn_closer.cpp:56-58,138-141)."""
+
+    def __init__(self, frameMinNonZeroThreshold=3000, frameMaxOutliersThreshold=100, frameMinInliersThreshold=1000):
+        self.frameMinNonZeroThreshold, self.frameMaxOutliersThreshold, self.frameMinInliersThreshold = frameMinNonZeroThreshold, frameMaxOutliersThreshold, frameMinInliersThreshold
+
+    def accept(self, result) -> bool:
+        return not (result["image_nonZeros"] < self.frameMinNonZeroThreshold or result["image_outliers"] > self.frameMaxOutliersThreshold
+                    or result["image_inliers"] < self.frameMinInliersThreshold)
 
 
 def v2t(v):

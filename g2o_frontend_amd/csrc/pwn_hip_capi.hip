@@ -52,6 +52,7 @@ struct pwn_hip_ctx {
   FrameDesc* frames_dev = nullptr; PairDesc* pairs_dev = nullptr; RawDesc* raw_dev = nullptr; int* counts_dev = nullptr;
   FrameDesc* frames_host = nullptr; PairDesc* pairs_host = nullptr; RawDesc* raw_host = nullptr; PairState* state_host = nullptr; int* counts_host = nullptr;
   // misc scratch
+  MatchAcc* match_dev = nullptr; MatchAcc* match_host = nullptr; int match_cap = 0;
   SolveOut* solve_dev = nullptr; int* counters_dev = nullptr; int2* corr_ws = nullptr; int* scratch_count = nullptr;
   float* io_ws = nullptr;   // N*16 floats staging for cloud up/download
   // images of the last single align
@@ -194,6 +195,11 @@ int ensure_desc(pwn_hip_ctx* ctx, int n) {
   HIPCHK(ctx, hipHostMalloc((void**)&ctx->raw_host, B * sizeof(RawDesc)), PWN_HIP_ERR_ALLOCATION);
   HIPCHK(ctx, hipHostMalloc((void**)&ctx->state_host, B * sizeof(PairState)), PWN_HIP_ERR_ALLOCATION);
   HIPCHK(ctx, hipHostMalloc((void**)&ctx->counts_host, B * sizeof(int)), PWN_HIP_ERR_ALLOCATION);
+  if (ctx->match_dev) (void)hipFree(ctx->match_dev);
+  if (ctx->match_host) (void)hipHostFree(ctx->match_host);
+  ctx->match_dev = nullptr; ctx->match_host = nullptr;
+  HIPCHK(ctx, hipMalloc((void**)&ctx->match_dev, B * sizeof(MatchAcc)), PWN_HIP_ERR_ALLOCATION);
+  HIPCHK(ctx, hipHostMalloc((void**)&ctx->match_host, B * sizeof(MatchAcc)), PWN_HIP_ERR_ALLOCATION);
   ctx->desc_cap = (int)B;
   return PWN_HIP_OK;
 }
@@ -388,8 +394,9 @@ int pwn_hip_ctx_destroy(pwn_hip_ctx* ctx) {
                   ctx->partials_ws, ctx->state_ws, ctx->frames_dev, ctx->pairs_dev, ctx->raw_dev, ctx->counts_dev, ctx->solve_dev, ctx->counters_dev,
                   ctx->corr_ws, ctx->scratch_count, ctx->io_ws };
   for (void* p : dev) if (p) (void)hipFree(p);
-  void* host[] = { ctx->frames_host, ctx->pairs_host, ctx->raw_host, ctx->state_host, ctx->counts_host };
+  void* host[] = { ctx->frames_host, ctx->pairs_host, ctx->raw_host, ctx->state_host, ctx->counts_host, ctx->match_host };
   for (void* p : host) if (p) (void)hipHostFree(p);
+  if (ctx->match_dev) (void)hipFree(ctx->match_dev);
   collect_stage_times(ctx);
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
@@ -762,8 +769,16 @@ int pwn_hip_linearize(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, const p
   return PWN_HIP_OK;
 }
 
-int pwn_hip_align_batch(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* refs, pwn_hip_cloud* const* curs,
-                        const float* guesses, pwn_hip_align_result* results) {
+static void finish_match(const MatchAcc& a, pwn_hip_match_result* r) {
+  r->image_non_zeros = (int)a.nonZeros;
+  r->image_inliers = (int)a.inliers;
+  r->image_outliers = (int)a.nonZeros - (int)a.inliers;
+  // sum of the masked differences: exact in 1/64 units; values below 2^-120 only matter when nothing else was added
+  const double sum = a.sum64 ? (double)a.sum64 / 64.0 : (double)a.tiny * 1e-37;
+  r->image_reprojection_distance = (float)sum / (float)(int)a.nonZeros;          // pwn_matcher_base.cpp:179 (0/0 = NaN like the reference)
+}
+static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* refs, pwn_hip_cloud* const* curs,
+                            const float* guesses, pwn_hip_align_result* results, pwn_hip_match_result* scores, float match_threshold) {
   if (!ctx || !p || !refs || !curs || !results || n < 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if (int rc = check_image(ctx, p->rows, p->cols)) return rc;
   if (p->min_distance < 0.f) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "min_distance must be >= 0");
@@ -805,7 +820,9 @@ int pwn_hip_align_batch(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n
   if (n > 0) {
     HIPCHK(ctx, hipMemcpyAsync(ctx->pairs_dev, ctx->pairs_host, sizeof(PairDesc) * n, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
     HIPCHK(ctx, hipMemcpyAsync(ctx->state_ws, ctx->state_host, sizeof(PairState) * n, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
+    if (scores) HIPCHK(ctx, hipMemsetAsync(ctx->match_dev, 0, sizeof(MatchAcc) * n, ctx->stream), PWN_HIP_ERR_COPY);
   }
+  const unsigned lastRefTag = kZTag0 - (unsigned)std::max(0, p->outer_iterations - 1);
   for (int base = 0; base < n; base += sub) {
     const int m = std::min(sub, n - base);
     const PairDesc* pr = ctx->pairs_dev + base;
@@ -831,8 +848,14 @@ int pwn_hip_align_batch(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n
           hipLaunchKernelGGL(k_solve_update, dim3(m), dim3(256), 0, ctx->stream, pr, ap, nb, lastInner ? 1 : 0); }
       }
     }
+    if (scores && p->outer_iterations > 0) {
+      StageTimer t(ctx, "match_score");     // the z-buffers of this sub-batch still hold the finder's last depth images
+      hipLaunchKernelGGL(k_match_score, dim3(std::min((N + 255) / 256, 256), m), dim3(256), 0, ctx->stream, pr, N, lastRefTag, kZTag0, 1000.0f,
+                         match_threshold, ctx->match_dev + base);
+    }
     HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
   }
+  if (n > 0 && scores) HIPCHK(ctx, hipMemcpyAsync(ctx->match_host, ctx->match_dev, sizeof(MatchAcc) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
   if (n > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->state_host, ctx->state_ws, sizeof(PairState) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
   for (int i = 0; i < n; ++i) {
@@ -846,6 +869,7 @@ int pwn_hip_align_batch(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n
     }
     if (st.it > 0) { r.error = st.chi2[st.it - 1]; r.inliers = st.inliers[st.it - 1]; }
     r.n_reference = refs[i]->n_host; r.n_current = curs[i]->n_host;
+    if (scores) finish_match(ctx->match_host[i], &scores[i]);
   }
   HIPCHK(ctx, hipEventRecord(ctx->t1, ctx->stream), PWN_HIP_ERR_LAUNCH);
   HIPCHK(ctx, hipEventSynchronize(ctx->t1), PWN_HIP_ERR_LAUNCH);
@@ -854,6 +878,30 @@ int pwn_hip_align_batch(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n
   ctx->img_rows = p->rows; ctx->img_cols = p->cols; ctx->img_valid = n > 0;
   ctx->img_ref_tag = kZTag0 - (unsigned)std::max(0, p->outer_iterations - 1);
   collect_stage_times(ctx);
+  return PWN_HIP_OK;
+}
+int pwn_hip_align_batch(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* refs, pwn_hip_cloud* const* curs,
+                        const float* guesses, pwn_hip_align_result* results) {
+  return align_batch_impl(ctx, p, n, refs, curs, guesses, results, nullptr, 0.f);
+}
+int pwn_hip_match_batch(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* refs, pwn_hip_cloud* const* curs,
+                        const float* guesses, float threshold, pwn_hip_align_result* results, pwn_hip_match_result* scores) {
+  if (!scores) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null scores");
+  return align_batch_impl(ctx, p, n, refs, curs, guesses, results, scores, threshold);
+}
+int pwn_hip_match_score(pwn_hip_ctx* ctx, float threshold, pwn_hip_match_result* out) {
+  if (!ctx || !out) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (!ctx->img_valid) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "no alignment has run on this context");
+  const int N = ctx->img_rows * ctx->img_cols;
+  ctx->pairs_host[0].zref = ctx->zref_ws; ctx->pairs_host[0].zcur = ctx->zcur_ws;       // slot 0 = the pair of the last single align
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pairs_dev, ctx->pairs_host, sizeof(PairDesc), hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipMemsetAsync(ctx->match_dev, 0, sizeof(MatchAcc), ctx->stream), PWN_HIP_ERR_COPY);
+  hipLaunchKernelGGL(k_match_score, dim3(std::min((N + 255) / 256, 256), 1), dim3(256), 0, ctx->stream, ctx->pairs_dev, N, ctx->img_ref_tag, kZTag0, 1000.0f,
+                     threshold, ctx->match_dev);
+  HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
+  HIPCHK(ctx, hipMemcpyAsync(ctx->match_host, ctx->match_dev, sizeof(MatchAcc), hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+  finish_match(ctx->match_host[0], out);
   return PWN_HIP_OK;
 }
 int pwn_hip_align(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, const pwn_hip_cloud* ref, const pwn_hip_cloud* cur, pwn_hip_align_result* result) {

@@ -846,6 +846,44 @@ __global__ void __launch_bounds__(kAlignBlock) k_linearize_list(CloudDev ref, Cl
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// PwnMatcherBase::matchClouds post-alignment score (pwn_tracker/pwn_matcher_base.cpp:153-182): both finder depth images
+// -> uint16 millimetres (DepthImage_convert_32FC1_to_16UC1, FLT_MAX -> 0), mask = both > 0, diff = |cur - ref| as float
+// BITWISE-ANDed with the float mask 255.0f (that is what cv::Mat `abs(a-b) & mask` does on CV_32F data), inliers =
+// mask && diff < threshold, sum of diff.  Every surviving diff is a multiple of 1/64 (or < 2^-120), so the sum is kept
+// exactly in 1/64 fixed point with integer atomics -> bitwise reproducible.  out[pair] = {nonZeros, inliers, sum64, tiny}.
+struct MatchAcc { unsigned long long nonZeros, inliers; long long sum64; unsigned long long tiny; };
+__device__ __forceinline__ unsigned short depth_to_u16(float d, float scale) { return (d < FLT_MAX) ? (unsigned short)(scale * d) : (unsigned short)0; }
+__global__ void __launch_bounds__(256) k_match_score(const PairDesc* __restrict__ pairs, int n, unsigned refTag, unsigned curTag, float scale,
+                                                     float threshold, MatchAcc* __restrict__ out) {
+  const PairDesc& pd = pairs[blockIdx.y];
+  int nz = 0, inl = 0; long long sum = 0; int tiny = 0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const unsigned short c = depth_to_u16(zkey_depth(pd.zcur[i], curTag), scale);
+    const unsigned short r = depth_to_u16(zkey_depth(pd.zref[i], refTag), scale);
+    if (c > 0 && r > 0) {
+      ++nz;
+      const float ad = fabsf((float)c - (float)r);
+      const unsigned bits = __float_as_uint(ad) & 0x437F0000u;            // & bits(255.0f)
+      const float d = __uint_as_float(bits);
+      if (d < threshold) ++inl;
+      const unsigned e = bits >> 23;
+      if (e >= 128u) sum += (long long)(128u + ((bits >> 16) & 0x7Fu)) << ((e - 128u));   // d * 64 = (128+m7) * 2^(e-128)
+      else if (bits) ++tiny;                                               // d < 2^-120: cannot change a float sum >= 1/64
+    }
+  }
+  // wave reduction of the integers, then one atomic per wave
+  for (int off = 32; off > 0; off >>= 1) {
+    nz += __shfl_xor(nz, off, 64); inl += __shfl_xor(inl, off, 64); tiny += __shfl_xor(tiny, off, 64);
+    sum += __shfl_xor(sum, off, 64);
+  }
+  if (lane_id() == 0) {
+    MatchAcc* o = out + blockIdx.y;
+    atomicAdd(&o->nonZeros, (unsigned long long)nz); atomicAdd(&o->inliers, (unsigned long long)inl);
+    atomicAdd((unsigned long long*)&o->sum64, (unsigned long long)sum); atomicAdd(&o->tiny, (unsigned long long)tiny);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Deterministic final reduction (fixed block order, fp64) + the Gauss-Newton step of Aligner::align
 // (pwn_core/aligner.cpp:86-117): H = H_lin + I + 1000 I, dx = ldlt(H) \ (-b), invT = v2t(dx) * invT, and at the
 // end of an outer iteration _T = v2t(t2v(invT^-1)) plus the projector matrix of the next reference projection.

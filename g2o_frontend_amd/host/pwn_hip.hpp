@@ -305,4 +305,65 @@ class Aligner {
   pwn_hip_align_result _result;
 };
 
+// pwn_tracker/pwn_matcher_base.{h,cpp}: makeCloud + matchClouds with the reference's quirks kept (guess z zeroed :114,
+// projector re-configured and scaled per call :117-119, information matrix = 100*I :147-148).
+struct PwnMatcherBase {
+  struct MatcherResult {
+    double transform[16];            // column-major, Aligner::T() widened to double (convertScalar, .h:66-71)
+    double informationMatrix[36];
+    int cloud_inliers, image_nonZeros, image_outliers, image_inliers;
+    float image_reprojectionDistance;
+  };
+  PwnMatcherBase(Context* ctx, Aligner* aligner, DepthImageConverter* converter) : _ctx(ctx), _aligner(aligner), _converter(converter) {}
+  int scale() const { return _scale; }  void setScale(int s) { _scale = s; }
+  Aligner* aligner() { return _aligner; }  DepthImageConverter* converter() { return _converter; }
+
+  // .cpp:57-86: returns a new Cloud owned by the caller; r, c, cameraMatrix receive the scaled values
+  Cloud* makeCloud(int& r, int& c, Matrix3f& cameraMatrix, const Isometry3f& sensorOffset, const DepthImage& depthImage) {
+    PinholePointProjector* projector = _converter->projector();
+    const float invScale = 1.0f / _scale;
+    Matrix3f scaled = cameraMatrix;
+    for (int i = 0; i < 9; ++i) scaled.m[i] = scaled.m[i] * invScale;
+    scaled(2,2) = 1.0f;
+    projector->setCameraMatrix(scaled);
+    projector->setImageSize(depthImage.rows / _scale, depthImage.cols / _scale);
+    DepthImage scaledImage;
+    DepthImage_scale(*_ctx, scaledImage, depthImage, _scale);
+    cameraMatrix = projector->cameraMatrix(); r = projector->imageRows(); c = projector->imageCols();
+    Cloud* cloud = new Cloud(*_ctx, scaledImage.rows * scaledImage.cols > 0 ? scaledImage.rows * scaledImage.cols : 1);
+    _converter->compute(*cloud, scaledImage, sensorOffset);
+    ++numCalls;
+    return cloud;
+  }
+  // .cpp:88-183
+  void matchClouds(MatcherResult& result, Cloud* fromCloud, Cloud* toCloud, const Isometry3f& fromOffset, const Isometry3f& toOffset,
+                   const Matrix3f& toCameraMatrix, int toRows, int toCols, const Isometry3f& initialGuess = Isometry3f::Identity()) {
+    PinholePointProjector* projector = _aligner->projector();
+    _aligner->setReferenceSensorOffset(fromOffset);
+    _aligner->setCurrentSensorOffset(toOffset);
+    Isometry3f ig = initialGuess;
+    ig(2,3) = 0.f;
+    _aligner->setInitialGuess(ig);
+    projector->setCameraMatrix(toCameraMatrix);
+    projector->setImageSize(toRows, toCols);
+    projector->scale((float)(1. / _scale));
+    _aligner->correspondenceFinder()->setImageSize(projector->imageRows(), projector->imageCols());
+    _aligner->setReferenceCloud(fromCloud);
+    _aligner->setCurrentCloud(toCloud);
+    _aligner->align();
+    for (int i = 0; i < 16; ++i) result.transform[i] = _aligner->T().m[i];
+    for (int i = 0; i < 36; ++i) result.informationMatrix[i] = (i % 7 == 0) ? 100.0 : 0.0;
+    result.cloud_inliers = _aligner->inliers();
+    pwn_hip_match_result m;
+    _ctx->check(pwn_hip_match_score(_ctx->handle(), _frameInlierDepthThreshold, &m));
+    result.image_reprojectionDistance = m.image_reprojection_distance;
+    result.image_nonZeros = m.image_non_zeros; result.image_outliers = m.image_outliers; result.image_inliers = m.image_inliers;
+  }
+  int numCalls = 0;
+ protected:
+  Context* _ctx; Aligner* _aligner; DepthImageConverter* _converter;
+  float _frameInlierDepthThreshold = 50.f;   // .cpp:13
+  int _scale = 2;                            // .cpp:12
+};
+
 }  // namespace pwn_hip

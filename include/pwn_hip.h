@@ -100,6 +100,15 @@ typedef struct pwn_hip_align_result {
   int   n_reference, n_current;                /* M_r, M_c */
 } pwn_hip_align_result;
 
+/* PwnMatcherBase::MatcherResult image fields (pwn_tracker/pwn_matcher_base.h:13-22), what PwnCloser::matchFrames
+ * thresholds (pwn_tracker/pwn_closer.cpp:56-58,138-141). */
+typedef struct pwn_hip_match_result {
+  int   image_non_zeros;               /* pixels where both finder depth images are > 0 after the uint16-mm conversion */
+  int   image_outliers;                /* non_zeros - inliers */
+  int   image_inliers;                 /* masked pixels whose (bit-masked) |depth difference| < threshold */
+  float image_reprojection_distance;   /* sum of the differences / non_zeros */
+} pwn_hip_match_result;
+
 /* ------------------------------------------------------------------ context ------------------ */
 /* cf. pwn_cuda createContext(AlignerContext**, maxRef, maxCur, rows, cols) (cudaaligner.h:59).
  * max_batch = largest number of frames (convert_batch) / pairs (align_batch) per call. */
@@ -202,6 +211,17 @@ int pwn_hip_align_images(pwn_hip_ctx* ctx, int* reference_index, float* referenc
  * p is shared by all pairs; initial_guesses: n*16 floats or NULL (= p->initial_guess for all). */
 int pwn_hip_align_batch(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* references,
                         pwn_hip_cloud* const* currents, const float* initial_guesses, pwn_hip_align_result* results);
+
+/* ------------------------------------------------------------------ matcher ---------- */
+/* Post-alignment depth-agreement score of PwnMatcherBase::matchClouds (pwn_tracker/pwn_matcher_base.cpp:153-182) on the
+ * finder depth images of the last pwn_hip_align: DepthImage_convert_32FC1_to_16UC1 of both (scale 1000, FLT_MAX -> 0),
+ * mask, |difference|, counts.  frame_inlier_depth_threshold: _frameInlierDepthThreshold (50, pwn_matcher_base.cpp:13). */
+int pwn_hip_match_score(pwn_hip_ctx* ctx, float frame_inlier_depth_threshold, pwn_hip_match_result* out);
+/* pwn_hip_align_batch + the score of every pair (the loop-closure check of PwnCloser::processPartition,
+ * pwn_tracker/pwn_closer.cpp:92-111, without the host loop).  scores: n records. */
+int pwn_hip_match_batch(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* references,
+                        pwn_hip_cloud* const* currents, const float* initial_guesses, float frame_inlier_depth_threshold,
+                        pwn_hip_align_result* results, pwn_hip_match_result* scores);
 
 /* ------------------------------------------------------------------ helpers ------------------ */
 /* PinholePointProjector::_updateMatrices (pinholepointprojector.cpp:17-31): KRt, iKRt (4x4), iK (3x3) */

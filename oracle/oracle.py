@@ -86,6 +86,7 @@ def lib():
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_set_trig_mode.argtypes = [C.c_int]
+        L.orc_match_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 4
         _lib = L
     return _lib
 
@@ -303,6 +304,14 @@ def align(p: AlignerParams, ref: Cloud, cur: Cloud, images=False):
     if images:
         out.update(ref_index=ri, ref_depth=rd, cur_index=ci, cur_depth=cd)
     return out
+
+
+def match_score(ref_depth, cur_depth, threshold=50.0):
+    """pwn_matcher_base.cpp:153-182 -> dict(image_nonZeros, image_outliers, image_inliers, image_reprojectionDistance)"""
+    r, c = _f32(ref_depth), _f32(cur_depth)
+    nz, out, inl, dist = C.c_int(0), C.c_int(0), C.c_int(0), C.c_float(0)
+    lib().orc_match_score(_p(r), _p(c), r.size, C.c_float(threshold), C.byref(nz), C.byref(out), C.byref(inl), C.byref(dist))
+    return dict(image_nonZeros=nz.value, image_outliers=out.value, image_inliers=inl.value, image_reprojectionDistance=dist.value)
 
 
 def v2t(v):

@@ -858,6 +858,28 @@ void orc_align(const orc_aligner_params* p, const orc_cloud* ref, const orc_clou
   if (cur_depth_out) std::memcpy(cur_depth_out, curDepth.data(), N * sizeof(float));
 }
 
+/* pwn_tracker/pwn_matcher_base.cpp:153-182.  cv::Mat semantics restated: (a>0)&(b>0) is a 0/255 uchar mask, converted
+ * to float it is 0.0f/255.0f, and `abs(cur-ref) & mask` on CV_32F data is a BITWISE and of the float words. */
+void orc_match_score(const float* ref_depth, const float* cur_depth, int n, float threshold, int* non_zeros, int* outliers,
+                     int* inliers, float* reprojection_distance) {
+  std::vector<uint16_t> c(n), r(n);
+  orc_convert_32f_to_16u(cur_depth, c.data(), n, 1000.0f);     /* :157 */
+  orc_convert_32f_to_16u(ref_depth, r.data(), n, 1000.0f);     /* :160 */
+  int nz = 0, inl = 0; float sum = 0;
+  for (int i = 0; i < n; ++i) {
+    const bool m = c[i] > 0 && r[i] > 0;                        /* :163 */
+    const float maskf = m ? 255.0f : 0.0f;                      /* :166 */
+    const float ad = std::fabs((float)c[i] - (float)r[i]);      /* :164-165,167 */
+    uint32_t a, b; std::memcpy(&a, &ad, 4); std::memcpy(&b, &maskf, 4);
+    const uint32_t w = a & b; float d; std::memcpy(&d, &w, 4);  /* :167 bitwise and */
+    nz += m;                                                     /* :168 countNonZero(mask) */
+    if (maskf && d < threshold) ++inl;                          /* :174-175 */
+    sum += d;                                                    /* :176 */
+  }
+  *non_zeros = nz; *inliers = inl; *outliers = nz - inl;        /* :180-182 */
+  *reprojection_distance = sum / nz;                            /* :179 */
+}
+
 void orc_v2t(const float v[6], float T[16]) { const M4 t = v2t(v); std::memcpy(T, t.m, sizeof(t.m)); }
 void orc_t2v(const float T[16], float v[6]) { t2v(m4_load(T), v); }
 void orc_eigen3(const float A[9], float evals[3], float evecs[9]) {

@@ -138,6 +138,10 @@ void orc_align(const orc_aligner_params* p, const orc_cloud* ref, const orc_clou
                float T_out[16], float* error_out, int* inliers_out, orc_iter_trace* trace,
                int* ref_index_out, float* ref_depth_out, int* cur_index_out, float* cur_depth_out);
 
+/* PwnMatcherBase::matchClouds post-align scoring (pwn_tracker/pwn_matcher_base.cpp:153-182) on the finder's depth images */
+void orc_match_score(const float* ref_depth, const float* cur_depth, int n, float threshold, int* non_zeros, int* outliers,
+                     int* inliers, float* reprojection_distance);
+
 /* bm_se3.h:9-52 exposed for unit tests */
 void orc_v2t(const float v[6], float T[16]);
 void orc_t2v(const float T[16], float v[6]);

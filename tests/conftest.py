@@ -36,6 +36,7 @@ def pytest_collection_modifyitems(config, items):
 CASES = {
     "small": dict(rows=120, cols=160, scale=4),
     "vga": dict(rows=480, cols=640, scale=1),
+    "k2": dict(rows=960, cols=1280, scale=1),      # BASELINE configs[4]: Kinect-2-scale frames
 }
 
 
@@ -43,6 +44,8 @@ def case_params(name):
     from g2o_frontend_amd import synth
     from oracle import oracle as O
     c = CASES[name]
+    if name == "k2":     # K = (1050,1050,639.5,479.5), stats radii x2 (min 20, max 60, minPoints 200), rest as VGA
+        return c["rows"], c["cols"], synth.K_1280, dict(O.VGA_CONF_CONVERTER, min_image_radius=20, max_image_radius=60, min_points=200), dict(O.VGA_CONF_ALIGNER)
     K = synth.scaled_K(synth.K_VGA, c["scale"]) if c["scale"] != 1 else synth.K_VGA
     conv = dict(O.QVGA4_CONF_CONVERTER if c["scale"] == 4 else O.VGA_CONF_CONVERTER)
     alig = dict(O.QVGA4_CONF_ALIGNER if c["scale"] == 4 else O.VGA_CONF_ALIGNER)

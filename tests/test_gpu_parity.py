@@ -394,6 +394,30 @@ def test_full_pipeline_depth_to_pose(ctx, oracle, name, seed):
     _check_teacher_forced(aligner, o)      # strict 1e-5 per iteration, from depth images to chi2, all on the GPU
 
 
+def test_full_pipeline_1280x960(oracle):
+    """BASELINE configs[4] frame size: converter bit-exact, alignment trace within the bars, at 1280x960."""
+    from g2o_frontend_amd import api
+    name = "k2"
+    rows, cols, K, conv, _ = case_params(name)
+    ref, cur, Ttrue, _, _ = make_depth_pair(name, 0)
+    cp, ap = oracle_params(oracle, name, accumulate_fp64=1)
+    oref, oidx, _ = oracle.convert(cp, ref); ocur, _, _ = oracle.convert(cp, cur)
+    o = oracle.align(ap, oref, ocur)
+    big = api.Context(0, rows, cols, 2)
+    _, converter, aligner = gpu_objects(big, name)
+    gref, gcur = api.Cloud(big, rows * cols), api.Cloud(big, rows * cols)
+    converter.compute(gref, ref)
+    assert np.array_equal(oidx, converter.indexImage())
+    _compare_clouds(oref.arrays(), gref.arrays(), name)
+    converter.compute(gcur, cur)
+    aligner.setReferenceCloud(gref); aligner.setCurrentCloud(gcur)
+    g = aligner.align()
+    _check_alignment(o, g)
+    _check_teacher_forced(aligner, o)
+    assert np.abs(g["T"][:3, 3] - Ttrue[:3, 3]).max() < 5e-3
+    big.close()
+
+
 def test_align_with_sensor_offset_and_guess(ctx, oracle):
     from g2o_frontend_amd import api, synth
     name = "small"
