@@ -91,6 +91,8 @@ PROTOTYPES = {
     "pwn_hip_match_score": (_I, [_VP, _F, _VP]),
     "pwn_hip_match_batch": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _F, _VP, _VP]),
     "pwn_hip_projector_matrices": (None, [_VP, _VP, _VP, _VP, _VP]),
+    "pwn_hip_iso_inverse": (None, [_VP, _VP]),
+    "pwn_hip_iso_mul": (None, [_VP, _VP, _VP]),
     "pwn_hip_v2t": (None, [_VP, _VP]),
     "pwn_hip_t2v": (None, [_VP, _VP]),
     "pwn_hip_last_stage_ms": (_I, [_VP, C.c_char_p, C.POINTER(_F), C.POINTER(_I)]),

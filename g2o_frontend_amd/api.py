@@ -597,6 +597,134 @@ class PwnCloserAcceptance:
                     or result["image_inliers"] < self.frameMinInliersThreshold)
 
 
+def iso_inverse(T):
+    """Eigen::Isometry3f::inverse() in float with the CPU path's evaluation order"""
+    o = np.empty(16, np.float32)
+    _lib.lib().pwn_hip_iso_inverse(_ptr(_colmajor(T, 4)), _ptr(o))
+    return o.reshape(4, 4).T.copy()
+
+
+def iso_mul(A, B):
+    """Isometry3f * Isometry3f in float with the CPU path's evaluation order"""
+    o = np.empty(16, np.float32)
+    _lib.lib().pwn_hip_iso_mul(_ptr(_colmajor(A, 4)), _ptr(_colmajor(B, 4)), _ptr(o))
+    return o.reshape(4, 4).T.copy()
+
+
+def _mul3(A, B):
+    """3x3 float product with Eigen's left-to-right inner products (no BLAS, no FMA)"""
+    A = np.asarray(A, np.float32); B = np.asarray(B, np.float32)
+    R = np.empty((3, 3), np.float32)
+    for i in range(3):
+        for j in range(3):
+            s = np.float32(A[i, 0] * B[0, j]); s = np.float32(s + np.float32(A[i, 1] * B[1, j])); s = np.float32(s + np.float32(A[i, 2] * B[2, j]))
+            R[i, j] = s
+    return R
+
+
+class CloudCache:
+    """Device-resident LRU of clouds keyed by frame (pwn_tracker/pwn_tracker_cache.cpp:24-51 + boss_map_building cache):
+    a miss re-runs the converter on the frame's stored depth image (PwnCache::loadFrame), so loop-closure batches do not
+    re-convert frames that are still resident in HBM."""
+
+    def __init__(self, matcher: "PwnMatcherBase", capacity: int = 64):
+        self._matcher, self._capacity = matcher, capacity
+        self._clouds = {}        # key -> Cloud, insertion order = recency
+        self._frames = {}        # key -> (depthImage, cameraMatrix, sensorOffset)
+        self.hits = self.misses = 0
+
+    def addFrame(self, key, depthImage, cameraMatrix, sensorOffset, cloud: Cloud = None):
+        self._frames[key] = (np.ascontiguousarray(depthImage, np.float32), np.asarray(cameraMatrix, np.float32).copy(),
+                             np.asarray(sensorOffset, np.float32).copy())
+        if cloud is not None:
+            self._insert(key, cloud)
+
+    def _insert(self, key, cloud):
+        self._clouds.pop(key, None)
+        self._clouds[key] = cloud
+        while len(self._clouds) > self._capacity:
+            self._clouds.pop(next(iter(self._clouds)))          # least recently used
+
+    def get(self, key) -> Cloud:
+        c = self._clouds.pop(key, None)
+        if c is not None:
+            self.hits += 1
+            self._clouds[key] = c
+            return c
+        self.misses += 1
+        depth, K, off = self._frames[key]
+        c, _, _, _ = self._matcher.makeCloud(K, off, depth)    # pwn_tracker_cache.cpp:38-44
+        self._insert(key, c)
+        return c
+
+
+class PwnTracker(PwnMatcherBase):
+    """pwn_tracker/pwn_tracker.{h,cpp}: sequential odometry with key-cloud switching (processFrame, .cpp:106-215).
+    The BOSS map bookkeeping of the reference (frames / relations written to the map manager, :217-281) is reported
+    through the returned dict instead."""
+
+    def __init__(self, aligner, converter):
+        super().__init__(aligner, converter)
+        self._previousCloud = None
+        self._globalT = np.eye(4, dtype=np.float32)
+        self._previousCloudTransform = np.eye(4, dtype=np.float32)
+        self._previousCloudOffset = np.eye(4, dtype=np.float32)
+        self._newFrameInliersFraction = 0.4          # pwn_tracker.cpp:36
+        self._counter = 0
+        self._numKeyframes = 0
+
+    def globalT(self): return self._globalT
+    def numKeyframes(self): return self._numKeyframes
+    def setNewFrameInliersFraction(self, v): self._newFrameInliersFraction = float(v)
+
+    def init(self):
+        """pwn_tracker.cpp:38-49"""
+        self._previousCloud = None
+        self._globalT = np.eye(4, dtype=np.float32); self._previousCloudTransform = np.eye(4, dtype=np.float32)
+        self._counter = 0; self._numKeyframes = 0
+
+    def processFrame(self, depthImage, sensorOffset, cameraMatrix, initialGuess=None):
+        """pwn_tracker.cpp:106-215"""
+        a = self._aligner
+        initialGuess = np.eye(4, dtype=np.float32) if initialGuess is None else np.asarray(initialGuess, np.float32)
+        currentCloudOffset = np.asarray(sensorOffset, np.float32)
+        currentCloud, r, c, scaledCameraMatrix = self.makeCloud(cameraMatrix, currentCloudOffset, depthImage)     # :115
+        out = dict(newFrame=False, aligned=False, inliers=0, error=0.0, T=None)
+        if self._previousCloud is not None:
+            a.setCurrentSensorOffset(currentCloudOffset); a.setCurrentCloud(currentCloud)
+            a.setReferenceSensorOffset(self._previousCloudOffset); a.setReferenceCloud(self._previousCloud)
+            a.correspondenceFinder().setImageSize(r, c)
+            a.projector().setCameraMatrix(scaledCameraMatrix); a.projector().setImageSize(r, c)
+            guess = iso_mul(iso_mul(iso_inverse(self._previousCloudTransform), self._globalT), initialGuess)      # :132
+            a.setInitialGuess(guess)
+            res = a.align()                                                                                        # :136
+            if res["inliers"] > 0:
+                self._globalT = iso_mul(self._previousCloudTransform, res["T"])                                   # :147
+            else:
+                self._globalT = iso_mul(self._globalT, guess)                                                     # :150
+            if not (self._counter % 50):                                                                            # :154-159
+                R = self._globalT[:3, :3].astype(np.float32)
+                E = _mul3(R.T, R); E[np.arange(3), np.arange(3)] -= np.float32(1)
+                self._globalT[:3, :3] = (R - _mul3(np.float32(0.5) * R, E)).astype(np.float32)
+            self._globalT[3] = (0, 0, 0, 1)
+            inliersFraction = np.float32(res["inliers"]) / np.float32(r * c)
+            out.update(aligned=True, inliers=res["inliers"], error=res["error"], T=res["T"], inliersFraction=float(inliersFraction))
+            if inliersFraction < self._newFrameInliersFraction:                                                     # :164-185
+                out["newFrame"] = True
+                self._numKeyframes += 1
+                self._previousCloud = currentCloud
+                self._previousCloudTransform = self._globalT.copy()
+        else:                                                                                                       # :194-200
+            out["newFrame"] = True
+            self._previousCloud = currentCloud
+            self._previousCloudTransform = self._globalT.copy()
+            self._previousCloudOffset = currentCloudOffset.copy()
+            self._numKeyframes += 1
+        self._counter += 1
+        out["globalT"] = self._globalT.copy()
+        return out
+
+
 def v2t(v):
     """pwn_core/bm_se3.h:37-43"""
     v = np.ascontiguousarray(v, np.float32); T = np.empty(16, np.float32)

@@ -937,6 +937,8 @@ void pwn_hip_projector_matrices(const float K[9], const float T[16], float KRt[1
   if (iKRt) std::memcpy(iKRt, b.m, sizeof(b.m));
   if (iK) std::memcpy(iK, c.m, sizeof(c.m));
 }
+void pwn_hip_iso_inverse(const float T[16], float out[16]) { const Mat4 r = iso_inverse(mat4_from(T)); std::memcpy(out, r.m, sizeof(r.m)); }
+void pwn_hip_iso_mul(const float A[16], const float B[16], float out[16]) { const Mat4 r = iso_mul(mat4_from(A), mat4_from(B)); std::memcpy(out, r.m, sizeof(r.m)); }
 void pwn_hip_v2t(const float v[6], float T[16]) { const Mat4 t = v2t(v); std::memcpy(T, t.m, sizeof(t.m)); }
 void pwn_hip_t2v(const float T[16], float v[6]) { t2v(mat4_from(T), v); }
 

@@ -226,6 +226,9 @@ int pwn_hip_match_batch(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n
 /* ------------------------------------------------------------------ helpers ------------------ */
 /* PinholePointProjector::_updateMatrices (pinholepointprojector.cpp:17-31): KRt, iKRt (4x4), iK (3x3) */
 void pwn_hip_projector_matrices(const float K[9], const float T[16], float KRt[16], float iKRt[16], float iK[9]);
+/* Eigen::Isometry3f::inverse() and Isometry3f * Isometry3f with the evaluation order the CPU path has (host code) */
+void pwn_hip_iso_inverse(const float T[16], float out[16]);
+void pwn_hip_iso_mul(const float A[16], const float B[16], float out[16]);
 /* bm_se3.h:37-52 */
 void pwn_hip_v2t(const float v[6], float T[16]);
 void pwn_hip_t2v(const float T[16], float v[6]);

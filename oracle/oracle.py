@@ -86,6 +86,8 @@ def lib():
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_set_trig_mode.argtypes = [C.c_int]
+        L.orc_iso_inverse.argtypes = [C.c_void_p] * 2
+        L.orc_iso_mul.argtypes = [C.c_void_p] * 3
         L.orc_match_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 4
         _lib = L
     return _lib
@@ -312,6 +314,18 @@ def match_score(ref_depth, cur_depth, threshold=50.0):
     nz, out, inl, dist = C.c_int(0), C.c_int(0), C.c_int(0), C.c_float(0)
     lib().orc_match_score(_p(r), _p(c), r.size, C.c_float(threshold), C.byref(nz), C.byref(out), C.byref(inl), C.byref(dist))
     return dict(image_nonZeros=nz.value, image_outliers=out.value, image_inliers=inl.value, image_reprojectionDistance=dist.value)
+
+
+def iso_inverse(T):
+    Tc = _f32(np.asarray(T, np.float32).T.reshape(-1)); o = np.empty(16, np.float32)
+    lib().orc_iso_inverse(_p(Tc), _p(o))
+    return o.reshape(4, 4).T.copy()
+
+
+def iso_mul(A, B):
+    a = _f32(np.asarray(A, np.float32).T.reshape(-1)); b = _f32(np.asarray(B, np.float32).T.reshape(-1)); o = np.empty(16, np.float32)
+    lib().orc_iso_mul(_p(a), _p(b), _p(o))
+    return o.reshape(4, 4).T.copy()
 
 
 def v2t(v):

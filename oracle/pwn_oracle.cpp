@@ -880,6 +880,8 @@ void orc_match_score(const float* ref_depth, const float* cur_depth, int n, floa
   *reprojection_distance = sum / nz;                            /* :179 */
 }
 
+void orc_iso_inverse(const float T[16], float out[16]) { const M4 r = iso_inverse(m4_load(T)); std::memcpy(out, r.m, sizeof(r.m)); }
+void orc_iso_mul(const float A[16], const float B[16], float out[16]) { const M4 r = iso_mul(m4_load(A), m4_load(B)); std::memcpy(out, r.m, sizeof(r.m)); }
 void orc_v2t(const float v[6], float T[16]) { const M4 t = v2t(v); std::memcpy(T, t.m, sizeof(t.m)); }
 void orc_t2v(const float T[16], float v[6]) { t2v(m4_load(T), v); }
 void orc_eigen3(const float A[9], float evals[3], float evecs[9]) {

@@ -142,6 +142,9 @@ void orc_align(const orc_aligner_params* p, const orc_cloud* ref, const orc_clou
 void orc_match_score(const float* ref_depth, const float* cur_depth, int n, float threshold, int* non_zeros, int* outliers,
                      int* inliers, float* reprojection_distance);
 
+/* Isometry3f::inverse / product (used by the tracker harness of the tests) */
+void orc_iso_inverse(const float T[16], float out[16]);
+void orc_iso_mul(const float A[16], const float B[16], float out[16]);
 /* bm_se3.h:9-52 exposed for unit tests */
 void orc_v2t(const float v[6], float T[16]);
 void orc_t2v(const float T[16], float v[6]);
