@@ -44,7 +44,8 @@ def parse():
     ap.add_argument("--no-latency", action="store_true")
     ap.add_argument("--align-only", action="store_true", help="also time align-only (clouds resident)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run only the CPU baseline leg and print its JSON")
-    ap.add_argument("--no-profile", action="store_true", help="no per-kernel hipEvent timing in the timed region (roofline fields become 0)")
+    ap.add_argument("--no-profile", action="store_true", help="skip the serial profiled pass (roofline fields become 0)")
+    ap.add_argument("--streams", type=int, default=2, help="HIP streams the batch calls use in the timed region (1 = serial)")
     return ap.parse_args()
 
 
@@ -139,7 +140,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
-    slots = max(args.sub_frames, args.sub_pairs, 1)
+    slots = 2 * max(args.sub_frames, args.sub_pairs, 1)      # room for two sub-batches in flight (two-stream mode)
     ctx = api.Context(device=local, max_rows=rows, max_cols=cols, max_batch=slots)
     ctx.set_subbatch(args.sub_frames, args.sub_pairs)
     converter, aligner = build_objects(ctx, rows, cols, K, conv, alig)
@@ -187,15 +188,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    ctx.set_profiling(not args.no_profile)      # hipEvent pairs around every kernel stage, on the library's stream
+    # timed region: the product configuration (two streams, no event instrumentation)
+    ctx.set_concurrency(args.streams)
+    ctx.set_profiling(False)
     for _ in range(args.warmup):
         step(False)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step(True)
+        step(False)
     barrier()
     dt = time.perf_counter() - t0
+    # per-kernel durations: the same K steps again on ONE stream with a hipEvent pair around every kernel stage (on the
+    # library's stream).  With two streams, launches of different sub-batches overlap and a launch's elapsed time is no
+    # longer the kernel's own duration, so the roofline figures come from this serial pass (rocprofv3 summaries in profiles/
+    # are taken the same way: bench.py --streams 1).
+    dt_serial = None
+    if not args.no_profile:
+        ctx.set_concurrency(1)
+        ctx.set_profiling(True)
+        step(False)
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(True)
+        barrier()
+        dt_serial = time.perf_counter() - t1
+        ctx.set_profiling(False)
+        ctx.set_concurrency(args.streams)
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -256,11 +276,15 @@ def main():
                                    f"(u16 mm frames resident in HBM; per pair: convert 2 frames + Aligner::align, "
                                    f"{alig['outer_iterations']}x{alig['inner_iterations']} GN iterations); BASELINE configs[3] shard",
                        "pairs_per_gpu": P, "rows": rows, "cols": cols, "sub_frames": args.sub_frames, "sub_pairs": args.sub_pairs,
+                       "streams": args.streams,
                        "parallelism": f"independent pairs sharded over {world} GPU(s), RCCL all-gather of poses only"},
             "roofline": {"bound": "hbm", "kernel": "k_corr_linearize", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_launch_algorithmic": k_bytes, "avg_launch_ms": k_ms, "launches": stage_n["corr_linearize"],
-                         "dominant_by_time": dom},
+                         "dominant_by_time": dom,
+                         "measured_in": "serial profiled pass of the same K steps (one stream, hipEvent pair per kernel stage); "
+                                        "the timed region runs two streams without instrumentation",
+                         "serial_pass_alignments_per_s": (world * P * args.steps / dt_serial) if dt_serial else None},
             "cpu_baseline": cpu,
             "path_roofline": {"algorithmic_bytes_per_pair": total_bytes_step / P, "achieved_GBps": total_bytes_step * args.steps / dt / 1e9,
                               "frac_of_peak": total_bytes_step * args.steps / dt / 1e9 / HBM_PEAK_GBS},

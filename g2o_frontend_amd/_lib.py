@@ -62,6 +62,7 @@ PROTOTYPES = {
     "pwn_hip_ctx_set_stream": (_I, [_VP, _VP]),
     "pwn_hip_ctx_synchronize": (_I, [_VP]),
     "pwn_hip_ctx_set_subbatch": (_I, [_VP, _I, _I]),
+    "pwn_hip_ctx_set_concurrency": (_I, [_VP, _I]),
     "pwn_hip_last_error_string": (C.c_char_p, [_VP]),
     "pwn_hip_device_count": (_I, []),
     "pwn_hip_default_converter_params": (None, [_VP]),

@@ -83,6 +83,9 @@ class Context:
     def set_subbatch(self, frames, pairs):
         self.check(self._L.pwn_hip_ctx_set_subbatch(self.h, frames, pairs))
 
+    def set_concurrency(self, streams: int):
+        self.check(self._L.pwn_hip_ctx_set_concurrency(self.h, streams))
+
     def synchronize(self):
         self.check(self._L.pwn_hip_ctx_synchronize(self.h))
 

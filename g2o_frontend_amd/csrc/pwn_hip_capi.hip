@@ -38,9 +38,12 @@ struct pwn_hip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;
+  hipStream_t stream2 = nullptr;           // batch calls alternate sub-batches between `stream` and `stream2` (own streams only)
+  hipEvent_t fork_ev = nullptr, join_ev = nullptr;
   int max_rows = 0, max_cols = 0, max_batch = 0;
   size_t N = 0;
   int sub_frames = 64, sub_pairs = 64;
+  int concurrency = 2;
   // convert workspaces (per slot)
   float* depth_ws = nullptr; int* index_ws = nullptr; int* interval_ws = nullptr; float* integral_ws = nullptr; int* rowoff_ws = nullptr;
   uint16_t* raw_ws = nullptr;
@@ -96,12 +99,37 @@ hipEvent_t get_event(pwn_hip_ctx* ctx) {
   hipEvent_t e; (void)hipEventCreateWithFlags(&e, hipEventDisableSystemFence); return e;
 }
 struct StageTimer {
-  pwn_hip_ctx* ctx; EventRec rec; bool on;
-  StageTimer(pwn_hip_ctx* c, const char* stage) : ctx(c), on(c->profiling) {
-    if (on) { rec.stage = stage; rec.a = get_event(ctx); rec.b = get_event(ctx); (void)hipEventRecord(rec.a, ctx->stream); }
+  pwn_hip_ctx* ctx; EventRec rec; bool on; hipStream_t st;
+  StageTimer(pwn_hip_ctx* c, const char* stage, hipStream_t s = nullptr) : ctx(c), on(c->profiling), st(s ? s : c->stream) {
+    if (on) { rec.stage = stage; rec.a = get_event(ctx); rec.b = get_event(ctx); (void)hipEventRecord(rec.a, st); }
   }
-  ~StageTimer() { if (on) { (void)hipEventRecord(rec.b, ctx->stream); ctx->pending.push_back(rec); } }
+  ~StageTimer() { if (on) { (void)hipEventRecord(rec.b, st); ctx->pending.push_back(rec); } }
 };
+// Two-stream mode: only with the context's own streams and when the workspaces hold two sub-batches.
+struct StreamPlan {
+  int sub; bool dual; hipStream_t s[2];
+  hipStream_t stream(int k) const { return s[dual ? (k & 1) : 0]; }
+  int slot0(int k) const { return dual ? (k & 1) * sub : 0; }
+};
+StreamPlan make_plan(pwn_hip_ctx* ctx, int want_sub, int n) {
+  StreamPlan p;
+  p.sub = std::max(1, std::min(want_sub, ctx->max_batch));
+  p.dual = ctx->concurrency >= 2 && ctx->stream == ctx->own_stream && ctx->stream2 && n > p.sub && 2 * p.sub <= ctx->max_batch;
+  p.s[0] = ctx->stream; p.s[1] = p.dual ? ctx->stream2 : ctx->stream;
+  return p;
+}
+int plan_fork(pwn_hip_ctx* ctx, const StreamPlan& p) {      // stream2 starts after everything enqueued so far on stream
+  if (!p.dual) return PWN_HIP_OK;
+  HIPCHK(ctx, hipEventRecord(ctx->fork_ev, p.s[0]), PWN_HIP_ERR_LAUNCH);
+  HIPCHK(ctx, hipStreamWaitEvent(p.s[1], ctx->fork_ev, 0), PWN_HIP_ERR_LAUNCH);
+  return PWN_HIP_OK;
+}
+int plan_join(pwn_hip_ctx* ctx, const StreamPlan& p) {      // stream continues after stream2's work
+  if (!p.dual) return PWN_HIP_OK;
+  HIPCHK(ctx, hipEventRecord(ctx->join_ev, p.s[1]), PWN_HIP_ERR_LAUNCH);
+  HIPCHK(ctx, hipStreamWaitEvent(p.s[0], ctx->join_ev, 0), PWN_HIP_ERR_LAUNCH);
+  return PWN_HIP_OK;
+}
 void collect_stage_times(pwn_hip_ctx* ctx) {
   for (auto& r : ctx->pending) {
     float ms = 0.f;
@@ -205,18 +233,18 @@ int ensure_desc(pwn_hip_ctx* ctx, int n) {
 }
 
 // launch sequence of the converter for the frames [base, base+n) of the uploaded descriptor array
-int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n) {
+int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, hipStream_t st) {
   const FrameDesc* fr = ctx->frames_dev + base;
-  { StageTimer t(ctx, "unproject");
-    hipLaunchKernelGGL(k_row_count, dim3(cp.rows, n), dim3(256), 0, ctx->stream, fr, cp);
-    hipLaunchKernelGGL(k_row_offsets, dim3(n), dim3(1024), 0, ctx->stream, fr, cp.rows);
-    hipLaunchKernelGGL(k_unproject, dim3(cp.rows, n), dim3(256), 0, ctx->stream, fr, cp); }
-  { StageTimer t(ctx, "integral_rows");
-    hipLaunchKernelGGL(k_integral_rows, dim3((cp.rows + kIR_Rows - 1) / kIR_Rows, n), dim3(256), 0, ctx->stream, fr, cp.rows, cp.cols); }
-  { StageTimer t(ctx, "integral_cols");
-    hipLaunchKernelGGL(k_integral_cols, dim3((cp.cols + 255) / 256, kIntegralChannels, n), dim3(256), 0, ctx->stream, fr, cp.rows, cp.cols); }
-  { StageTimer t(ctx, "stats");
-    hipLaunchKernelGGL(k_stats, dim3((cp.cols + 255) / 256, cp.rows, n), dim3(256), 0, ctx->stream, fr, cp); }
+  { StageTimer t(ctx, "unproject", st);
+    hipLaunchKernelGGL(k_row_count, dim3(cp.rows, n), dim3(256), 0, st, fr, cp);
+    hipLaunchKernelGGL(k_row_offsets, dim3(n), dim3(1024), 0, st, fr, cp.rows);
+    hipLaunchKernelGGL(k_unproject, dim3(cp.rows, n), dim3(256), 0, st, fr, cp); }
+  { StageTimer t(ctx, "integral_rows", st);
+    hipLaunchKernelGGL(k_integral_rows, dim3((cp.rows + kIR_Rows - 1) / kIR_Rows, n), dim3(256), 0, st, fr, cp.rows, cp.cols); }
+  { StageTimer t(ctx, "integral_cols", st);
+    hipLaunchKernelGGL(k_integral_cols, dim3((cp.cols + 255) / 256, kIntegralChannels, n), dim3(256), 0, st, fr, cp.rows, cp.cols); }
+  { StageTimer t(ctx, "stats", st);
+    hipLaunchKernelGGL(k_stats, dim3((cp.cols + 255) / 256, cp.rows, n), dim3(256), 0, st, fr, cp); }
   HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
   return PWN_HIP_OK;
 }
@@ -257,7 +285,8 @@ int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, cons
   const size_t N = (size_t)rows * cols;
   ctx->stages.clear();
   const ConvertParams cp = make_convert_params(p, nullptr, rows, cols, keep_stats);
-  const int sub = std::max(1, std::min(ctx->sub_frames, ctx->max_batch));
+  const StreamPlan plan = make_plan(ctx, ctx->sub_frames, n);
+  const int sub = plan.sub;
   if (int rc = ensure_desc(ctx, n)) return rc;
   const bool raw = std::is_same<SRC, uint16_t>::value;
   // every frame gets a descriptor; workspace slots are reused round-robin (stream order serialises the reuse)
@@ -268,7 +297,7 @@ int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, cons
     c->has_stats = keep_stats != 0;
     if (c->d.OmN) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH); (void)hipFree(c->d.OmN); c->d.OmN = nullptr; }
     make_omega_n_classes(p, c->d);
-    const int slot = i % sub;
+    const int slot = plan.slot0(i / sub) + i % sub;
     const float* depth_dev = nullptr;
     if (raw) {
       const uint16_t* src = reinterpret_cast<const uint16_t*>(frames[i]);
@@ -284,27 +313,31 @@ int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, cons
   const bool host_input = !is_device_ptr(frames[0]);
   if (host_input) {
     for (int i = 0; i < n; ++i) {
-      const int slot = i % sub;
+      const int slot = plan.slot0(i / sub) + i % sub;
       if (raw) ctx->raw_host[i].src = ctx->raw_ws + (size_t)slot * ctx->N;
       else ctx->frames_host[i].depth = ctx->depth_ws + (size_t)slot * ctx->N;
     }
   }
   HIPCHK(ctx, hipMemcpyAsync(ctx->frames_dev, ctx->frames_host, sizeof(FrameDesc) * n, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
   if (raw) HIPCHK(ctx, hipMemcpyAsync(ctx->raw_dev, ctx->raw_host, sizeof(RawDesc) * n, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
-  for (int base = 0; base < n; base += sub) {
+  if (int rc = plan_fork(ctx, plan)) return rc;
+  for (int base = 0, k = 0; base < n; base += sub, ++k) {
     const int m = std::min(sub, n - base);
+    hipStream_t st = plan.stream(k);
+    const int s0 = plan.slot0(k);
     if (host_input) {
       for (int i = 0; i < m; ++i) {
-        if (raw) HIPCHK(ctx, hipMemcpyAsync(ctx->raw_ws + (size_t)i * ctx->N, frames[base + i], N * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
-        else HIPCHK(ctx, hipMemcpyAsync(ctx->depth_ws + (size_t)i * ctx->N, frames[base + i], N * sizeof(float), hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
+        if (raw) HIPCHK(ctx, hipMemcpyAsync(ctx->raw_ws + (size_t)(s0 + i) * ctx->N, frames[base + i], N * sizeof(uint16_t), hipMemcpyHostToDevice, st), PWN_HIP_ERR_COPY);
+        else HIPCHK(ctx, hipMemcpyAsync(ctx->depth_ws + (size_t)(s0 + i) * ctx->N, frames[base + i], N * sizeof(float), hipMemcpyHostToDevice, st), PWN_HIP_ERR_COPY);
       }
     }
     if (raw) {
-      StageTimer t(ctx, "u16_to_f32");
-      hipLaunchKernelGGL(k_u16_to_f32, dim3((unsigned)std::min<size_t>((N + 255) / 256, 1024), m), dim3(256), 0, ctx->stream, ctx->raw_dev + base, (int)N, depth_scale);
+      StageTimer t(ctx, "u16_to_f32", st);
+      hipLaunchKernelGGL(k_u16_to_f32, dim3((unsigned)std::min<size_t>((N + 255) / 256, 1024), m), dim3(256), 0, st, ctx->raw_dev + base, (int)N, depth_scale);
     }
-    if (int rc = launch_convert(ctx, cp, base, m)) return rc;
+    if (int rc = launch_convert(ctx, cp, base, m, st)) return rc;
   }
+  if (int rc = plan_join(ctx, plan)) return rc;
   return sync_and_counts(ctx, clouds, n);
 }
 
@@ -364,6 +397,8 @@ int pwn_hip_ctx_create(pwn_hip_ctx** out, int device, int max_rows, int max_cols
 #define HALLOC(ptr, bytes) do { hipError_t e_ = hipHostMalloc((void**)&(ptr), (bytes)); if (e_ != hipSuccess) { std::string m = std::string("hipHostMalloc ") + #ptr + ": " + hipGetErrorString(e_); pwn_hip_ctx_destroy(ctx); return fail(nullptr, PWN_HIP_ERR_ALLOCATION, m); } } while (0)
   if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return fail(nullptr, PWN_HIP_ERR_ALLOCATION, "hipStreamCreate failed"); }
   ctx->stream = ctx->own_stream;
+  (void)hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+  (void)hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming); (void)hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming);
   ALLOC(ctx->depth_ws, B * N * sizeof(float));
   ALLOC(ctx->raw_ws, B * N * sizeof(uint16_t));
   ALLOC(ctx->index_ws, B * N * sizeof(int));
@@ -402,6 +437,9 @@ int pwn_hip_ctx_destroy(pwn_hip_ctx* ctx) {
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+  if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+  if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
+  if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
   delete ctx;
   return PWN_HIP_OK;
 }
@@ -419,6 +457,12 @@ int pwn_hip_ctx_synchronize(pwn_hip_ctx* ctx) {
 int pwn_hip_ctx_set_subbatch(pwn_hip_ctx* ctx, int frames, int pairs) {
   if (!ctx || frames <= 0 || pairs <= 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "bad subbatch");
   ctx->sub_frames = std::min(frames, ctx->max_batch); ctx->sub_pairs = std::min(pairs, ctx->max_batch);
+  return PWN_HIP_OK;
+}
+int pwn_hip_ctx_set_concurrency(pwn_hip_ctx* ctx, int streams) {
+  if (!ctx || streams < 1 || streams > 2) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "streams must be 1 or 2");
+  HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+  ctx->concurrency = streams;
   return PWN_HIP_OK;
 }
 int pwn_hip_set_profiling(pwn_hip_ctx* ctx, int enabled) {
@@ -789,14 +833,15 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
   const AlignParams ap = make_align_params(p);
   const int nb = align_nblocks(N);
   ctx->stages.clear();
-  const int sub = std::max(1, std::min(ctx->sub_pairs, ctx->max_batch));
+  const StreamPlan plan = make_plan(ctx, ctx->sub_pairs, n);
+  const int sub = plan.sub;
   if (int rc = ensure_desc(ctx, n)) return rc;
   HIPCHK(ctx, hipEventRecord(ctx->t0, ctx->stream), PWN_HIP_ERR_LAUNCH);
   // descriptors + initial states of all pairs; workspace slots are reused round-robin across sub-batches
   for (int i = 0; i < n; ++i) {
     const pwn_hip_cloud* r = refs[i]; const pwn_hip_cloud* c = curs[i];
     if (!r || !c) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null cloud in batch");
-    const int slot = i % sub;
+    const int slot = plan.slot0(i / sub) + i % sub;
     PairDesc& pd = ctx->pairs_host[i];
     pd.ref = r->d; pd.cur = c->d;
     pd.zref = ctx->zref_ws + (size_t)slot * ctx->N;
@@ -823,38 +868,42 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
     if (scores) HIPCHK(ctx, hipMemsetAsync(ctx->match_dev, 0, sizeof(MatchAcc) * n, ctx->stream), PWN_HIP_ERR_COPY);
   }
   const unsigned lastRefTag = kZTag0 - (unsigned)std::max(0, p->outer_iterations - 1);
-  for (int base = 0; base < n; base += sub) {
+  if (int rc = plan_fork(ctx, plan)) return rc;
+  for (int base = 0, kk = 0; base < n; base += sub, ++kk) {
     const int m = std::min(sub, n - base);
     const PairDesc* pr = ctx->pairs_dev + base;
+    hipStream_t st = plan.stream(kk);
+    const size_t s0 = (size_t)plan.slot0(kk);
     int maxcap_ref = 0, maxcap_cur = 0;
     for (int i = 0; i < m; ++i) { maxcap_ref = std::max(maxcap_ref, refs[base + i]->d.capacity); maxcap_cur = std::max(maxcap_cur, curs[base + i]->d.capacity); }
     // z-buffers start empty; slots are contiguous
-    HIPCHK(ctx, hipMemsetAsync(ctx->zref_ws, 0xFF, (size_t)m * ctx->N * 8, ctx->stream), PWN_HIP_ERR_COPY);
-    HIPCHK(ctx, hipMemsetAsync(ctx->zcur_ws, 0xFF, (size_t)m * ctx->N * 8, ctx->stream), PWN_HIP_ERR_COPY);
-    { StageTimer t(ctx, "project");
-      hipLaunchKernelGGL(k_project, dim3((maxcap_cur + 255) / 256, m), dim3(256), 0, ctx->stream, pr, ap, 1, kZTag0);
-      hipLaunchKernelGGL(k_resolve_cur, dim3(std::min((N + 255) / 256, 1024), m), dim3(256), 0, ctx->stream, pr, N, kZTag0); }
+    HIPCHK(ctx, hipMemsetAsync(ctx->zref_ws + s0 * ctx->N, 0xFF, (size_t)m * ctx->N * 8, st), PWN_HIP_ERR_COPY);
+    HIPCHK(ctx, hipMemsetAsync(ctx->zcur_ws + s0 * ctx->N, 0xFF, (size_t)m * ctx->N * 8, st), PWN_HIP_ERR_COPY);
+    { StageTimer t(ctx, "project", st);
+      hipLaunchKernelGGL(k_project, dim3((maxcap_cur + 255) / 256, m), dim3(256), 0, st, pr, ap, 1, kZTag0);
+      hipLaunchKernelGGL(k_resolve_cur, dim3(std::min((N + 255) / 256, 1024), m), dim3(256), 0, st, pr, N, kZTag0); }
     for (int i = 0; i < p->outer_iterations; ++i) {
       const unsigned tag = kZTag0 - (unsigned)i;      // epoch of this outer iteration's reference projection
-      { StageTimer t(ctx, "project");
-        hipLaunchKernelGGL(k_project, dim3((maxcap_ref + 255) / 256, m), dim3(256), 0, ctx->stream, pr, ap, 0, tag); }
+      { StageTimer t(ctx, "project", st);
+        hipLaunchKernelGGL(k_project, dim3((maxcap_ref + 255) / 256, m), dim3(256), 0, st, pr, ap, 0, tag); }
       for (int k = 0; k < p->inner_iterations; ++k) {
         const bool lastInner = (k == p->inner_iterations - 1);
-        { StageTimer t(ctx, "corr_linearize");
+        { StageTimer t(ctx, "corr_linearize", st);
           // first inner pass: the linearizer's transform is bitwise the finder's (aligner.cpp:79,84)
-          if (k == 0) hipLaunchKernelGGL(k_corr_linearize<true>, dim3(nb, m), dim3(kAlignBlock), 0, ctx->stream, pr, ap, tag);
-          else hipLaunchKernelGGL(k_corr_linearize<false>, dim3(nb, m), dim3(kAlignBlock), 0, ctx->stream, pr, ap, tag); }
-        { StageTimer t(ctx, "solve");
-          hipLaunchKernelGGL(k_solve_update, dim3(m), dim3(256), 0, ctx->stream, pr, ap, nb, lastInner ? 1 : 0); }
+          if (k == 0) hipLaunchKernelGGL(k_corr_linearize<true>, dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, tag);
+          else hipLaunchKernelGGL(k_corr_linearize<false>, dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, tag); }
+        { StageTimer t(ctx, "solve", st);
+          hipLaunchKernelGGL(k_solve_update, dim3(m), dim3(256), 0, st, pr, ap, nb, lastInner ? 1 : 0); }
       }
     }
     if (scores && p->outer_iterations > 0) {
-      StageTimer t(ctx, "match_score");     // the z-buffers of this sub-batch still hold the finder's last depth images
-      hipLaunchKernelGGL(k_match_score, dim3(std::min((N + 255) / 256, 256), m), dim3(256), 0, ctx->stream, pr, N, lastRefTag, kZTag0, 1000.0f,
+      StageTimer t(ctx, "match_score", st);     // the z-buffers of this sub-batch still hold the finder's last depth images
+      hipLaunchKernelGGL(k_match_score, dim3(std::min((N + 255) / 256, 256), m), dim3(256), 0, st, pr, N, lastRefTag, kZTag0, 1000.0f,
                          match_threshold, ctx->match_dev + base);
     }
     HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
   }
+  if (int rc = plan_join(ctx, plan)) return rc;
   if (n > 0 && scores) HIPCHK(ctx, hipMemcpyAsync(ctx->match_host, ctx->match_dev, sizeof(MatchAcc) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
   if (n > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->state_host, ctx->state_ws, sizeof(PairState) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
