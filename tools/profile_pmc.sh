@@ -3,7 +3,7 @@
 # usage (on the GPU box, from the repo root): bash tools/profile_pmc.sh <outdir> [bench args...]
 set -u
 OUT=${1:-gpurun_out/pmc}; shift || true
-ARGS=${@:---pairs 64 --steps 1 --warmup 1 --no-cpu-baseline --no-latency}
+ARGS=${@:---pairs 128 --steps 1 --warmup 1 --no-cpu-baseline --no-latency --no-profile --streams 1}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
 run() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py $ARGS > "$OUT/$name.json" 2> "$OUT/$name.err"; }
