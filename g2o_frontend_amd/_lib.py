@@ -54,6 +54,11 @@ class MatchResult(C.Structure):
                 ("image_reprojection_distance", C.c_float)]
 
 
+class AlignStatistics(C.Structure):
+    _fields_ = [("mean", C.c_float * 6), ("omega", C.c_float * 36), ("translational_eigen_ratio", C.c_float),
+                ("rotational_eigen_ratio", C.c_float), ("H", C.c_float * 36), ("b", C.c_float * 6), ("error", C.c_float), ("inliers", C.c_int)]
+
+
 # name -> (restype, argtypes); every symbol include/pwn_hip.h declares
 _VP, _I, _F = C.c_void_p, C.c_int, C.c_float
 PROTOTYPES = {
@@ -89,6 +94,8 @@ PROTOTYPES = {
     "pwn_hip_align": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "pwn_hip_align_images": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "pwn_hip_align_batch": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP]),
+    "pwn_hip_align_batch_ex": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _F, _VP, _VP]),
+    "pwn_hip_compute_statistics": (None, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "pwn_hip_match_score": (_I, [_VP, _F, _VP]),
     "pwn_hip_match_batch": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _F, _VP, _VP]),
     "pwn_hip_projector_matrices": (None, [_VP, _VP, _VP, _VP, _VP]),

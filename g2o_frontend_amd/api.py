@@ -15,7 +15,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import AlignerParams, AlignResult, ConverterParams, MatchResult, PwnHipError
+from ._lib import AlignerParams, AlignResult, AlignStatistics, ConverterParams, MatchResult, PwnHipError
 
 
 def _ptr(x):
@@ -399,6 +399,9 @@ class Aligner:
         self._referenceSensorOffset, self._currentSensorOffset = I.copy(), I.copy()
         self._totalTime, self._error, self._inliers = 0.0, 0.0, 0
         self._result = None
+        self._omega = np.zeros((6, 6), np.float32); self._mean = np.zeros(6, np.float32); self._statistics = None
+        self._translationalEigenRatio = self._rotationalEigenRatio = float(np.finfo(np.float32).max)
+        self._rotationalMinEigenRatio = self._translationalMinEigenRatio = 50.0       # aligner.cpp:29-30
 
     @staticmethod
     def _iso(T):
@@ -452,12 +455,33 @@ class Aligner:
                     C=np.array(r.iter_correspondences[:n], np.int32), K=np.array(r.iter_candidates[:n], np.int32),
                     n_reference=r.n_reference, n_current=r.n_current)
 
-    def align(self, images: bool = False):
-        """aligner.cpp:49-125"""
+    def omega(self): return self._omega                                        # aligner.h:314
+    def translationalEigenRatio(self): return self._translationalEigenRatio
+    def rotationalEigenRatio(self): return self._rotationalEigenRatio
+    def setTranslationalMinEigenRatio(self, v): self._translationalMinEigenRatio = float(v)
+    def setRotationalMinEigenRatio(self, v): self._rotationalMinEigenRatio = float(v)
+
+    def solutionValid(self) -> bool:
+        """the eigen-ratio test of aligner.cpp:128-129 (needs align(statistics=True))"""
+        return not (self._rotationalEigenRatio > self._rotationalMinEigenRatio or self._translationalEigenRatio > self._translationalMinEigenRatio)
+
+    def align(self, images: bool = False, statistics: bool = False):
+        """aligner.cpp:49-150; statistics=True also runs _computeStatistics (:127,152-199)"""
         assert self._referenceCloud is not None and self._currentCloud is not None, "Aligner: missing cloud"
         p = self.params()
         r = AlignResult()
-        self.ctx.check(self.ctx._L.pwn_hip_align(self.ctx.h, C.byref(p), self._referenceCloud.h, self._currentCloud.h, C.byref(r)))
+        if statistics:
+            q = AlignStatistics()
+            refs = (C.c_void_p * 1)(self._referenceCloud.h); curs = (C.c_void_p * 1)(self._currentCloud.h)
+            self.ctx.check(self.ctx._L.pwn_hip_align_batch_ex(self.ctx.h, C.byref(p), 1, refs, curs, None, C.byref(r), 0.0, None, C.byref(q)))
+            self._omega = _from_colmajor(q.omega, 6); self._mean = np.array(list(q.mean), np.float32)
+            self._translationalEigenRatio, self._rotationalEigenRatio = q.translational_eigen_ratio, q.rotational_eigen_ratio
+            self._statistics = dict(mean=self._mean, omega=self._omega, translationalEigenRatio=q.translational_eigen_ratio,
+                                    rotationalEigenRatio=q.rotational_eigen_ratio, H=_from_colmajor(q.H, 6), b=np.array(list(q.b), np.float32),
+                                    error=q.error, inliers=q.inliers)
+            self._linearizer._H, self._linearizer._b = self._statistics["H"], self._statistics["b"]
+        else:
+            self.ctx.check(self.ctx._L.pwn_hip_align(self.ctx.h, C.byref(p), self._referenceCloud.h, self._currentCloud.h, C.byref(r)))
         self._result = self._unpack(r)
         self._T, self._error, self._inliers = self._result["T"], r.error, r.inliers
         self._totalTime = r.total_time_ms

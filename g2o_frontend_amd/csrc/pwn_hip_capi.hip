@@ -8,6 +8,7 @@
 // returns PWN_HIP_ERR_NO_DEVICE.
 #include "../../include/pwn_hip.h"
 #include "pwn_kernels.h"
+#include "pwn_stats.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -56,6 +57,7 @@ struct pwn_hip_ctx {
   FrameDesc* frames_host = nullptr; PairDesc* pairs_host = nullptr; RawDesc* raw_host = nullptr; PairState* state_host = nullptr; int* counts_host = nullptr;
   // misc scratch
   MatchAcc* match_dev = nullptr; MatchAcc* match_host = nullptr; int match_cap = 0;
+  SolveOut* stats_dev = nullptr; SolveOut* stats_host = nullptr;
   SolveOut* solve_dev = nullptr; int* counters_dev = nullptr; int2* corr_ws = nullptr; int* scratch_count = nullptr;
   float* io_ws = nullptr;   // N*16 floats staging for cloud up/download
   // images of the last single align
@@ -228,6 +230,11 @@ int ensure_desc(pwn_hip_ctx* ctx, int n) {
   ctx->match_dev = nullptr; ctx->match_host = nullptr;
   HIPCHK(ctx, hipMalloc((void**)&ctx->match_dev, B * sizeof(MatchAcc)), PWN_HIP_ERR_ALLOCATION);
   HIPCHK(ctx, hipHostMalloc((void**)&ctx->match_host, B * sizeof(MatchAcc)), PWN_HIP_ERR_ALLOCATION);
+  if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
+  if (ctx->stats_host) (void)hipHostFree(ctx->stats_host);
+  ctx->stats_dev = nullptr; ctx->stats_host = nullptr;
+  HIPCHK(ctx, hipMalloc((void**)&ctx->stats_dev, B * sizeof(SolveOut)), PWN_HIP_ERR_ALLOCATION);
+  HIPCHK(ctx, hipHostMalloc((void**)&ctx->stats_host, B * sizeof(SolveOut)), PWN_HIP_ERR_ALLOCATION);
   ctx->desc_cap = (int)B;
   return PWN_HIP_OK;
 }
@@ -244,7 +251,8 @@ int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, h
   { StageTimer t(ctx, "integral_cols", st);
     hipLaunchKernelGGL(k_integral_cols, dim3((cp.cols + 255) / 256, kIntegralChannels, n), dim3(256), 0, st, fr, cp.rows, cp.cols); }
   { StageTimer t(ctx, "stats", st);
-    hipLaunchKernelGGL(k_stats, dim3((cp.cols + 255) / 256, cp.rows, n), dim3(256), 0, st, fr, cp); }
+    const unsigned nblk = 8u * (unsigned)((n + 7) / 8) * (unsigned)cp.rows * (unsigned)((cp.cols + 255) / 256);
+    hipLaunchKernelGGL(k_stats, dim3(nblk), dim3(256), 0, st, fr, cp, n); }
   HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
   return PWN_HIP_OK;
 }
@@ -432,6 +440,8 @@ int pwn_hip_ctx_destroy(pwn_hip_ctx* ctx) {
   void* host[] = { ctx->frames_host, ctx->pairs_host, ctx->raw_host, ctx->state_host, ctx->counts_host, ctx->match_host };
   for (void* p : host) if (p) (void)hipHostFree(p);
   if (ctx->match_dev) (void)hipFree(ctx->match_dev);
+  if (ctx->stats_dev) (void)hipFree(ctx->stats_dev);
+  if (ctx->stats_host) (void)hipHostFree(ctx->stats_host);
   collect_stage_times(ctx);
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
@@ -822,7 +832,8 @@ static void finish_match(const MatchAcc& a, pwn_hip_match_result* r) {
   r->image_reprojection_distance = (float)sum / (float)(int)a.nonZeros;          // pwn_matcher_base.cpp:179 (0/0 = NaN like the reference)
 }
 static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* refs, pwn_hip_cloud* const* curs,
-                            const float* guesses, pwn_hip_align_result* results, pwn_hip_match_result* scores, float match_threshold) {
+                            const float* guesses, pwn_hip_align_result* results, pwn_hip_match_result* scores, float match_threshold,
+                            pwn_hip_align_statistics* statistics = nullptr) {
   if (!ctx || !p || !refs || !curs || !results || n < 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if (int rc = check_image(ctx, p->rows, p->cols)) return rc;
   if (p->min_distance < 0.f) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "min_distance must be >= 0");
@@ -890,11 +901,18 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
         const bool lastInner = (k == p->inner_iterations - 1);
         { StageTimer t(ctx, "corr_linearize", st);
           // first inner pass: the linearizer's transform is bitwise the finder's (aligner.cpp:79,84)
-          if (k == 0) hipLaunchKernelGGL(k_corr_linearize<true>, dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, tag);
-          else hipLaunchKernelGGL(k_corr_linearize<false>, dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, tag); }
+          if (k == 0) hipLaunchKernelGGL(k_corr_linearize<true>, dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, tag, 0);
+          else hipLaunchKernelGGL(k_corr_linearize<false>, dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, tag, 0); }
         { StageTimer t(ctx, "solve", st);
           hipLaunchKernelGGL(k_solve_update, dim3(m), dim3(256), 0, st, pr, ap, nb, lastInner ? 1 : 0); }
       }
+    }
+    if (statistics && p->outer_iterations > 0) {
+      // Aligner::_computeStatistics' extra Linearizer::update: the finder's correspondences of the last outer iteration
+      // (tests with that iteration's transform) re-linearized at the final transform (aligner.cpp:165-170)
+      StageTimer t(ctx, "statistics", st);
+      hipLaunchKernelGGL(k_corr_linearize<false>, dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, lastRefTag, 1);
+      hipLaunchKernelGGL(k_reduce_pairs, dim3(m), dim3(256), 0, st, pr, nb, ctx->stats_dev + base);
     }
     if (scores && p->outer_iterations > 0) {
       StageTimer t(ctx, "match_score", st);     // the z-buffers of this sub-batch still hold the finder's last depth images
@@ -905,6 +923,7 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
   }
   if (int rc = plan_join(ctx, plan)) return rc;
   if (n > 0 && scores) HIPCHK(ctx, hipMemcpyAsync(ctx->match_host, ctx->match_dev, sizeof(MatchAcc) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
+  if (n > 0 && statistics) HIPCHK(ctx, hipMemcpyAsync(ctx->stats_host, ctx->stats_dev, sizeof(SolveOut) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
   if (n > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->state_host, ctx->state_ws, sizeof(PairState) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
   for (int i = 0; i < n; ++i) {
@@ -919,6 +938,15 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
     if (st.it > 0) { r.error = st.chi2[st.it - 1]; r.inliers = st.inliers[st.it - 1]; }
     r.n_reference = refs[i]->n_host; r.n_current = curs[i]->n_host;
     if (scores) finish_match(ctx->match_host[i], &scores[i]);
+    if (statistics) {
+      pwn_hip_align_statistics& q = statistics[i];
+      std::memset(&q, 0, sizeof(q));
+      if (p->outer_iterations > 0) {
+        const SolveOut& so = ctx->stats_host[i];
+        std::memcpy(q.H, so.H, sizeof(q.H)); std::memcpy(q.b, so.b, sizeof(q.b)); q.error = so.chi2; q.inliers = so.inliers;
+        compute_statistics(so.H, st.T, q.mean, q.omega, &q.translational_eigen_ratio, &q.rotational_eigen_ratio);
+      }
+    }
   }
   HIPCHK(ctx, hipEventRecord(ctx->t1, ctx->stream), PWN_HIP_ERR_LAUNCH);
   HIPCHK(ctx, hipEventSynchronize(ctx->t1), PWN_HIP_ERR_LAUNCH);
@@ -937,6 +965,14 @@ int pwn_hip_match_batch(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n
                         const float* guesses, float threshold, pwn_hip_align_result* results, pwn_hip_match_result* scores) {
   if (!scores) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null scores");
   return align_batch_impl(ctx, p, n, refs, curs, guesses, results, scores, threshold);
+}
+int pwn_hip_align_batch_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* refs, pwn_hip_cloud* const* curs,
+                           const float* guesses, pwn_hip_align_result* results, float threshold, pwn_hip_match_result* scores,
+                           pwn_hip_align_statistics* statistics) {
+  return align_batch_impl(ctx, p, n, refs, curs, guesses, results, scores, threshold, statistics);
+}
+void pwn_hip_compute_statistics(const float H[36], const float T[16], float mean[6], float omega[36], float* tr, float* rr) {
+  compute_statistics(H, mat4_from(T), mean, omega, tr, rr);
 }
 int pwn_hip_match_score(pwn_hip_ctx* ctx, float threshold, pwn_hip_match_result* out) {
   if (!ctx || !out) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");

@@ -78,6 +78,7 @@ struct ConvertParams {
 struct PairState {
   Mat4 T;          // Aligner::_T
   Mat4 invTcorr;   // _T.inverse() handed to CorrespondenceFinder::compute
+  Mat4 invTcorrPrev; // the one of the last executed outer iteration (the finder's correspondences that _computeStatistics reuses)
   Mat4 invT;       // Linearizer::_T
   Mat4 KRt;        // projector matrix of the next reference projection
   Mat4 KRtCur;     // projector matrix of the current-cloud projection
@@ -356,13 +357,22 @@ __global__ void __launch_bounds__(256) k_integral_cols(const FrameDesc* __restri
 // StatsCalculatorIntegralImage::compute per-pixel loop (pwn_core/statscalculatorintegralimage.cpp:33-80) fused with
 // PointInformationMatrixCalculator / NormalInformationMatrixCalculator::compute (informationmatrixcalculator.cpp:9-58)
 // and Cloud::transformInPlace (cloud.cpp:173-186).  One thread per pixel, lanes along x.
-// grid = (ceil(cols/256), rows, frames), block = 256.
+// XCD-aware 1-D grid: workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an XCD and its 4 MiB L2), so
+// block b works on frame 8*(k / blocksPerFrame) + (b % 8), k = b / 8, walking that frame's rows in order: every frame lives on
+// one XCD and the four corner reads of neighbouring rows (2*radius rows apart, ~1.6 MB of planes) are L2 hits instead of one
+// L2 fill per XCD.  Placement only affects speed.  grid = 8 * ceil(frames/8) * rows * ceil(cols/256), block = 256.
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { v = (v < lo) ? lo : v; v = (v > hi) ? hi : v; return v; }
 
-__global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ frames, ConvertParams cp) {
-  const FrameDesc& f = frames[blockIdx.z];
-  const int r = blockIdx.y;
-  const int c = blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ frames, ConvertParams cp, int nframes) {
+  const int nxb = (cp.cols + 255) / 256;
+  const int perFrame = nxb * cp.rows;
+  const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+  const int frame = (k / perFrame) * 8 + xcd;
+  if (frame >= nframes) return;
+  const int rem = k % perFrame;
+  const FrameDesc& f = frames[frame];
+  const int r = rem / nxb;
+  const int c = (rem % nxb) * 256 + threadIdx.x;
   if (c >= cp.cols) return;
   const int rows = cp.rows, cols = cp.cols;
   const size_t N = (size_t)rows * cols;
@@ -774,11 +784,13 @@ __device__ __forceinline__ void candidate_consume(const PairDesc& pd, const Alig
 #endif
   linearize_term(rp, rn, make_float3(c.cP.x, c.cP.y, c.cP.z), make_float3(c.cN.x, c.cN.y, c.cN.z), oP, oN, ap.maxChi2, ap.robust, acc);
 }
+// usePrevTc: the acceptance tests run with the previous outer iteration's transform (Aligner::_computeStatistics re-linearizes
+// the finder's existing correspondences at the final transform, aligner.cpp:165-170).
 template <bool SAME_T>
-__global__ void __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_corr_linearize(const PairDesc* __restrict__ pairs, AlignParams ap, unsigned tag) {
+__global__ void __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_corr_linearize(const PairDesc* __restrict__ pairs, AlignParams ap, unsigned tag, int usePrevTc) {
   const PairDesc& pd = pairs[blockIdx.y];
   const int N = ap.rows * ap.cols;
-  const Mat4 Tc = uniform_iso(pd.state->invTcorr);
+  const Mat4 Tc = uniform_iso(usePrevTc ? pd.state->invTcorrPrev : pd.state->invTcorr);
   const Mat4 Tl = uniform_iso(pd.state->invT);
   float acc[kAccN];
 #pragma unroll
@@ -948,6 +960,7 @@ __global__ void __launch_bounds__(256) k_solve_update(const PairDesc* __restrict
     set_last_row(T);
     st.T = T;
     const Mat4 Tinv = iso_inverse(T);
+    st.invTcorrPrev = st.invTcorr;
     st.invTcorr = Tinv;
     invT = Tinv;
     Mat4 KRt, iKRt; Mat3 iK;
@@ -956,6 +969,15 @@ __global__ void __launch_bounds__(256) k_solve_update(const PairDesc* __restrict
   }
   set_last_row(invT);
   st.invT = invT;
+}
+// reduction only, one record per pair (Aligner::_computeStatistics' 11th update).  grid = pairs, block = 256
+__global__ void __launch_bounds__(256) k_reduce_pairs(const PairDesc* __restrict__ pairs, int nblocks, SolveOut* __restrict__ out) {
+  __shared__ double sums[kAccN];
+  reduce_partials(pairs[blockIdx.x].partials, nblocks, sums);
+  if (threadIdx.x != 0) return;
+  SolveOut* o = out + blockIdx.x;
+  assemble_Hb(sums, o->H, o->b);
+  o->chi2 = (float)sums[33]; o->inliers = (int)sums[34]; o->ncorr = (int)sums[35]; o->ncand = (int)sums[36];
 }
 // reduction only (pwn_hip_linearize)
 __global__ void __launch_bounds__(256) k_reduce_only(const double* __restrict__ partials, int nblocks, SolveOut* __restrict__ out) {

@@ -109,6 +109,19 @@ typedef struct pwn_hip_match_result {
   float image_reprojection_distance;   /* sum of the differences / non_zeros */
 } pwn_hip_match_result;
 
+/* What Aligner::_computeStatistics leaves behind (aligner.cpp:127,152-199): omega() (aligner.h:314), the eigen-ratio
+ * validity measures compared with rotational/translationalMinEigenRatio (aligner.cpp:128-129), the remapped mean. */
+typedef struct pwn_hip_align_statistics {
+  float mean[6];                       /* (t, q) of the solution as reconstructed from the sigma points */
+  float omega[36];                     /* column-major 6x6 information matrix of the estimate */
+  float translational_eigen_ratio;
+  float rotational_eigen_ratio;
+  float H[36];                         /* Linearizer::H() of the extra update at the final transform (what the statistics start from) */
+  float b[6];
+  float error;                         /* Linearizer::error() / inliers() of that extra update (aligner.cpp:168 overwrites the */
+  int   inliers;                       /* linearizer's values, not the Aligner's cached ones) */
+} pwn_hip_align_statistics;
+
 /* ------------------------------------------------------------------ context ------------------ */
 /* cf. pwn_cuda createContext(AlignerContext**, maxRef, maxCur, rows, cols) (cudaaligner.h:59).
  * max_batch = largest number of frames (convert_batch) / pairs (align_batch) per call. */
@@ -226,6 +239,17 @@ int pwn_hip_match_score(pwn_hip_ctx* ctx, float frame_inlier_depth_threshold, pw
 int pwn_hip_match_batch(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* references,
                         pwn_hip_cloud* const* currents, const float* initial_guesses, float frame_inlier_depth_threshold,
                         pwn_hip_align_result* results, pwn_hip_match_result* scores);
+
+/* Everything Aligner::align() does for n pairs in one call: the Gauss-Newton loop, optionally the matcher's depth-agreement
+ * score (scores != NULL) and optionally Aligner::_computeStatistics (statistics != NULL; aligner.cpp:127,152-199: one more
+ * linearizer update at the final transform on the finder's last correspondences, then the 6x6 covariance / unscented math
+ * on the host).  pwn_hip_align_batch / pwn_hip_match_batch are this call with the optional outputs left NULL. */
+int pwn_hip_align_batch_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* references,
+                           pwn_hip_cloud* const* currents, const float* initial_guesses, pwn_hip_align_result* results,
+                           float frame_inlier_depth_threshold, pwn_hip_match_result* scores, pwn_hip_align_statistics* statistics);
+/* the host-side part alone: H = Linearizer::H() at the final transform, T = Aligner::T() */
+void pwn_hip_compute_statistics(const float H[36], const float T[16], float mean[6], float omega[36],
+                                float* translational_eigen_ratio, float* rotational_eigen_ratio);
 
 /* ------------------------------------------------------------------ helpers ------------------ */
 /* PinholePointProjector::_updateMatrices (pinholepointprojector.cpp:17-31): KRt, iKRt (4x4), iK (3x3) */

@@ -86,6 +86,8 @@ def lib():
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_set_trig_mode.argtypes = [C.c_int]
+        L.orc_compute_statistics.argtypes = [C.c_void_p] * 6
+        L.orc_align_statistics.argtypes = [C.c_void_p] * 9
         L.orc_iso_inverse.argtypes = [C.c_void_p] * 2
         L.orc_iso_mul.argtypes = [C.c_void_p] * 3
         L.orc_match_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 4
@@ -314,6 +316,22 @@ def match_score(ref_depth, cur_depth, threshold=50.0):
     nz, out, inl, dist = C.c_int(0), C.c_int(0), C.c_int(0), C.c_float(0)
     lib().orc_match_score(_p(r), _p(c), r.size, C.c_float(threshold), C.byref(nz), C.byref(out), C.byref(inl), C.byref(dist))
     return dict(image_nonZeros=nz.value, image_outliers=out.value, image_inliers=inl.value, image_reprojectionDistance=dist.value)
+
+
+def compute_statistics(H, T):
+    """aligner.cpp:152-199 on a given linearizer H (row-indexed 6x6) and final transform"""
+    Hc = _f32(np.asarray(H, np.float32).T.reshape(-1)); Tc = _f32(np.asarray(T, np.float32).T.reshape(-1))
+    mean = np.empty(6, np.float32); om = np.empty(36, np.float32); tr, rr = C.c_float(0), C.c_float(0)
+    lib().orc_compute_statistics(_p(Hc), _p(Tc), _p(mean), _p(om), C.byref(tr), C.byref(rr))
+    return dict(mean=mean, omega=om.reshape(6, 6).T.copy(), translationalEigenRatio=tr.value, rotationalEigenRatio=rr.value)
+
+
+def align_statistics(p: AlignerParams, ref: "Cloud", cur: "Cloud", T):
+    """_computeStatistics after the last align() of this process (11th linearizer update + statistics)"""
+    Tc = _f32(np.asarray(T, np.float32).T.reshape(-1))
+    H = np.empty(36, np.float32); mean = np.empty(6, np.float32); om = np.empty(36, np.float32); tr, rr = C.c_float(0), C.c_float(0)
+    lib().orc_align_statistics(C.byref(p), ref.h, cur.h, _p(Tc), _p(H), _p(mean), _p(om), C.byref(tr), C.byref(rr))
+    return dict(H=H.reshape(6, 6).T.copy(), mean=mean, omega=om.reshape(6, 6).T.copy(), translationalEigenRatio=tr.value, rotationalEigenRatio=rr.value)
 
 
 def iso_inverse(T):

@@ -808,6 +808,18 @@ void orc_linearize(const orc_aligner_params* p, const orc_cloud* ref, const orc_
   else                    linearize_impl<float>(p, ref, cur, corr, C, m4_load(T), H, b, chi2, chi2_fp64, inliers);
 }
 
+static std::vector<int> g_last_corr;     /* correspondences of the last outer iteration of the last orc_align (single-threaded test use) */
+static int g_last_C_tmp = 0;
+/* Aligner::_computeStatistics after orc_align: the 11th Linearizer::update at the final transform on the finder's last
+ * correspondences (aligner.cpp:165-170), then orc_compute_statistics. */
+void orc_align_statistics(const orc_aligner_params* p, const orc_cloud* ref, const orc_cloud* cur, const float T[16], float H_out[36],
+                          float mean[6], float omega[36], float* translational_ratio, float* rotational_ratio) {
+  M4 invT = iso_inverse(m4_load(T)); force_last_row(invT);
+  float H[36], b[6], chi2; double chi2d; int inl;
+  orc_linearize(p, ref, cur, g_last_corr.data(), (int)(g_last_corr.size() / 2), invT.m, H, b, &chi2, &chi2d, &inl);
+  if (H_out) std::memcpy(H_out, H, sizeof(H));
+  orc_compute_statistics(H, T, mean, omega, translational_ratio, rotational_ratio);
+}
 void orc_align(const orc_aligner_params* p, const orc_cloud* ref, const orc_cloud* cur, float T_out[16], float* error_out,
                int* inliers_out, orc_iter_trace* trace, int* ref_index_out, float* ref_depth_out, int* cur_index_out,
                float* cur_depth_out) {
@@ -826,6 +838,7 @@ void orc_align(const orc_aligner_params* p, const orc_cloud* ref, const orc_clou
     project_points(pr, p->rows, p->cols, ref->points.data(), (int)ref->points.size(), refIdx.data(), refDepth.data());
     int K = 0;
     const int C = correspondences(p, ref, cur, refIdx.data(), curIdx.data(), iso_inverse(T), corr.data(), &K);
+    g_last_C_tmp = C;
     M4 invT = iso_inverse(T);
     for (int k = 0; k < p->inner_iterations; ++k, ++it) {
       force_last_row(invT);
@@ -849,6 +862,7 @@ void orc_align(const orc_aligner_params* p, const orc_cloud* ref, const orc_clou
     float v[6]; t2v(T, v); T = v2t(v);
     force_last_row(T);
   }
+  g_last_corr.assign(corr.begin(), corr.begin() + 2 * (size_t)g_last_C_tmp);
   std::memcpy(T_out, T.m, sizeof(T.m));
   if (error_out) *error_out = err;
   if (inliers_out) *inliers_out = inl;
@@ -878,6 +892,109 @@ void orc_match_score(const float* ref_depth, const float* cur_depth, int n, floa
   }
   *non_zeros = nz; *inliers = inl; *outliers = nz - inl;        /* :180-182 */
   *reprojection_distance = sum / nz;                            /* :179 */
+}
+
+/* ------------------------------------------------ Aligner::_computeStatistics (aligner.cpp:152-199) ------------ */
+namespace {
+/* Symmetric eigen-decomposition by cyclic Jacobi rotations (float).  Stands in for Eigen's JacobiSVD on the symmetric
+ * positive (semi)definite matrices of this function: singular values = eigenvalues, U = V = eigenvectors. */
+void jacobi_sym(int n, std::vector<float>& A, std::vector<float>& V, std::vector<float>& ev) {
+  V.assign(n * n, 0.f); for (int i = 0; i < n; ++i) V[i + n * i] = 1.f;
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    float off = 0.f;
+    for (int p = 0; p < n; ++p) for (int q = p + 1; q < n; ++q) off += A[p + n * q] * A[p + n * q];
+    if (off < 1e-30f) break;
+    for (int p = 0; p < n; ++p)
+      for (int q = p + 1; q < n; ++q) {
+        const float apq = A[p + n * q];
+        if (std::fabs(apq) < 1e-30f) continue;
+        const float theta = (A[q + n * q] - A[p + n * p]) / (2.f * apq);
+        const float t = (theta >= 0.f ? 1.f : -1.f) / (std::fabs(theta) + std::sqrt(theta * theta + 1.f));
+        const float c = 1.f / std::sqrt(t * t + 1.f), sn = t * c;
+        for (int k = 0; k < n; ++k) { const float akp = A[k + n * p], akq = A[k + n * q]; A[k + n * p] = c * akp - sn * akq; A[k + n * q] = sn * akp + c * akq; }
+        for (int k = 0; k < n; ++k) { const float apk = A[p + n * k], aqk = A[q + n * k]; A[p + n * k] = c * apk - sn * aqk; A[q + n * k] = sn * apk + c * aqk; }
+        for (int k = 0; k < n; ++k) { const float vkp = V[k + n * p], vkq = V[k + n * q]; V[k + n * p] = c * vkp - sn * vkq; V[k + n * q] = sn * vkp + c * vkq; }
+      }
+  }
+  ev.resize(n); for (int i = 0; i < n; ++i) ev[i] = A[i + n * i];
+}
+/* general inverse by Gauss-Jordan with partial pivoting (Eigen Matrix6f::inverse() = PartialPivLU) */
+bool inverse_n(int n, const float* Ain, float* out) {
+  std::vector<float> a(Ain, Ain + n * n), b(n * n, 0.f);
+  for (int i = 0; i < n; ++i) b[i + n * i] = 1.f;
+  for (int c = 0; c < n; ++c) {
+    int piv = c; float best = std::fabs(a[c + n * c]);
+    for (int r = c + 1; r < n; ++r) if (std::fabs(a[r + n * c]) > best) { best = std::fabs(a[r + n * c]); piv = r; }
+    if (best == 0.f) return false;
+    if (piv != c) for (int k = 0; k < n; ++k) { std::swap(a[c + n * k], a[piv + n * k]); std::swap(b[c + n * k], b[piv + n * k]); }
+    const float d = a[c + n * c];
+    for (int k = 0; k < n; ++k) { a[c + n * k] /= d; b[c + n * k] /= d; }
+    for (int r = 0; r < n; ++r) if (r != c) {
+      const float f = a[r + n * c];
+      if (f != 0.f) for (int k = 0; k < n; ++k) { a[r + n * k] -= f * a[c + n * k]; b[r + n * k] -= f * b[c + n * k]; }
+    }
+  }
+  std::memcpy(out, b.data(), sizeof(float) * n * n);
+  return true;
+}
+}  // namespace
+
+/* H: the linearizer's 6x6 at the final transform (no damping); T: Aligner::_T.  Outputs as aligner.cpp:152-199. */
+void orc_compute_statistics(const float Hin[36], const float T[16], float mean[6], float omega[36], float* translational_ratio, float* rotational_ratio) {
+  const int n = 6;
+  std::vector<float> H(Hin, Hin + 36), V, ev;
+  for (int i = 0; i < n; ++i) H[i + n * i] += 1.0f;                                   /* :169 H += linearizer.H + I */
+  std::vector<float> A = H;
+  jacobi_sym(n, A, V, ev);                                                            /* :172 JacobiSVD */
+  float smax = 0.f; for (float v : ev) smax = std::max(smax, std::fabs(v));
+  std::vector<float> sigma(36, 0.f);                                                  /* :173 svd.solve(I): pseudo-inverse */
+  for (int k = 0; k < n; ++k) {
+    if (std::fabs(ev[k]) <= FLT_EPSILON * n * smax) continue;
+    const float inv = 1.0f / ev[k];
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) sigma[i + n * j] += V[i + n * k] * inv * V[j + n * k];
+  }
+  /* unscented.h:23-50 sampleUnscented(mean = 0, covariance = sigma) */
+  const double alpha = 1e-3, beta = 2., lambda = alpha * alpha * n;
+  const double wi = 1. / (2. * (n + lambda));
+  std::vector<float> L(36, 0.f), C(36);
+  for (int k = 0; k < 36; ++k) C[k] = sigma[k] * (float)(n + lambda);                 /* covariance*(dim+lambda), float matrix */
+  for (int j = 0; j < n; ++j) {                                                       /* LLT */
+    float d = C[j + n * j];
+    for (int k = 0; k < j; ++k) d -= L[j + n * k] * L[j + n * k];
+    d = std::sqrt(d);
+    L[j + n * j] = d;
+    for (int i = j + 1; i < n; ++i) { float v = C[i + n * j]; for (int k = 0; k < j; ++k) v -= L[i + n * k] * L[j + n * k]; L[i + n * j] = v / d; }
+  }
+  struct SP { float s[6]; double wi, wp; };
+  std::vector<SP> sp(2 * n + 1);
+  for (int k = 0; k < 6; ++k) sp[0].s[k] = 0.f;
+  sp[0].wi = lambda / (n + lambda); sp[0].wp = lambda / (n + lambda) + (1. - alpha * alpha + beta);
+  for (int i = 0, k = 1; i < n; ++i) {
+    for (int r = 0; r < n; ++r) { sp[k].s[r] = L[r + n * i]; sp[k + 1].s[r] = -L[r + n * i]; }
+    sp[k].wi = sp[k].wp = wi; sp[k + 1].wi = sp[k + 1].wp = wi; k += 2;
+  }
+  /* :178-185 remap: p = t2v(dT * v2t(p).inverse()) */
+  const M4 dT = m4_load(T);
+  for (auto& p : sp) { const M4 X = iso_mul(dT, iso_inverse(v2t(p.s))); t2v(X, p.s); }
+  /* unscented.h:52-65 reconstructGaussian */
+  float m[6] = {0, 0, 0, 0, 0, 0}; std::vector<float> cov(36, 0.f);
+  for (auto& p : sp) for (int r = 0; r < n; ++r) m[r] += (float)p.wi * p.s[r];
+  for (auto& p : sp) { float dlt[6]; for (int r = 0; r < n; ++r) dlt[r] = p.s[r] - m[r];
+    for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) cov[i + n * j] += (float)p.wp * (dlt[i] * dlt[j]); }
+  std::memcpy(mean, m, sizeof(m));
+  if (!inverse_n(n, cov.data(), omega)) for (int k = 0; k < 36; ++k) omega[k] = 0.f;  /* :190 */
+  /* :193-198 singular values of the two 3x3 diagonal blocks */
+  for (int blk = 0; blk < 2; ++blk) {
+    std::vector<float> B(9), Vb, eb;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) B[i + 3 * j] = omega[(i + 3 * blk) + n * (j + 3 * blk)];
+    /* singular values of a general 3x3 = sqrt(eig(B^T B)) */
+    std::vector<float> BtB(9, 0.f);
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) BtB[i + 3 * j] += B[k + 3 * i] * B[k + 3 * j];
+    jacobi_sym(3, BtB, Vb, eb);
+    float s0 = 0.f, s2 = FLT_MAX;
+    for (float v : eb) { const float sv = std::sqrt(std::max(v, 0.f)); s0 = std::max(s0, sv); s2 = std::min(s2, sv); }
+    (blk == 0 ? *translational_ratio : *rotational_ratio) = s0 / s2;
+  }
 }
 
 void orc_iso_inverse(const float T[16], float out[16]) { const M4 r = iso_inverse(m4_load(T)); std::memcpy(out, r.m, sizeof(r.m)); }

@@ -142,6 +142,11 @@ void orc_align(const orc_aligner_params* p, const orc_cloud* ref, const orc_clou
 void orc_match_score(const float* ref_depth, const float* cur_depth, int n, float threshold, int* non_zeros, int* outliers,
                      int* inliers, float* reprojection_distance);
 
+/* Aligner::_computeStatistics (aligner.cpp:152-199): H = linearizer H at the final transform, T = Aligner::_T */
+void orc_compute_statistics(const float H[36], const float T[16], float mean[6], float omega[36], float* translational_ratio, float* rotational_ratio);
+/* the same after the last orc_align (runs the 11th linearizer update on the finder's last correspondences) */
+void orc_align_statistics(const orc_aligner_params* p, const orc_cloud* ref, const orc_cloud* cur, const float T[16], float H_out[36],
+                          float mean[6], float omega[36], float* translational_ratio, float* rotational_ratio);
 /* Isometry3f::inverse / product (used by the tracker harness of the tests) */
 void orc_iso_inverse(const float T[16], float out[16]);
 void orc_iso_mul(const float A[16], const float B[16], float out[16]);
