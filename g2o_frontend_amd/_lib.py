@@ -59,6 +59,10 @@ class AlignStatistics(C.Structure):
                 ("rotational_eigen_ratio", C.c_float), ("H", C.c_float * 36), ("b", C.c_float * 6), ("error", C.c_float), ("inliers", C.c_int)]
 
 
+class Prior(C.Structure):
+    _fields_ = [("kind", C.c_int), ("mean", C.c_float * 16), ("reference_transform", C.c_float * 16), ("information", C.c_float * 36)]
+
+
 # name -> (restype, argtypes); every symbol include/pwn_hip.h declares
 _VP, _I, _F = C.c_void_p, C.c_int, C.c_float
 PROTOTYPES = {
@@ -94,6 +98,7 @@ PROTOTYPES = {
     "pwn_hip_align": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "pwn_hip_align_images": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "pwn_hip_align_batch": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP]),
+    "pwn_hip_align_with_priors": (_I, [_VP, _VP, _VP, _VP, _I, _VP, _VP]),
     "pwn_hip_align_batch_ex": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _F, _VP, _VP]),
     "pwn_hip_compute_statistics": (None, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "pwn_hip_match_score": (_I, [_VP, _F, _VP]),

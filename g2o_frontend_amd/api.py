@@ -15,7 +15,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from ._lib import AlignerParams, AlignResult, AlignStatistics, ConverterParams, MatchResult, PwnHipError
+from ._lib import AlignerParams, AlignResult, AlignStatistics, ConverterParams, MatchResult, Prior, PwnHipError
 
 
 def _ptr(x):
@@ -399,6 +399,7 @@ class Aligner:
         self._referenceSensorOffset, self._currentSensorOffset = I.copy(), I.copy()
         self._totalTime, self._error, self._inliers = 0.0, 0.0, 0
         self._result = None
+        self._priors = []
         self._omega = np.zeros((6, 6), np.float32); self._mean = np.zeros(6, np.float32); self._statistics = None
         self._translationalEigenRatio = self._rotationalEigenRatio = float(np.finfo(np.float32).max)
         self._rotationalMinEigenRatio = self._translationalMinEigenRatio = 50.0       # aligner.cpp:29-30
@@ -413,8 +414,8 @@ class Aligner:
     def projector(self): return self._projector
     def linearizer(self): return self._linearizer
     def correspondenceFinder(self): return self._correspondenceFinder
-    def setReferenceCloud(self, c): self._referenceCloud = c
-    def setCurrentCloud(self, c): self._currentCloud = c
+    def setReferenceCloud(self, c): self._referenceCloud = c; self.clearPriors()     # aligner.h:60-63 (setting a cloud clears the priors)
+    def setCurrentCloud(self, c): self._currentCloud = c; self.clearPriors()         # aligner.h:77-80
     def setOuterIterations(self, n): self._outerIterations = int(n)
     def setInnerIterations(self, n): self._innerIterations = int(n)
     def setInitialGuess(self, T): self._initialGuess = self._iso(T)
@@ -455,6 +456,16 @@ class Aligner:
                     C=np.array(r.iter_correspondences[:n], np.int32), K=np.array(r.iter_candidates[:n], np.int32),
                     n_reference=r.n_reference, n_current=r.n_current)
 
+    def addRelativePrior(self, mean, informationMatrix):
+        """aligner.cpp:34-36"""
+        self._priors.append((0, np.asarray(mean, np.float32).copy(), np.eye(4, dtype=np.float32), np.asarray(informationMatrix, np.float32).copy()))
+
+    def addAbsolutePrior(self, referenceTransform, mean, informationMatrix):
+        """aligner.cpp:38-40"""
+        self._priors.append((1, np.asarray(mean, np.float32).copy(), np.asarray(referenceTransform, np.float32).copy(), np.asarray(informationMatrix, np.float32).copy()))
+
+    def clearPriors(self): self._priors = []                                    # aligner.cpp:42-47
+
     def omega(self): return self._omega                                        # aligner.h:314
     def translationalEigenRatio(self): return self._translationalEigenRatio
     def rotationalEigenRatio(self): return self._rotationalEigenRatio
@@ -480,6 +491,11 @@ class Aligner:
                                     rotationalEigenRatio=q.rotational_eigen_ratio, H=_from_colmajor(q.H, 6), b=np.array(list(q.b), np.float32),
                                     error=q.error, inliers=q.inliers)
             self._linearizer._H, self._linearizer._b = self._statistics["H"], self._statistics["b"]
+        elif self._priors:
+            arr = (Prior * len(self._priors))()
+            for a, (kind, mean, reft, info) in zip(arr, self._priors):
+                a.kind = kind; _set(a.mean, mean, 4); _set(a.reference_transform, reft, 4); _set(a.information, info, 6)
+            self.ctx.check(self.ctx._L.pwn_hip_align_with_priors(self.ctx.h, C.byref(p), self._referenceCloud.h, self._currentCloud.h, len(arr), arr, C.byref(r)))
         else:
             self.ctx.check(self.ctx._L.pwn_hip_align(self.ctx.h, C.byref(p), self._referenceCloud.h, self._currentCloud.h, C.byref(r)))
         self._result = self._unpack(r)

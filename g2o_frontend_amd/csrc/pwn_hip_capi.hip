@@ -966,6 +966,85 @@ int pwn_hip_match_batch(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n
   if (!scores) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null scores");
   return align_batch_impl(ctx, p, n, refs, curs, guesses, results, scores, threshold);
 }
+int pwn_hip_align_with_priors(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, const pwn_hip_cloud* ref, const pwn_hip_cloud* cur, int n_priors,
+                              const pwn_hip_prior* priors, pwn_hip_align_result* result) {
+  if (n_priors <= 0) return pwn_hip_align(ctx, p, ref, cur, result);
+  if (!ctx || !p || !ref || !cur || !priors || !result) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (int rc = check_image(ctx, p->rows, p->cols)) return rc;
+  if (p->min_distance < 0.f) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "min_distance must be >= 0");
+  const int nit = p->outer_iterations * p->inner_iterations;
+  if (p->outer_iterations < 0 || p->inner_iterations < 0 || nit > PWN_HIP_MAX_ITERATIONS)
+    return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "outer*inner iterations exceeds PWN_HIP_MAX_ITERATIONS");
+  std::vector<PriorHost> pr(n_priors);
+  for (int i = 0; i < n_priors; ++i) {
+    pr[i].kind = priors[i].kind; pr[i].mean = mat4_from(priors[i].mean);
+    pr[i].invReference = priors[i].kind == 1 ? iso_inverse(mat4_from(priors[i].reference_transform)) : mat4_identity();
+    std::memcpy(pr[i].information, priors[i].information, sizeof(pr[i].information));
+  }
+  const int N = p->rows * p->cols;
+  const AlignParams ap = make_align_params(p);
+  const int nb = align_nblocks(N);
+  hipStream_t st = ctx->stream;
+  PairDesc& pd = ctx->pairs_host[0];
+  pd.ref = ref->d; pd.cur = cur->d;
+  pd.zref = ctx->zref_ws; pd.zcur = ctx->zcur_ws; pd.curidx = ctx->curidx_ws; pd.partials = ctx->partials_ws; pd.state = ctx->state_ws;
+  PairState& hs = ctx->state_host[0];
+  std::memset(&hs, 0, sizeof(hs));
+  Mat4 T = mat4_from(p->initial_guess); set_last_row(T);
+  Mat4 iKRt; Mat3 iK;
+  projector_matrices(ap.K, mat4_from(p->current_sensor_offset), hs.KRtCur, iKRt, iK);
+  HIPCHK(ctx, hipEventRecord(ctx->t0, st), PWN_HIP_ERR_LAUNCH);
+  HIPCHK(ctx, hipMemcpyAsync(ctx->pairs_dev, ctx->pairs_host, sizeof(PairDesc), hipMemcpyHostToDevice, st), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipMemcpyAsync(ctx->state_ws, &hs, sizeof(PairState), hipMemcpyHostToDevice, st), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipMemsetAsync(ctx->zref_ws, 0xFF, (size_t)ctx->N * 8, st), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipMemsetAsync(ctx->zcur_ws, 0xFF, (size_t)ctx->N * 8, st), PWN_HIP_ERR_COPY);
+  hipLaunchKernelGGL(k_project, dim3((cur->d.capacity + 255) / 256, 1), dim3(256), 0, st, ctx->pairs_dev, ap, 1, kZTag0);
+  hipLaunchKernelGGL(k_resolve_cur, dim3(std::min((N + 255) / 256, 1024), 1), dim3(256), 0, st, ctx->pairs_dev, N, kZTag0);
+  std::memset(result, 0, sizeof(*result));
+  int it = 0;
+  for (int i = 0; i < p->outer_iterations; ++i) {
+    const unsigned tag = kZTag0 - (unsigned)i;
+    set_last_row(T);                                                                 // aligner.cpp:72
+    hs.T = T; hs.invTcorr = iso_inverse(T);
+    projector_matrices(ap.K, iso_mul(T, ap.refOffset), hs.KRt, iKRt, iK);            // :73
+    Mat4 invT = iso_inverse(T);                                                      // :84
+    for (int k = 0; k < p->inner_iterations; ++k, ++it) {
+      set_last_row(invT);                                                            // :86
+      hs.invT = invT;
+      HIPCHK(ctx, hipMemcpyAsync(ctx->state_ws, &hs, sizeof(PairState), hipMemcpyHostToDevice, st), PWN_HIP_ERR_COPY);
+      if (k == 0) hipLaunchKernelGGL(k_project, dim3((ref->d.capacity + 255) / 256, 1), dim3(256), 0, st, ctx->pairs_dev, ap, 0, tag);
+      if (k == 0) hipLaunchKernelGGL(k_corr_linearize<true>, dim3(nb, 1), dim3(kAlignBlock), 0, st, ctx->pairs_dev, ap, tag, 0);
+      else hipLaunchKernelGGL(k_corr_linearize<false>, dim3(nb, 1), dim3(kAlignBlock), 0, st, ctx->pairs_dev, ap, tag, 0);
+      hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, st, ctx->pairs_dev, nb, ctx->stats_dev);
+      HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
+      HIPCHK(ctx, hipMemcpyAsync(ctx->stats_host, ctx->stats_dev, sizeof(SolveOut), hipMemcpyDeviceToHost, st), PWN_HIP_ERR_COPY);
+      HIPCHK(ctx, hipStreamSynchronize(st), PWN_HIP_ERR_LAUNCH);
+      const SolveOut& so = ctx->stats_host[0];
+      result->chi2[it] = so.chi2; result->iter_inliers[it] = so.inliers; result->iter_correspondences[it] = so.ncorr; result->iter_candidates[it] = so.ncand;
+      float H[36], b[6];
+      std::memcpy(H, so.H, sizeof(H)); std::memcpy(b, so.b, sizeof(b));
+      for (int d = 0; d < 6; ++d) H[d + 6 * d] = H[d + 6 * d] + 1.0f;                // :92
+      for (int d = 0; d < 6; ++d) H[d + 6 * d] = H[d + 6 * d] + 1000.0f;             // :94
+      for (int j = 0; j < n_priors; ++j) prior_accumulate(pr[j], invT, H, b);        // :97-108
+      float nbv[6], dx[6];
+      for (int d = 0; d < 6; ++d) nbv[d] = -b[d];
+      ldlt_solve6(H, nbv, dx);                                                       // :110
+      invT = iso_mul(v2t(dx), invT);                                                 // :111-112
+    }
+    T = iso_inverse(invT);                                                           // :115-117
+    float v[6]; t2v(T, v); T = v2t(v); set_last_row(T);
+  }
+  HIPCHK(ctx, hipEventRecord(ctx->t1, st), PWN_HIP_ERR_LAUNCH);
+  HIPCHK(ctx, hipEventSynchronize(ctx->t1), PWN_HIP_ERR_LAUNCH);
+  float ms = 0.f; (void)hipEventElapsedTime(&ms, ctx->t0, ctx->t1);
+  std::memcpy(result->T, T.m, sizeof(result->T));
+  result->iterations = it; result->total_time_ms = ms;
+  if (it > 0) { result->error = result->chi2[it - 1]; result->inliers = result->iter_inliers[it - 1]; }
+  result->n_reference = ref->n_host; result->n_current = cur->n_host;
+  ctx->img_rows = p->rows; ctx->img_cols = p->cols; ctx->img_valid = true;
+  ctx->img_ref_tag = kZTag0 - (unsigned)std::max(0, p->outer_iterations - 1);
+  return PWN_HIP_OK;
+}
 int pwn_hip_align_batch_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* refs, pwn_hip_cloud* const* curs,
                            const float* guesses, pwn_hip_align_result* results, float threshold, pwn_hip_match_result* scores,
                            pwn_hip_align_statistics* statistics) {

@@ -114,4 +114,40 @@ inline void compute_statistics(const float Hin[36], const Mat4& T, float mean[6]
   }
 }
 
+// ---- SE(3) priors (reference pwn_core/se3_prior.{h,cpp}, consumed by aligner.cpp:96-108) ---------------------------
+struct PriorHost {
+  int kind;            // 0: SE3RelativePrior (error = t2v(invT * mean)), 1: SE3AbsolutePrior (error = t2v(invT * ref^-1 * mean))
+  Mat4 mean;           // _priorMean
+  Mat4 invReference;   // _inverseReferenceTransform (identity for relative priors)
+  float information[36];
+};
+inline void prior_error(const PriorHost& pr, const Mat4& mean, const Mat4& invT, float e[6]) {      // se3_prior.cpp:58-60,69-71
+  const Mat4 X = pr.kind == 0 ? iso_mul(invT, mean) : iso_mul(iso_mul(invT, pr.invReference), mean);
+  t2v(X, e);
+}
+inline void mat6_mul(const float* A, const float* B, float* R) {      // column-major, left-to-right inner products
+  for (int j = 0; j < 6; ++j) for (int i = 0; i < 6; ++i) { float s = A[i] * B[6 * j]; for (int k = 1; k < 6; ++k) s = s + A[i + 6 * k] * B[k + 6 * j]; R[i + 6 * j] = s; }
+}
+inline void mat6_transpose(const float* A, float* R) { for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) R[i + 6 * j] = A[j + 6 * i]; }
+// Adds J^T * Omega' * J to H and J^T * Omega' * e to b (aligner.cpp:99-107) with the numeric Jacobians of se3_prior.cpp:8-52.
+inline void prior_accumulate(const PriorHost& pr, const Mat4& invT, float H[36], float b[6]) {
+  const float epsilon = 1e-3f, iEpsilon = 0.5f / epsilon;
+  float e[6]; prior_error(pr, pr.mean, invT, e);
+  float J[36], Jz[36];
+  for (int i = 0; i < 6; ++i) {
+    float up[6] = {0, 0, 0, 0, 0, 0}, dn[6] = {0, 0, 0, 0, 0, 0}, eu[6], ed[6];
+    up[i] = epsilon; dn[i] = -epsilon;
+    prior_error(pr, pr.mean, iso_mul(v2t(up), invT), eu); prior_error(pr, pr.mean, iso_mul(v2t(dn), invT), ed);        // jacobian
+    for (int r = 0; r < 6; ++r) J[r + 6 * i] = iEpsilon * (eu[r] - ed[r]);
+    prior_error(pr, iso_mul(pr.mean, v2t(up)), invT, eu); prior_error(pr, iso_mul(pr.mean, v2t(dn)), invT, ed);        // jacobianZ
+    for (int r = 0; r < 6; ++r) Jz[r + 6 * i] = iEpsilon * (eu[r] - ed[r]);
+  }
+  float iJz[36], iJzT[36], t1[36], Om[36], Jt[36], t2[36], Hp[36];
+  if (!gauss_jordan_inverse(6, Jz, iJz)) return;
+  mat6_transpose(iJz, iJzT); mat6_mul(iJzT, pr.information, t1); mat6_mul(t1, iJz, Om);                                 // errorInformation
+  mat6_transpose(J, Jt); mat6_mul(Jt, Om, t2); mat6_mul(t2, J, Hp);
+  for (int i = 0; i < 36; ++i) H[i] = H[i] + Hp[i];
+  for (int i = 0; i < 6; ++i) { float sacc = t2[i] * e[0]; for (int k = 1; k < 6; ++k) sacc = sacc + t2[i + 6 * k] * e[k]; b[i] = b[i] + sacc; }
+}
+
 }  // namespace pwnhip

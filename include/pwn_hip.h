@@ -122,6 +122,14 @@ typedef struct pwn_hip_align_statistics {
   int   inliers;                       /* linearizer's values, not the Aligner's cached ones) */
 } pwn_hip_align_statistics;
 
+/* Aligner::addRelativePrior / addAbsolutePrior (aligner.h:342-361, se3_prior.h) */
+typedef struct pwn_hip_prior {
+  int   kind;                     /* 0 = SE3RelativePrior, 1 = SE3AbsolutePrior */
+  float mean[16];                 /* prior mean (column-major isometry) */
+  float reference_transform[16];  /* SE3AbsolutePrior::referenceTransform; ignored for relative priors */
+  float information[36];          /* column-major 6x6 */
+} pwn_hip_prior;
+
 /* ------------------------------------------------------------------ context ------------------ */
 /* cf. pwn_cuda createContext(AlignerContext**, maxRef, maxCur, rows, cols) (cudaaligner.h:59).
  * max_batch = largest number of frames (convert_batch) / pairs (align_batch) per call. */
@@ -247,6 +255,12 @@ int pwn_hip_match_batch(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n
 int pwn_hip_align_batch_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* references,
                            pwn_hip_cloud* const* currents, const float* initial_guesses, pwn_hip_align_result* results,
                            float frame_inlier_depth_threshold, pwn_hip_match_result* scores, pwn_hip_align_statistics* statistics);
+/* Aligner::align with priors (aligner.cpp:96-108).  The prior terms (numeric Jacobians, se3_prior.cpp:8-52) are 6x6 host math
+ * that changes the normal equations of every iteration, so this entry point keeps the reference's host-driven loop: per
+ * iteration the GPU projects, finds correspondences and reduces H, b; the host adds damping + priors, solves and updates.
+ * n_priors = 0 is the device-resident loop of pwn_hip_align. */
+int pwn_hip_align_with_priors(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, const pwn_hip_cloud* reference,
+                              const pwn_hip_cloud* current, int n_priors, const pwn_hip_prior* priors, pwn_hip_align_result* result);
 /* the host-side part alone: H = Linearizer::H() at the final transform, T = Aligner::T() */
 void pwn_hip_compute_statistics(const float H[36], const float T[16], float mean[6], float omega[36],
                                 float* translational_eigen_ratio, float* rotational_eigen_ratio);

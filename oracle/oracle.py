@@ -86,6 +86,7 @@ def lib():
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_set_trig_mode.argtypes = [C.c_int]
+        L.orc_add_prior.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_compute_statistics.argtypes = [C.c_void_p] * 6
         L.orc_align_statistics.argtypes = [C.c_void_p] * 9
         L.orc_iso_inverse.argtypes = [C.c_void_p] * 2
@@ -316,6 +317,17 @@ def match_score(ref_depth, cur_depth, threshold=50.0):
     nz, out, inl, dist = C.c_int(0), C.c_int(0), C.c_int(0), C.c_float(0)
     lib().orc_match_score(_p(r), _p(c), r.size, C.c_float(threshold), C.byref(nz), C.byref(out), C.byref(inl), C.byref(dist))
     return dict(image_nonZeros=nz.value, image_outliers=out.value, image_inliers=inl.value, image_reprojectionDistance=dist.value)
+
+
+def clear_priors():
+    lib().orc_clear_priors()
+
+
+def add_prior(kind, mean, information, reference_transform=None):
+    m = _f32(np.asarray(mean, np.float32).T.reshape(-1))
+    r = _f32(np.asarray(np.eye(4) if reference_transform is None else reference_transform, np.float32).T.reshape(-1))
+    i = _f32(np.asarray(information, np.float32).T.reshape(-1))
+    lib().orc_add_prior(int(kind), _p(m), _p(r), _p(i))
 
 
 def compute_statistics(H, T):

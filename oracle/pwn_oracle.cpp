@@ -808,6 +808,45 @@ void orc_linearize(const orc_aligner_params* p, const orc_cloud* ref, const orc_
   else                    linearize_impl<float>(p, ref, cur, corr, C, m4_load(T), H, b, chi2, chi2_fp64, inliers);
 }
 
+/* --------------------------------------------- se3_prior.{h,cpp} + aligner.cpp:96-108 -------------------------------- */
+namespace {
+bool inverse_n(int n, const float* Ain, float* out);      /* defined with the statistics helpers below */
+struct Prior { int kind; M4 mean; M4 invRef; float info[36]; };
+std::vector<Prior> g_priors;      /* priors of the next orc_align calls (Aligner::addRelativePrior / addAbsolutePrior) */
+void prior_error(const Prior& pr, const M4& mean, const M4& invT, float e[6]) {                 /* se3_prior.cpp:58-60, 69-71 */
+  const M4 X = pr.kind == 0 ? iso_mul(invT, mean) : iso_mul(iso_mul(invT, pr.invRef), mean);
+  t2v(X, e);
+}
+void m6_mul(const float* A, const float* B, float* R) {
+  for (int j = 0; j < 6; ++j) for (int i = 0; i < 6; ++i) { float s = A[i] * B[6 * j]; for (int k = 1; k < 6; ++k) s = s + A[i + 6 * k] * B[k + 6 * j]; R[i + 6 * j] = s; }
+}
+void m6_t(const float* A, float* R) { for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) R[i + 6 * j] = A[j + 6 * i]; }
+void prior_add(const Prior& pr, const M4& invT, float H[36], float b[6]) {
+  const float epsilon = 1e-3f, iEpsilon = 0.5f / epsilon;                                       /* se3_prior.cpp:10-11 */
+  float e[6]; prior_error(pr, pr.mean, invT, e);
+  float J[36], Jz[36];
+  for (int i = 0; i < 6; ++i) {
+    float up[6] = {0,0,0,0,0,0}, dn[6] = {0,0,0,0,0,0}, eu[6], ed[6];
+    up[i] = epsilon; dn[i] = -epsilon;
+    prior_error(pr, pr.mean, iso_mul(v2t(up), invT), eu); prior_error(pr, pr.mean, iso_mul(v2t(dn), invT), ed);          /* :18 */
+    for (int r = 0; r < 6; ++r) J[r + 6 * i] = iEpsilon * (eu[r] - ed[r]);
+    prior_error(pr, iso_mul(pr.mean, v2t(up)), invT, eu); prior_error(pr, iso_mul(pr.mean, v2t(dn)), invT, ed);          /* :34-40 */
+    for (int r = 0; r < 6; ++r) Jz[r + 6 * i] = iEpsilon * (eu[r] - ed[r]);
+  }
+  float iJz[36], iJzT[36], t1[36], Om[36], Jt[36], t2[36], Hp[36];
+  if (!inverse_n(6, Jz, iJz)) return;                                                           /* :50 */
+  m6_t(iJz, iJzT); m6_mul(iJzT, pr.info, t1); m6_mul(t1, iJz, Om);                              /* :51 */
+  m6_t(J, Jt); m6_mul(Jt, Om, t2); m6_mul(t2, J, Hp);                                           /* aligner.cpp:103 */
+  for (int i = 0; i < 36; ++i) H[i] = H[i] + Hp[i];                                             /* :106 */
+  for (int i = 0; i < 6; ++i) { float sacc = t2[i] * e[0]; for (int k = 1; k < 6; ++k) sacc = sacc + t2[i + 6 * k] * e[k]; b[i] = b[i] + sacc; }   /* :104,107 */
+}
+}  // namespace
+void orc_clear_priors(void) { g_priors.clear(); }
+void orc_add_prior(int kind, const float mean[16], const float reference_transform[16], const float information[36]) {
+  Prior p; p.kind = kind; p.mean = m4_load(mean); p.invRef = kind == 1 ? iso_inverse(m4_load(reference_transform)) : m4_identity();
+  std::memcpy(p.info, information, sizeof(p.info)); g_priors.push_back(p);
+}
+
 static std::vector<int> g_last_corr;     /* correspondences of the last outer iteration of the last orc_align (single-threaded test use) */
 static int g_last_C_tmp = 0;
 /* Aligner::_computeStatistics after orc_align: the 11th Linearizer::update at the final transform on the finder's last
@@ -852,6 +891,7 @@ void orc_align(const orc_aligner_params* p, const orc_cloud* ref, const orc_clou
       }
       for (int d = 0; d < 6; ++d) { H[d + 6 * d] = H[d + 6 * d] + 1.0f; }        /* aligner.cpp:92 */
       for (int d = 0; d < 6; ++d) { H[d + 6 * d] = H[d + 6 * d] + 1000.0f; }     /* aligner.cpp:94 */
+      for (const Prior& pr : g_priors) prior_add(pr, invT, H, b);                /* aligner.cpp:97-108 */
       float nb[6], dx[6];
       for (int d = 0; d < 6; ++d) nb[d] = -b[d];
       ldlt_solve6(H, nb, dx);

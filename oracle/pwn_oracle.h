@@ -142,6 +142,10 @@ void orc_align(const orc_aligner_params* p, const orc_cloud* ref, const orc_clou
 void orc_match_score(const float* ref_depth, const float* cur_depth, int n, float threshold, int* non_zeros, int* outliers,
                      int* inliers, float* reprojection_distance);
 
+/* Aligner::clearPriors / addRelativePrior (kind 0) / addAbsolutePrior (kind 1): priors used by the following orc_align calls
+ * (aligner.cpp:34-47, 96-108; se3_prior.cpp) */
+void orc_clear_priors(void);
+void orc_add_prior(int kind, const float mean[16], const float reference_transform[16], const float information[36]);
 /* Aligner::_computeStatistics (aligner.cpp:152-199): H = linearizer H at the final transform, T = Aligner::_T */
 void orc_compute_statistics(const float H[36], const float T[16], float mean[6], float omega[36], float* translational_ratio, float* rotational_ratio);
 /* the same after the last orc_align (runs the 11th linearizer update on the finder's last correspondences) */
