@@ -598,9 +598,23 @@ __device__ __forceinline__ void mul_skew(const float* a /*row-major 3x3*/, float
     out[3 * i + 2] = a[3 * i + 0] * (-ty) + a[3 * i + 1] * tx;
   }
 }
+// Accumulator policies of linearize_term: registers (RegAcc) or one private LDS column per thread (LdsAcc; frees ~34 VGPRs,
+// which is what limits the occupancy of the fused kernel).  LdsAcc::add is a plain read-add-write of the thread's own slot.
+struct RegAcc {
+  float* a;
+  __device__ __forceinline__ void add(int k, float v) const { a[k] += v; }
+};
+#ifndef PWN_LDS_ACC
+#define PWN_LDS_ACC 1
+#endif
+struct LdsAcc {
+  float* base;      // &lds[threadIdx.x], stride kAlignBlock
+  __device__ __forceinline__ void add(int k, float v) const { base[k * kAlignBlock] += v; }
+};
 // returns false if the term is rejected (non-robust kernel and chi2 above threshold)
+template <typename ACC>
 __device__ __forceinline__ bool linearize_term(const float3 rp, const float3 rn, const float3 cp, const float3 cn,
-                                               const float* oP, const float* oN, float maxChi2, int robust, float* acc) {
+                                               const float* oP, const float* oN, float maxChi2, int robust, const ACC acc) {
   const float pe0 = rp.x - cp.x, pe1 = rp.y - cp.y, pe2 = rp.z - cp.z;
   const float ne0 = rn.x - cn.x, ne1 = rn.y - cn.y, ne2 = rn.z - cn.z;
   float ep[3], en[3];
@@ -626,10 +640,10 @@ __device__ __forceinline__ bool linearize_term(const float3 rp, const float3 rn,
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const float a0 = oP[3 * i], a1 = oP[3 * i + 1], a2 = oP[3 * i + 2];
-    acc[0 + i] += a0; acc[0 + i + 3] += a1; acc[0 + i + 6] += a2;
-    acc[9 + i]     += a1 * (-ptz) + a2 * pty;                    // (omegaP * Sp)(i, 0..2)
-    acc[9 + i + 3] += a0 * ptz + a2 * (-ptx);
-    acc[9 + i + 6] += a0 * (-pty) + a1 * ptx;
+    acc.add(0 + i, a0); acc.add(0 + i + 3, a1); acc.add(0 + i + 6, a2);
+    acc.add(9 + i, a1 * (-ptz) + a2 * pty);                    // (omegaP * Sp)(i, 0..2)
+    acc.add(9 + i + 3, a0 * ptz + a2 * (-ptx));
+    acc.add(9 + i + 6, a0 * (-pty) + a1 * ptx);
     // row i of Sp^T*omegaP and of Sn^T*omegaN
     float p0, p1, p2, q0, q1, q2;
     if (i == 0) {
@@ -642,14 +656,13 @@ __device__ __forceinline__ bool linearize_term(const float3 rp, const float3 rn,
       p0 = (-pty) * oP[0] + ptx * oP[3]; p1 = (-pty) * oP[1] + ptx * oP[4]; p2 = (-pty) * oP[2] + ptx * oP[5];
       q0 = (-nty) * oN[0] + ntx * oN[3]; q1 = (-nty) * oN[1] + ntx * oN[4]; q2 = (-nty) * oN[2] + ntx * oN[5];
     }
-    acc[18 + i]     += (p1 * (-ptz) + p2 * pty) + (q1 * (-ntz) + q2 * nty);
-    acc[18 + i + 3] += (p0 * ptz + p2 * (-ptx)) + (q0 * ntz + q2 * (-ntx));
-    acc[18 + i + 6] += (p0 * (-pty) + p1 * ptx) + (q0 * (-nty) + q1 * ntx);
+    acc.add(18 + i, (p1 * (-ptz) + p2 * pty) + (q1 * (-ntz) + q2 * nty));
+    acc.add(18 + i + 3, (p0 * ptz + p2 * (-ptx)) + (q0 * ntz + q2 * (-ntx)));
+    acc.add(18 + i + 6, (p0 * (-pty) + p1 * ptx) + (q0 * (-nty) + q1 * ntx));
   }
-  acc[27] += kscale * ep[0]; acc[28] += kscale * ep[1]; acc[29] += kscale * ep[2];
-  acc[30] += kscale * s0; acc[31] += kscale * s1; acc[32] += kscale * s2;
-  acc[33] += kscale * localError;
-  acc[34] += 1.f;
+  acc.add(27, kscale * ep[0]); acc.add(28, kscale * ep[1]); acc.add(29, kscale * ep[2]);
+  acc.add(30, kscale * s0); acc.add(31, kscale * s1); acc.add(32, kscale * s2);
+  acc.add(33, kscale * localError);
   return true;
 }
 __device__ __forceinline__ void load_omegas(const CloudDev& cur, int ci, int cls, float* oP, float* oN) {
@@ -753,14 +766,14 @@ __device__ __forceinline__ void candidate_load(const PairDesc& pd, int ri, int c
 #endif
   }
 }
-template <bool SAME_T>
+template <bool SAME_T, typename ACC>
 __device__ __forceinline__ void candidate_consume(const PairDesc& pd, const AlignParams& ap, const Mat4& Tc, const Mat4& Tl,
-                                                  const Candidate& c, float* acc) {
+                                                  const Candidate& c, const ACC acc, float* cnt /* K, C, inliers */) {
   if (!c.valid) return;
-  acc[36] += 1.f;
+  cnt[0] += 1.f;
   float3 rp, rn;
   if (!correspondence_test(ap, Tc, c.rP, c.rN, c.cP, c.cN, rp, rn)) return;
-  acc[35] += 1.f;
+  cnt[1] += 1.f;
   float oN[9];
   const int cls = __float_as_int(c.cN.w);
   if (pd.cur.OmN) {
@@ -782,7 +795,8 @@ __device__ __forceinline__ void candidate_consume(const PairDesc& pd, const Alig
     for (int k = 0; k < 9; ++k) oP[k] = pd.cur.Om[k * cap + c.ci];
   }
 #endif
-  linearize_term(rp, rn, make_float3(c.cP.x, c.cP.y, c.cP.z), make_float3(c.cN.x, c.cN.y, c.cN.z), oP, oN, ap.maxChi2, ap.robust, acc);
+  if (linearize_term(rp, rn, make_float3(c.cP.x, c.cP.y, c.cP.z), make_float3(c.cN.x, c.cN.y, c.cN.z), oP, oN, ap.maxChi2, ap.robust, acc))
+    cnt[2] += 1.f;
 }
 // usePrevTc: the acceptance tests run with the previous outer iteration's transform (Aligner::_computeStatistics re-linearizes
 // the finder's existing correspondences at the final transform, aligner.cpp:165-170).
@@ -792,9 +806,18 @@ __global__ void __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_corr_linearize(co
   const int N = ap.rows * ap.cols;
   const Mat4 Tc = uniform_iso(usePrevTc ? pd.state->invTcorrPrev : pd.state->invTcorr);
   const Mat4 Tl = uniform_iso(pd.state->invT);
+#if PWN_LDS_ACC
+  __shared__ float lacc[34 * kAlignBlock];            // 34 float sums per thread, column threadIdx.x (bank-conflict free)
+#pragma unroll
+  for (int k = 0; k < 34; ++k) lacc[k * kAlignBlock + threadIdx.x] = 0.f;
+  const LdsAcc sums = { &lacc[threadIdx.x] };
+#else
   float acc[kAccN];
 #pragma unroll
   for (int k = 0; k < kAccN; ++k) acc[k] = 0.f;
+  const RegAcc sums = { acc };
+#endif
+  float cnt[3] = { 0.f, 0.f, 0.f };
   const int nref = min(*pd.ref.count, pd.ref.capacity), ncur = min(*pd.cur.count, pd.cur.capacity);
   const int pix0 = blockIdx.x * kPixPerThread * kAlignBlock + threadIdx.x;
   auto load_indices = [&](int j, int& ri, int& ci) {
@@ -812,8 +835,14 @@ __global__ void __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_corr_linearize(co
     const Candidate cur = nxt;
     candidate_load(pd, ri2, ci2, nref, ncur, nxt);       // gathers of pixel j+1: in flight during the arithmetic below
     load_indices(j + 2, ri2, ci2);                        // indices of pixel j+2
-    candidate_consume<SAME_T>(pd, ap, Tc, Tl, cur, acc);
+    candidate_consume<SAME_T>(pd, ap, Tc, Tl, cur, sums, cnt);
   }
+#if PWN_LDS_ACC
+  float acc[kAccN];
+#pragma unroll
+  for (int k = 0; k < 34; ++k) acc[k] = lacc[k * kAlignBlock + threadIdx.x];
+#endif
+  acc[36] = cnt[0]; acc[35] = cnt[1]; acc[34] = cnt[2];
   block_reduce_store(acc, pd.partials + (size_t)blockIdx.x * kAccN);
 }
 
@@ -852,7 +881,7 @@ __global__ void __launch_bounds__(kAlignBlock) k_linearize_list(CloudDev ref, Cl
     float oP[9], oN[9];
     load_omegas(cur, c.y, __float_as_int(cN.w), oP, oN);
     const float3 rp = iso_point(Tl, rP), rn = iso_normal(Tl, rN);
-    linearize_term(rp, rn, make_float3(cP.x, cP.y, cP.z), make_float3(cN.x, cN.y, cN.z), oP, oN, ap.maxChi2, ap.robust, acc);
+    if (linearize_term(rp, rn, make_float3(cP.x, cP.y, cP.z), make_float3(cN.x, cN.y, cN.z), oP, oN, ap.maxChi2, ap.robust, RegAcc{ acc })) acc[34] += 1.f;
   }
   block_reduce_store(acc, partials + (size_t)blockIdx.x * kAccN);
 }
