@@ -242,12 +242,11 @@ int ensure_desc(pwn_hip_ctx* ctx, int n) {
 // launch sequence of the converter for the frames [base, base+n) of the uploaded descriptor array
 int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, hipStream_t st) {
   const FrameDesc* fr = ctx->frames_dev + base;
-  { StageTimer t(ctx, "unproject", st);
+  { StageTimer t(ctx, "unproject", st);          // ordered compaction: per-row counts and offsets
     hipLaunchKernelGGL(k_row_count, dim3(cp.rows, n), dim3(256), 0, st, fr, cp);
-    hipLaunchKernelGGL(k_row_offsets, dim3(n), dim3(1024), 0, st, fr, cp.rows);
-    hipLaunchKernelGGL(k_unproject, dim3(cp.rows, n), dim3(256), 0, st, fr, cp); }
-  { StageTimer t(ctx, "integral_rows", st);
-    hipLaunchKernelGGL(k_integral_rows, dim3((cp.rows + kIR_Rows - 1) / kIR_Rows, n), dim3(256), 0, st, fr, cp.rows, cp.cols); }
+    hipLaunchKernelGGL(k_row_offsets, dim3(n), dim3(1024), 0, st, fr, cp.rows); }
+  { StageTimer t(ctx, "integral_rows", st);      // unProject + intervals + accumulate + row prefix, one pass over the depth
+    hipLaunchKernelGGL(k_unproject_integral_rows, dim3((cp.rows + kIR_Rows - 1) / kIR_Rows, n), dim3(256), 0, st, fr, cp); }
   { StageTimer t(ctx, "integral_cols", st);
     hipLaunchKernelGGL(k_integral_cols, dim3((cp.cols + 255) / 256, kIntegralChannels, n), dim3(256), 0, st, fr, cp.rows, cp.cols); }
   { StageTimer t(ctx, "stats", st);
@@ -258,7 +257,7 @@ int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, h
 }
 void fill_frame(pwn_hip_ctx* ctx, int entry, int slot, const float* depth_dev, const CloudDev& cl, int rows) {
   FrameDesc& f = ctx->frames_host[entry];
-  f.depth = depth_dev;
+  f.depth = depth_dev; f.raw = nullptr; f.raw_scale = 0.f;
   f.index = ctx->index_ws + (size_t)slot * ctx->N;
   f.interval = ctx->interval_ws + (size_t)slot * ctx->N;
   f.integral = ctx->integral_ws + (size_t)slot * ctx->N * kIntegralChannels;
@@ -307,27 +306,23 @@ int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, cons
     make_omega_n_classes(p, c->d);
     const int slot = plan.slot0(i / sub) + i % sub;
     const float* depth_dev = nullptr;
-    if (raw) {
-      const uint16_t* src = reinterpret_cast<const uint16_t*>(frames[i]);
-      ctx->raw_host[i].src = src;                                   // patched below if it is a host pointer
-      ctx->raw_host[i].dst = ctx->depth_ws + (size_t)slot * ctx->N;
-      depth_dev = ctx->raw_host[i].dst;
-    } else {
-      depth_dev = reinterpret_cast<const float*>(frames[i]);         // patched below if it is a host pointer
-    }
+    if (!raw) depth_dev = reinterpret_cast<const float*>(frames[i]);         // patched below if it is a host pointer
     fill_frame(ctx, i, slot, depth_dev, c->d, rows);
+    if (raw) {                                                                // uint16 frames are converted on the fly by the kernels
+      ctx->frames_host[i].raw = reinterpret_cast<const uint16_t*>(frames[i]); // patched below if it is a host pointer
+      ctx->frames_host[i].raw_scale = depth_scale;
+    }
   }
   // host inputs are staged per sub-batch; device inputs are used in place
   const bool host_input = !is_device_ptr(frames[0]);
   if (host_input) {
     for (int i = 0; i < n; ++i) {
       const int slot = plan.slot0(i / sub) + i % sub;
-      if (raw) ctx->raw_host[i].src = ctx->raw_ws + (size_t)slot * ctx->N;
+      if (raw) ctx->frames_host[i].raw = ctx->raw_ws + (size_t)slot * ctx->N;
       else ctx->frames_host[i].depth = ctx->depth_ws + (size_t)slot * ctx->N;
     }
   }
   HIPCHK(ctx, hipMemcpyAsync(ctx->frames_dev, ctx->frames_host, sizeof(FrameDesc) * n, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
-  if (raw) HIPCHK(ctx, hipMemcpyAsync(ctx->raw_dev, ctx->raw_host, sizeof(RawDesc) * n, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
   if (int rc = plan_fork(ctx, plan)) return rc;
   for (int base = 0, k = 0; base < n; base += sub, ++k) {
     const int m = std::min(sub, n - base);
@@ -338,10 +333,6 @@ int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, cons
         if (raw) HIPCHK(ctx, hipMemcpyAsync(ctx->raw_ws + (size_t)(s0 + i) * ctx->N, frames[base + i], N * sizeof(uint16_t), hipMemcpyHostToDevice, st), PWN_HIP_ERR_COPY);
         else HIPCHK(ctx, hipMemcpyAsync(ctx->depth_ws + (size_t)(s0 + i) * ctx->N, frames[base + i], N * sizeof(float), hipMemcpyHostToDevice, st), PWN_HIP_ERR_COPY);
       }
-    }
-    if (raw) {
-      StageTimer t(ctx, "u16_to_f32", st);
-      hipLaunchKernelGGL(k_u16_to_f32, dim3((unsigned)std::min<size_t>((N + 255) / 256, 1024), m), dim3(256), 0, st, ctx->raw_dev + base, (int)N, depth_scale);
     }
     if (int rc = launch_convert(ctx, cp, base, m, st)) return rc;
   }

@@ -54,7 +54,9 @@ struct CloudDev {
 };
 
 struct FrameDesc {
-  const float* depth;
+  const float* depth;        // float32 metres, or nullptr when `raw` is used
+  const uint16_t* raw;       // optional uint16 source (DepthImage_convert_16UC1_to_32FC1 fused in: d = raw ? scale*raw : 0)
+  float raw_scale;
   int* index;
   int* interval;
   float* integral;   // [10][rows*cols]
@@ -169,16 +171,20 @@ __global__ void k_depth_scale(const float* __restrict__ src, int srows, int scol
   dst[i] = out;
 }
 
+// depth of pixel i of a frame: the float image, or the raw uint16 image converted on the fly (pwn_static.cpp:54-68)
+__device__ __forceinline__ float frame_depth(const FrameDesc& f, size_t i) {
+  if (f.raw) { const uint16_t s = f.raw[i]; return s ? f.raw_scale * (float)s : 0.0f; }
+  return f.depth[i];
+}
 // ------------------------------------------------------------------------------------------------------------------
 // Ordered compaction, step 1: valid pixels per image row.  grid = (rows, frames), block = 256.
 // validity test = PinholePointProjector::_unProject (pwn_core/pinholepointprojector.h:246-248)
 __global__ void __launch_bounds__(256) k_row_count(const FrameDesc* __restrict__ frames, ConvertParams cp) {
   const FrameDesc& f = frames[blockIdx.y];
   const int r = blockIdx.x;
-  const float* row = f.depth + (size_t)r * cp.cols;
   int cnt = 0;
   for (int c = threadIdx.x; c < cp.cols; c += 256) {
-    const float d = row[c];
+    const float d = frame_depth(f, (size_t)r * cp.cols + c);
     cnt += !(d < cp.minD || d > cp.maxD);
   }
   __shared__ int s[4];
@@ -230,7 +236,7 @@ __global__ void __launch_bounds__(256) k_unproject(const FrameDesc* __restrict__
   for (int c0 = 0; c0 < cp.cols; c0 += 256) {
     const int c = c0 + threadIdx.x;
     const bool in = c < cp.cols;
-    const float d = in ? f.depth[(size_t)r * cp.cols + c] : 0.f;
+    const float d = in ? frame_depth(f, (size_t)r * cp.cols + c) : 0.f;
     const bool valid = in && !(d < cp.minD || d > cp.maxD);
     const unsigned long long bal = __ballot(valid);
     const int rank = __popcll(bal & ((1ull << lane) - 1ull));
@@ -321,6 +327,90 @@ __global__ void __launch_bounds__(256) k_integral_rows(const FrameDesc* __restri
     for (int j = 0; j < 4; ++j) {
       const int q = tid + 256 * j;
       const int lr = q / kIR_Cols, lc = q % kIR_Cols;
+      const int r = r0 + lr, c = x0 + lc;
+      if (r < rows && c < cols) {
+#pragma unroll
+        for (int k = 0; k < kIntegralChannels; ++k)
+          f.integral[k * N + (size_t)r * cols + c] = tile[(k * kIR_Rows + lr) * kIR_Stride + lc];
+      }
+    }
+    __syncthreads();
+  }
+}
+// Converter fast path: unProject + projectIntervals (k_unproject) fused into the row scan.  Depth is read once; the
+// kernel writes the points, the index and interval images AND the row-prefixed integral planes.  Wave w of the block owns
+// rows r0 + w + 4j (j = 0..3) of the 16-row band: one wave instruction covers 64 consecutive columns of one row, so the
+// point index of a valid pixel = row offset + running count of the row + popcount(ballot below the lane).
+// grid = (ceil(rows/16), frames), block = 256.
+__global__ void __launch_bounds__(256) k_unproject_integral_rows(const FrameDesc* __restrict__ frames, ConvertParams cp) {
+  const FrameDesc& f = frames[blockIdx.y];
+  const int rows = cp.rows, cols = cp.cols;
+  const int r0 = blockIdx.x * kIR_Rows;
+  __shared__ float tile[kIntegralChannels * kIR_Rows * kIR_Stride];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t N = (size_t)rows * cols;
+  const int srow = tid % kIR_Rows, sch = tid / kIR_Rows;
+  float carry = 0.f;
+  int base[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { const int r = r0 + wave + 4 * j; base[j] = (r < rows) ? f.rowoff[r] : 0; }
+  for (int x0 = 0; x0 < cols; x0 += kIR_Cols) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int lr = wave + 4 * j, lc = lane;
+      const int r = r0 + lr, c = x0 + lc;
+      const bool in = r < rows && c < cols;
+      const float d = in ? frame_depth(f, (size_t)r * cols + c) : 0.f;
+      const bool valid = in && !(d < cp.minD || d > cp.maxD);
+      const unsigned long long bal = __ballot(valid);
+      float v[kIntegralChannels];
+#pragma unroll
+      for (int k = 0; k < kIntegralChannels; ++k) v[k] = 0.f;
+      if (in) {
+        int idx = -1, itv = -1;
+        if (valid) {
+          idx = base[j] + __popcll(bal & ((1ull << lane) - 1ull));
+          const float a = (float)c * d, b = (float)r * d;
+          float4 p;
+          p.x = dot4seq(cp.iKRt(0,0), a, cp.iKRt(0,1), b, cp.iKRt(0,2), d, cp.iKRt(0,3), 1.0f);
+          p.y = dot4seq(cp.iKRt(1,0), a, cp.iKRt(1,1), b, cp.iKRt(1,2), d, cp.iKRt(1,3), 1.0f);
+          p.z = dot4seq(cp.iKRt(2,0), a, cp.iKRt(2,1), b, cp.iKRt(2,2), d, cp.iKRt(2,3), 1.0f);
+          p.w = 0.f;
+          if (idx < f.cloud.capacity) {
+            f.cloud.P[idx] = p;
+            v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = 1.0f;
+            v[4] = p.x * p.x; v[5] = p.x * p.y; v[6] = p.x * p.z;
+            v[7] = p.y * p.y; v[8] = p.y * p.z; v[9] = p.z * p.z;
+          }
+          const float inv = 1.0f / d;
+          const float px = cp.ivx * inv, py = cp.ivy * inv;
+          itv = (px > py) ? (int)px : (int)py;
+        }
+        f.index[(size_t)r * cols + c] = idx;
+        f.interval[(size_t)r * cols + c] = itv;
+      }
+      base[j] += __popcll(bal);
+#pragma unroll
+      for (int k = 0; k < kIntegralChannels; ++k) tile[(k * kIR_Rows + lr) * kIR_Stride + lc] = v[k];
+    }
+    __syncthreads();
+    if (tid < kIntegralChannels * kIR_Rows) {
+      float* t = &tile[(sch * kIR_Rows + srow) * kIR_Stride];
+#pragma unroll 1
+      for (int c0 = 0; c0 < kIR_Cols; c0 += 16) {          // 16 LDS reads in flight, then the sequential adds
+        float vals[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) vals[c] = t[c0 + c];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { carry = vals[c] + carry; vals[c] = carry; }
+#pragma unroll
+        for (int c = 0; c < 16; ++c) t[c0 + c] = vals[c];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int lr = wave + 4 * j, lc = lane;
       const int r = r0 + lr, c = x0 + lc;
       if (r < rows && c < cols) {
 #pragma unroll
