@@ -45,6 +45,14 @@ def _from_colmajor(a, n):
     return np.array(list(a), dtype=np.float32).reshape(n, n).T.copy()
 
 
+# numpy view of pwn_hip_align_result (include/pwn_hip.h): zero-copy access to a batch of results
+ALIGN_RESULT_DTYPE = np.dtype([("T", np.float32, 16), ("error", np.float32), ("inliers", np.int32), ("iterations", np.int32),
+                               ("total_time_ms", np.float32), ("chi2", np.float32, _lib.MAX_ITERATIONS),
+                               ("iter_inliers", np.int32, _lib.MAX_ITERATIONS), ("iter_correspondences", np.int32, _lib.MAX_ITERATIONS),
+                               ("iter_candidates", np.int32, _lib.MAX_ITERATIONS), ("n_reference", np.int32), ("n_current", np.int32)])
+assert ALIGN_RESULT_DTYPE.itemsize == C.sizeof(AlignResult)
+
+
 def device_count() -> int:
     return _lib.lib().pwn_hip_device_count()
 
@@ -323,15 +331,21 @@ class DepthImageConverterIntegralImage:
         ctx.check(ctx._L.pwn_hip_convert(ctx.h, C.byref(p), _ptr(depth), rows, cols, cloud.h, _ptr(idx), _ptr(itv), 1 if keep_stats else 0))
         self._indexImage, self._intervalImage = idx, itv
 
-    def computeBatch(self, clouds, depthImages, sensorOffset=None, raw_scale=None):
+    @staticmethod
+    def batchHandles(clouds, depthImages):
+        """(cloud handle array, frame pointer array) for computeBatch(..., prepared=...): build once, reuse every call."""
+        n = len(clouds)
+        return (C.c_void_p * n)(*[c.h for c in clouds]), (C.c_void_p * n)(*[_ptr(d) for d in depthImages]), n, tuple(depthImages[0].shape)
+
+    def computeBatch(self, clouds, depthImages, sensorOffset=None, raw_scale=None, prepared=None):
         """n independent frames in one call.  depthImages: list of float32 [rows, cols] arrays / CUDA tensors,
         or uint16 millimetre frames when raw_scale is given (fuses DepthImage_convert_16UC1_to_32FC1)."""
         ctx = clouds[0].ctx
-        n = len(clouds)
-        rows, cols = depthImages[0].shape
         p = self.params(sensorOffset)
-        ptrs = (C.c_void_p * n)(*[_ptr(d) for d in depthImages])
-        handles = (C.c_void_p * n)(*[c.h for c in clouds])
+        if prepared is not None:
+            handles, ptrs, n, (rows, cols) = prepared
+        else:
+            handles, ptrs, n, (rows, cols) = self.batchHandles(clouds, depthImages)
         if raw_scale is None:
             ctx.check(ctx._L.pwn_hip_convert_batch(ctx.h, C.byref(p), ptrs, n, rows, cols, handles))
         else:
@@ -510,18 +524,24 @@ class Aligner:
             f._images = dict(ref_index=ri, ref_depth=rd, cur_index=ci, cur_depth=cd)
         return self._result
 
-    def alignBatch(self, references, currents, initialGuesses=None):
+    def alignBatch(self, references, currents, initialGuesses=None, raw=False, prepared=None):
         """n independent alignments with this aligner's parameters (the loop-closure candidate batch,
-        pwn_tracker/pwn_closer.cpp:92-111)."""
-        n = len(references)
+        pwn_tracker/pwn_closer.cpp:92-111).  raw=True returns the results as one numpy structured array
+        (ALIGN_RESULT_DTYPE, T column-major) instead of a list of dicts; prepared = (refs, curs, n) handle arrays."""
         p = self.params()
+        if prepared is not None:
+            refs, curs, n = prepared
+        else:
+            n = len(references)
+            refs = (C.c_void_p * n)(*[c.h for c in references])
+            curs = (C.c_void_p * n)(*[c.h for c in currents])
         res = (AlignResult * n)()
-        refs = (C.c_void_p * n)(*[c.h for c in references])
-        curs = (C.c_void_p * n)(*[c.h for c in currents])
         g = None
         if initialGuesses is not None:
             g = np.ascontiguousarray(np.stack([_colmajor(self._iso(T), 4) for T in initialGuesses]), np.float32)
         self.ctx.check(self.ctx._L.pwn_hip_align_batch(self.ctx.h, C.byref(p), n, refs, curs, _ptr(g), res))
+        if raw:
+            return np.frombuffer(res, dtype=ALIGN_RESULT_DTYPE, count=n)
         return [self._unpack(r) for r in res]
 
     # stage-level entry points (CorrespondenceFinder::compute / Linearizer::update with explicit inputs)

@@ -251,7 +251,12 @@ int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, h
     hipLaunchKernelGGL(k_integral_cols, dim3((cp.cols + 255) / 256, kIntegralChannels, n), dim3(256), 0, st, fr, cp.rows, cp.cols); }
   { StageTimer t(ctx, "stats", st);
     const unsigned nblk = 8u * (unsigned)((n + 7) / 8) * (unsigned)cp.rows * (unsigned)((cp.cols + 255) / 256);
-    hipLaunchKernelGGL(k_stats, dim3(nblk), dim3(256), 0, st, fr, cp, n); }
+#ifndef PWN_STATS_LDS
+#define PWN_STATS_LDS 0
+#endif
+    // PWN_STATS_LDS: a dynamic-LDS request that only limits the resident blocks per CU, so that the rows in flight on an XCD
+    // (plus the 2*radius halo) fit its 4 MiB L2
+    hipLaunchKernelGGL(k_stats, dim3(nblk), dim3(256), PWN_STATS_LDS, st, fr, cp, n); }
   HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
   return PWN_HIP_OK;
 }
@@ -882,12 +887,12 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
     HIPCHK(ctx, hipMemsetAsync(ctx->zref_ws + s0 * ctx->N, 0xFF, (size_t)m * ctx->N * 8, st), PWN_HIP_ERR_COPY);
     HIPCHK(ctx, hipMemsetAsync(ctx->zcur_ws + s0 * ctx->N, 0xFF, (size_t)m * ctx->N * 8, st), PWN_HIP_ERR_COPY);
     { StageTimer t(ctx, "project", st);
-      hipLaunchKernelGGL(k_project, dim3((maxcap_cur + 255) / 256, m), dim3(256), 0, st, pr, ap, 1, kZTag0);
+      hipLaunchKernelGGL(k_project, dim3((maxcap_cur + 256 * kProjectPointsPerThread - 1) / (256 * kProjectPointsPerThread), m), dim3(256), 0, st, pr, ap, 1, kZTag0);
       hipLaunchKernelGGL(k_resolve_cur, dim3(std::min((N + 255) / 256, 1024), m), dim3(256), 0, st, pr, N, kZTag0); }
     for (int i = 0; i < p->outer_iterations; ++i) {
       const unsigned tag = kZTag0 - (unsigned)i;      // epoch of this outer iteration's reference projection
       { StageTimer t(ctx, "project", st);
-        hipLaunchKernelGGL(k_project, dim3((maxcap_ref + 255) / 256, m), dim3(256), 0, st, pr, ap, 0, tag); }
+        hipLaunchKernelGGL(k_project, dim3((maxcap_ref + 256 * kProjectPointsPerThread - 1) / (256 * kProjectPointsPerThread), m), dim3(256), 0, st, pr, ap, 0, tag); }
       for (int k = 0; k < p->inner_iterations; ++k) {
         const bool lastInner = (k == p->inner_iterations - 1);
         { StageTimer t(ctx, "corr_linearize", st);
@@ -989,7 +994,7 @@ int pwn_hip_align_with_priors(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p,
   HIPCHK(ctx, hipMemcpyAsync(ctx->state_ws, &hs, sizeof(PairState), hipMemcpyHostToDevice, st), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipMemsetAsync(ctx->zref_ws, 0xFF, (size_t)ctx->N * 8, st), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipMemsetAsync(ctx->zcur_ws, 0xFF, (size_t)ctx->N * 8, st), PWN_HIP_ERR_COPY);
-  hipLaunchKernelGGL(k_project, dim3((cur->d.capacity + 255) / 256, 1), dim3(256), 0, st, ctx->pairs_dev, ap, 1, kZTag0);
+  hipLaunchKernelGGL(k_project, dim3((cur->d.capacity + 256 * kProjectPointsPerThread - 1) / (256 * kProjectPointsPerThread), 1), dim3(256), 0, st, ctx->pairs_dev, ap, 1, kZTag0);
   hipLaunchKernelGGL(k_resolve_cur, dim3(std::min((N + 255) / 256, 1024), 1), dim3(256), 0, st, ctx->pairs_dev, N, kZTag0);
   std::memset(result, 0, sizeof(*result));
   int it = 0;
@@ -1003,7 +1008,7 @@ int pwn_hip_align_with_priors(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p,
       set_last_row(invT);                                                            // :86
       hs.invT = invT;
       HIPCHK(ctx, hipMemcpyAsync(ctx->state_ws, &hs, sizeof(PairState), hipMemcpyHostToDevice, st), PWN_HIP_ERR_COPY);
-      if (k == 0) hipLaunchKernelGGL(k_project, dim3((ref->d.capacity + 255) / 256, 1), dim3(256), 0, st, ctx->pairs_dev, ap, 0, tag);
+      if (k == 0) hipLaunchKernelGGL(k_project, dim3((ref->d.capacity + 256 * kProjectPointsPerThread - 1) / (256 * kProjectPointsPerThread), 1), dim3(256), 0, st, ctx->pairs_dev, ap, 0, tag);
       if (k == 0) hipLaunchKernelGGL(k_corr_linearize<true>, dim3(nb, 1), dim3(kAlignBlock), 0, st, ctx->pairs_dev, ap, tag, 0);
       else hipLaunchKernelGGL(k_corr_linearize<false>, dim3(nb, 1), dim3(kAlignBlock), 0, st, ctx->pairs_dev, ap, tag, 0);
       hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, st, ctx->pairs_dev, nb, ctx->stats_dev);

@@ -452,6 +452,25 @@ __global__ void __launch_bounds__(256) k_integral_cols(const FrameDesc* __restri
 // one XCD and the four corner reads of neighbouring rows (2*radius rows apart, ~1.6 MB of planes) are L2 hits instead of one
 // L2 fill per XCD.  Placement only affects speed.  grid = 8 * ceil(frames/8) * rows * ceil(cols/256), block = 256.
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { v = (v < lo) ? lo : v; v = (v > hi) ? hi : v; return v; }
+#ifndef PWN_STATS_NT
+#define PWN_STATS_NT 1
+#endif
+// streamed-once data of k_stats (index / interval / point in, cloud out) uses non-temporal accesses so that it does not evict the
+// integral-image lines, which are the only data with reuse (each value is read by ~4 pixels)
+template <typename T> __device__ __forceinline__ T stream_load(const T* p) {
+#if PWN_STATS_NT
+  return __builtin_nontemporal_load(p);
+#else
+  return *p;
+#endif
+}
+template <typename T> __device__ __forceinline__ void stream_store(T* p, T v) {
+#if PWN_STATS_NT
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
 
 __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ frames, ConvertParams cp, int nframes) {
   const int nxb = (cp.cols + 255) / 256;
@@ -467,10 +486,11 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
   const int rows = cp.rows, cols = cp.cols;
   const size_t N = (size_t)rows * cols;
   const size_t pix = (size_t)r * cols + c;
-  const int idx = f.index[pix];
+  const int idx = stream_load(&f.index[pix]);
   if (idx < 0 || idx >= f.cloud.capacity) return;
-  const int itv = f.interval[pix];
-  float4 P = f.cloud.P[idx];
+  const int itv = stream_load(&f.interval[pix]);
+  float4 P;
+  { const float* pp = reinterpret_cast<const float*>(&f.cloud.P[idx]); P.x = stream_load(pp); P.y = stream_load(pp + 1); P.z = stream_load(pp + 2); P.w = 0.f; }
   float nx = 0.f, ny = 0.f, nz = 0.f;
   float curvature = 0.f;          // Stats() default: eigenvalues 0 -> curvature() = 0/(0+1e-9) = 0  (stats.h:21-27,98-103)
   int cls = 0;
@@ -585,11 +605,14 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
       for (int j = 0; j < 3; ++j) om[3 * i + j] = dot3seq(t1[3 * i], m(j,0), t1[3 * i + 1], m(j,1), t1[3 * i + 2], m(j,2));
   }
   P.w = curvature;
-  f.cloud.P[idx] = P;
-  f.cloud.Nm[idx] = make_float4(nx, ny, nz, __int_as_float(cls));
+  {
+    float* pp = reinterpret_cast<float*>(&f.cloud.P[idx]); float* np_ = reinterpret_cast<float*>(&f.cloud.Nm[idx]);
+    stream_store(pp, P.x); stream_store(pp + 1, P.y); stream_store(pp + 2, P.z); stream_store(pp + 3, P.w);
+    stream_store(np_, nx); stream_store(np_ + 1, ny); stream_store(np_ + 2, nz); stream_store(np_ + 3, __int_as_float(cls));
+  }
   const int cap = f.cloud.capacity;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) f.cloud.Om[(size_t)k * cap + idx] = om[k];
+  for (int k = 0; k < 9; ++k) stream_store(&f.cloud.Om[(size_t)k * cap + idx], om[k]);
 }
 
 // Cloud::transformInPlace on an existing device cloud (cloud.cpp:173-186); grid = ceil(cap/256)
@@ -632,16 +655,29 @@ __device__ __forceinline__ void project_point(const Mat4& KRt, float minD, float
   // int conversion of out-of-range floats is undefined on the CPU; such points are rejected by the bounds test
   if (!(fx >= 0.f && fx < (float)cols && fy >= 0.f && fy < (float)rows)) return;
   const int x = (int)fx, y = (int)fy;
+#ifdef PWN_TIMING_PLAIN_STORE      /* timing experiment only: wrong results */
+  z[(size_t)y * cols + x] = zkey(tag, d, i);
+#else
   atomicMin(&z[(size_t)y * cols + x], zkey(tag, d, i));
+#endif
 }
+#ifndef PWN_PROJECT_PPT
+#define PWN_PROJECT_PPT 1
+#endif
+constexpr int kProjectPointsPerThread = PWN_PROJECT_PPT;      // grid.x = ceil(capacity / (256 * kProjectPointsPerThread))
 __global__ void __launch_bounds__(256) k_project(const PairDesc* __restrict__ pairs, AlignParams ap, int which, unsigned tag) {
   const PairDesc& pd = pairs[blockIdx.y];
   const CloudDev& cl = which ? pd.cur : pd.ref;
-  const int i = blockIdx.x * 256 + threadIdx.x;
   const int n = min(*cl.count, cl.capacity);
-  if (i >= n) return;
-  const Mat4 KRt = which ? pd.state->KRtCur : pd.state->KRt;
-  project_point(KRt, ap.minD, ap.maxD, ap.rows, ap.cols, cl.P[i], i, which ? pd.zcur : pd.zref, tag);
+  const int i0 = blockIdx.x * 256 * kProjectPointsPerThread + threadIdx.x;
+  if (i0 >= n) return;
+  const Mat4 KRt = uniform_iso(which ? pd.state->KRtCur : pd.state->KRt);
+  unsigned long long* z = which ? pd.zcur : pd.zref;
+  float4 p[kProjectPointsPerThread];
+#pragma unroll
+  for (int j = 0; j < kProjectPointsPerThread; ++j) { const int i = i0 + 256 * j; if (i < n) p[j] = cl.P[i]; }      // loads first
+#pragma unroll
+  for (int j = 0; j < kProjectPointsPerThread; ++j) { const int i = i0 + 256 * j; if (i < n) project_point(KRt, ap.minD, ap.maxD, ap.rows, ap.cols, p[j], i, z, tag); }
 }
 // current-cloud z-buffer -> int index image, once per alignment.  grid = (blocks, pairs)
 __global__ void k_resolve_cur(const PairDesc* __restrict__ pairs, int n, unsigned tag) {

@@ -221,9 +221,15 @@ PWN_HD void eig3_direct(float a00, float a10, float a20, float a11, float a21, f
     const float rho = sqrtf(a_over_3);
     // The three trig calls are evaluated correctly rounded (double precision rounded once to float) so
     // that host libm and device ocml give the same bits; fp64 is cheap on gfx950 and this is 3 calls/pixel.
+#ifdef PWN_TIMING_FLOAT_TRIG      /* timing experiment only: wrong last bits */
+    const float theta = atan2f(sqrtf(q), half_b) * s_inv3;
+    const float cos_theta = cosf(theta);
+    const float sin_theta = sinf(theta);
+#else
     const float theta = (float)atan2((double)sqrtf(q), (double)half_b) * s_inv3;
     const float cos_theta = (float)cos((double)theta);
     const float sin_theta = (float)sin((double)theta);
+#endif
     e[0] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
     e[1] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
     e[2] = c2_over_3 + 2.0f * rho * cos_theta;

@@ -33,13 +33,24 @@ def pack_results(results, pair_ids) -> np.ndarray:
     return out
 
 
+def pack_results_raw(results: np.ndarray, pair_ids) -> np.ndarray:
+    """Same records from the structured-array form (api.ALIGN_RESULT_DTYPE; T is already column-major)."""
+    out = np.empty((len(results), RECORD_FLOATS), np.float32)
+    out[:, :16] = results["T"]
+    out[:, 16] = results["error"]; out[:, 17] = results["inliers"]; out[:, 18] = results["iterations"]; out[:, 19] = np.asarray(pair_ids, np.float32)
+    return out
+
+
 def gather_records(local: "torch.Tensor", world: int, max_per_rank: int):
     """All-gather of the per-rank record blocks (padded to max_per_rank rows); returns [world*max_per_rank, R].
     Rows whose pair id (column 19) is negative are padding."""
     import torch
     import torch.distributed as dist
-    pad = torch.full((max_per_rank, local.shape[1]), -1.0, dtype=local.dtype, device=local.device)
-    pad[: local.shape[0]] = local
+    if local.shape[0] == max_per_rank:
+        pad = local
+    else:
+        pad = torch.full((max_per_rank, local.shape[1]), -1.0, dtype=local.dtype, device=local.device)
+        pad[: local.shape[0]] = local
     if world == 1:
         return pad
     out = torch.empty((world * max_per_rank, local.shape[1]), dtype=local.dtype, device=local.device)
