@@ -595,11 +595,15 @@ class PwnMatcherBase:
         scaled = (np.asarray(cameraMatrix, np.float32).reshape(3, 3) * invScale).astype(np.float32)
         scaled[2, 2] = 1.0
         projector.setCameraMatrix(scaled)
-        depth = np.ascontiguousarray(depthImage, np.float32)
-        projector.setImageSize(depth.shape[0] // self._scale, depth.shape[1] // self._scale)
-        scaledImage = ctx.DepthImage_scale(depth, self._scale)                       # :72
-        cloud = Cloud(ctx, max(1, scaledImage.size))
-        self._converter.compute(cloud, scaledImage, sensorOffset, images=False)     # :79
+        depth = depthImage if hasattr(depthImage, "data_ptr") else np.ascontiguousarray(depthImage, np.float32)
+        rows, cols = depth.shape
+        r, c = rows // self._scale, cols // self._scale
+        projector.setImageSize(r, c)
+        cloud = Cloud(ctx, max(1, r * c))
+        # DepthImage_scale (:72) + converter->compute (:79) in one device-side call; same side effects on the projector
+        projector.setTransform(np.eye(4, dtype=np.float32))
+        p = self._converter.params(sensorOffset)
+        ctx.check(ctx._L.pwn_hip_convert_scaled(ctx.h, C.byref(p), _ptr(depth), rows, cols, self._scale, 0.01, cloud.h))
         self.numCalls += 1
         return cloud, projector.imageRows(), projector.imageCols(), projector.cameraMatrix().copy()
 

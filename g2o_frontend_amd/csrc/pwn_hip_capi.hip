@@ -741,6 +741,22 @@ int pwn_hip_convert(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const f
   if (interval_image) HIPCHK(ctx, hipMemcpy(interval_image, ctx->frames_host[0].interval, N * 4, hipMemcpyDefault), PWN_HIP_ERR_COPY);
   return PWN_HIP_OK;
 }
+int pwn_hip_convert_scaled(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float* depth, int rows, int cols, int step, float max_depth_cov,
+                           pwn_hip_cloud* cloud) {
+  if (!ctx || !p || !depth || !cloud || step <= 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "bad argument");
+  if (int rc = check_image(ctx, rows, cols)) return rc;
+  const int orows = rows / step, ocols = cols / step;
+  if (orows <= 0 || ocols <= 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "scaled image has zero size");
+  const size_t n = (size_t)rows * cols, on = (size_t)orows * ocols;
+  const float* src = depth;
+  if (!is_device_ptr(depth)) { HIPCHK(ctx, hipMemcpyAsync(ctx->depth_ws, depth, n * 4, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY); src = ctx->depth_ws; }
+  float* scaled = ctx->io_ws;                                        // device scratch (N*16 floats)
+  hipLaunchKernelGGL(k_depth_scale, dim3((unsigned)((on + 255) / 256)), dim3(256), 0, ctx->stream, src, rows, cols, step, max_depth_cov, scaled);
+  HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
+  const float* frames[1] = { scaled };
+  pwn_hip_cloud* clouds[1] = { cloud };
+  return convert_batch_impl<float>(ctx, p, frames, 0.f, 1, orows, ocols, clouds, 0);
+}
 int pwn_hip_convert_batch(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float* const* depth_frames, int n, int rows, int cols,
                           pwn_hip_cloud* const* clouds) {
   return convert_batch_impl<float>(ctx, p, depth_frames, 0.f, n, rows, cols, clouds, 0);

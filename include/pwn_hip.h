@@ -199,6 +199,11 @@ int pwn_hip_integral_image(pwn_hip_ctx* ctx, const int* index_image, const pwn_h
  * (DepthImageConverter::indexImage(), depthimageconverter.h:111). keep_stats: also keep per-point Stats. */
 int pwn_hip_convert(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float* depth, int rows, int cols,
                     pwn_hip_cloud* cloud, int* index_image, int* interval_image, int keep_stats);
+/* PwnMatcherBase::makeCloud's data path in one call (pwn_tracker/pwn_matcher_base.cpp:71-79): DepthImage_scale(depth, step,
+ * max_depth_cov) followed by the converter on the (rows/step) x (cols/step) image, without leaving the device.
+ * p->K must already be the scaled camera matrix. */
+int pwn_hip_convert_scaled(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float* depth, int rows, int cols, int step,
+                           float max_depth_cov, pwn_hip_cloud* cloud);
 /* n independent frames of equal size in one call.  depth[i] -> clouds[i].
  * depth_frames: n pointers (host array) to rows*cols floats each (each host or device). */
 int pwn_hip_convert_batch(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float* const* depth_frames,
