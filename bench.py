@@ -136,9 +136,22 @@ def main():
     import torch.distributed as dist
     from g2o_frontend_amd import api, shard, synth
     torch.cuda.set_device(local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("PWN_BENCH_FORCE_DIST") == "1"      # FORCE_DIST: exercise the RCCL path at world size 1
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        os.environ.setdefault("MASTER_PORT", "29511")
+        # RCCL prints a version banner on stdout when the communicator is created; keep stdout for the one JSON line
+        sys.stdout.flush()
+        saved_fd = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved_fd, 1)
+            os.close(saved_fd)
 
     slots = 2 * max(args.sub_frames, args.sub_pairs, 1)      # room for two sub-batches in flight (two-stream mode)
     ctx = api.Context(device=local, max_rows=rows, max_cols=cols, max_batch=slots)
@@ -184,13 +197,13 @@ def main():
                 ms, n = ctx.stage_ms(k); stage_ms[k] += ms; stage_n[k] += n
         records_host.numpy()[:] = shard.pack_results_raw(res, seeds)
         records.copy_(records_host, non_blocking=False)
-        last["gathered"] = shard.gather_records(records, world, P)      # RCCL all-gather: the only collective of the path
+        last["gathered"] = shard.gather_records(records, world, P, force=use_dist)      # RCCL all-gather: the only collective of the path
         last["res"] = res
         if dbg and not profile:
             tm["convert"] += t_b - t_a; tm["align"] += t_c - t_b; tm["gather"] += time.perf_counter() - t_c
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -222,7 +235,7 @@ def main():
         dt_serial = time.perf_counter() - t1
         ctx.set_profiling(False)
         ctx.set_concurrency(args.streams)
-    if world > 1:
+    if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -301,7 +314,7 @@ def main():
         }
         out.update(extra)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

@@ -41,7 +41,7 @@ def pack_results_raw(results: np.ndarray, pair_ids) -> np.ndarray:
     return out
 
 
-def gather_records(local: "torch.Tensor", world: int, max_per_rank: int):
+def gather_records(local: "torch.Tensor", world: int, max_per_rank: int, force: bool = False):
     """All-gather of the per-rank record blocks (padded to max_per_rank rows); returns [world*max_per_rank, R].
     Rows whose pair id (column 19) is negative are padding."""
     import torch
@@ -51,7 +51,7 @@ def gather_records(local: "torch.Tensor", world: int, max_per_rank: int):
     else:
         pad = torch.full((max_per_rank, local.shape[1]), -1.0, dtype=local.dtype, device=local.device)
         pad[: local.shape[0]] = local
-    if world == 1:
+    if world == 1 and not force:
         return pad
     out = torch.empty((world * max_per_rank, local.shape[1]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, pad)
