@@ -1,0 +1,110 @@
+"""Size-independent properties of the HIP path at BASELINE's full frame size (VGA batches), no oracle involved:
+ground-truth recovery, bitwise invariance to batching / sub-batching / stream count / repetition, forward-backward
+consistency of the alignment, projection round trip, converter idempotence."""
+import hashlib
+
+import numpy as np
+import pytest
+
+from conftest import case_params
+
+pytestmark = pytest.mark.gpu
+
+N_PAIRS = 12
+
+
+@pytest.fixture(scope="module")
+def world():
+    from g2o_frontend_amd import api, synth
+    from test_gpu_parity import gpu_objects
+    rows, cols, K, _, _ = case_params("vga")
+    ctx = api.Context(0, rows, cols, 16)
+    _, converter, aligner = gpu_objects(ctx, "vga")
+    pairs = [synth.make_pair(200 + i, rows, cols, K) for i in range(N_PAIRS)]
+    refs = [api.Cloud(ctx, rows * cols) for _ in pairs]; curs = [api.Cloud(ctx, rows * cols) for _ in pairs]
+    converter.computeBatch(refs + curs, [p[0] for p in pairs] + [p[1] for p in pairs], raw_scale=0.001)
+    yield dict(ctx=ctx, converter=converter, aligner=aligner, pairs=pairs, refs=refs, curs=curs, rows=rows, cols=cols, K=K)
+    ctx.close()
+
+
+def _digest(results):
+    h = hashlib.sha256()
+    for r in results:
+        h.update(np.ascontiguousarray(r["T"]).tobytes()); h.update(np.ascontiguousarray(r["chi2"]).tobytes())
+        h.update(np.ascontiguousarray(r["C"]).tobytes()); h.update(np.ascontiguousarray(r["K"]).tobytes())
+    return h.hexdigest()
+
+
+def test_every_pair_recovers_the_true_motion(world):
+    res = world["aligner"].alignBatch(world["refs"], world["curs"])
+    for r, (_, _, Ttrue) in zip(res, world["pairs"]):
+        assert np.abs(r["T"][:3, 3] - Ttrue[:3, 3]).max() < 5e-3, np.abs(r["T"][:3, 3] - Ttrue[:3, 3]).max()
+        assert np.abs(r["T"][:3, :3] - Ttrue[:3, :3]).max() < 5e-3
+        assert np.abs(r["T"][:3, :3] @ r["T"][:3, :3].T - np.eye(3)).max() < 1e-5
+        assert r["chi2"][-1] < 0.2 * r["chi2"][0] and r["inliers"] > 100000 and r["iterations"] == 10
+        assert np.all(r["C"] <= r["K"]) and np.all(r["K"] <= world["rows"] * world["cols"])
+
+
+def test_results_do_not_depend_on_batching_streams_or_repetition(world):
+    ctx, aligner = world["ctx"], world["aligner"]
+    base = _digest(aligner.alignBatch(world["refs"], world["curs"]))
+    assert _digest(aligner.alignBatch(world["refs"], world["curs"])) == base              # run to run
+    for sub, streams in ((1, 1), (3, 2), (5, 1), (8, 2), (16, 1)):
+        ctx.set_subbatch(sub, sub); ctx.set_concurrency(streams)
+        assert _digest(aligner.alignBatch(world["refs"], world["curs"])) == base, (sub, streams)
+    ctx.set_subbatch(64, 64); ctx.set_concurrency(2)
+    single = []
+    for a, b in zip(world["refs"], world["curs"]):
+        aligner.setReferenceCloud(a); aligner.setCurrentCloud(b)
+        single.append(aligner.align())
+    assert _digest(single) == base                                                          # one at a time
+
+
+def test_converter_is_idempotent_and_batch_invariant(world):
+    from g2o_frontend_amd import api
+    ctx, converter = world["ctx"], world["converter"]
+    rows, cols = world["rows"], world["cols"]
+    mm = world["pairs"][0][0]
+    a, b = api.Cloud(ctx, rows * cols), api.Cloud(ctx, rows * cols)
+    converter.computeBatch([a], [mm], raw_scale=0.001)
+    depth = ctx.DepthImage_convert_16UC1_to_32FC1(mm)
+    converter.compute(b, depth)                                                             # float path, single call
+    x, y, z = a.arrays(), b.arrays(), world["refs"][0].arrays()                             # z: converted inside a 24-frame batch
+    for k in x:
+        assert np.array_equal(x[k].view(np.uint32), y[k].view(np.uint32)) and np.array_equal(x[k].view(np.uint32), z[k].view(np.uint32)), k
+
+
+def test_forward_backward_consistency(world):
+    """align(ref, cur) and align(cur, ref) are inverse motions (up to the accuracy of the registration itself)."""
+    aligner = world["aligner"]
+    for i in range(3):
+        aligner.setReferenceCloud(world["refs"][i]); aligner.setCurrentCloud(world["curs"][i])
+        f = aligner.align()["T"].astype(np.float64)
+        aligner.setReferenceCloud(world["curs"][i]); aligner.setCurrentCloud(world["refs"][i])
+        b = aligner.align()["T"].astype(np.float64)
+        assert np.abs(f @ b - np.eye(4)).max() < 3e-3
+
+
+def test_projection_round_trip_full_size(world):
+    """Projecting a cloud from the pose it was unprojected at returns its own index image (every valid pixel its own point)."""
+    from g2o_frontend_amd import api
+    from test_gpu_parity import gpu_objects
+    ctx = world["ctx"]
+    proj, converter, _ = gpu_objects(ctx, "vga")
+    depth = ctx.DepthImage_convert_16UC1_to_32FC1(world["pairs"][1][0])
+    c = api.Cloud(ctx, world["rows"] * world["cols"])
+    converter.compute(c, depth)
+    idx = converter.indexImage()
+    proj.setImageSize(world["rows"], world["cols"]); proj.setTransform(np.eye(4))
+    pi, pd = proj.project(c)
+    assert np.array_equal(pi, idx)
+    valid = idx >= 0
+    assert np.array_equal(pd[valid], depth[valid]) and np.all(pd[~valid] == np.finfo(np.float32).max)
+    assert c.size() == int(valid.sum()) and np.array_equal(idx[valid], np.arange(valid.sum()))
+
+
+def test_identical_frames_give_identity(world):
+    aligner = world["aligner"]
+    aligner.setReferenceCloud(world["refs"][0]); aligner.setCurrentCloud(world["refs"][0])
+    r = aligner.align()
+    assert np.abs(r["T"] - np.eye(4)).max() < 1e-5 and r["chi2"][-1] < 1e-3 * max(1.0, float(r["inliers"]))
