@@ -170,7 +170,7 @@ def main():
     curs = [api.Cloud(ctx, N) for _ in range(P)]
     records = torch.empty((P, shard.RECORD_FLOATS), dtype=torch.float32, device="cuda")
 
-    stage_names = ["u16_to_f32", "unproject", "integral_rows", "integral_cols", "stats", "project", "corr_linearize", "solve"]
+    stage_names = ["u16_to_f32", "unproject", "integral", "integral_rows", "integral_cols", "stats", "project", "corr_linearize", "solve"]
     stage_ms = {k: 0.0 for k in stage_names}
     stage_n = {k: 0 for k in stage_names}
     last = {}
@@ -188,12 +188,12 @@ def main():
         converter.computeBatch(refs + curs, ref_dev + cur_dev, raw_scale=0.001, prepared=conv_prep)
         t_b = time.perf_counter()
         if profile:
-            for k in stage_names[:5]:
+            for k in stage_names[:6]:
                 ms, n = ctx.stage_ms(k); stage_ms[k] += ms; stage_n[k] += n
         res = aligner.alignBatch(refs, curs, raw=True, prepared=align_prep)
         t_c = time.perf_counter()
         if profile:
-            for k in stage_names[5:]:
+            for k in stage_names[6:]:
                 ms, n = ctx.stage_ms(k); stage_ms[k] += ms; stage_n[k] += n
         records_host.numpy()[:] = shard.pack_results_raw(res, seeds)
         records.copy_(records_host, non_blocking=False)

@@ -48,6 +48,8 @@ struct pwn_hip_ctx {
   // convert workspaces (per slot)
   float* depth_ws = nullptr; int* index_ws = nullptr; int* interval_ws = nullptr; float* integral_ws = nullptr; int* rowoff_ws = nullptr;
   uint16_t* raw_ws = nullptr;
+  unsigned long long* carry_ws = nullptr; size_t carry_slot = 0; size_t rowoff_slot = 0;   // single-pass integral image: hand-over words, strip offsets
+  unsigned convert_epoch = 0; int* fault_dev = nullptr;
   // align workspaces (per slot)
   unsigned long long* zref_ws = nullptr; unsigned long long* zcur_ws = nullptr; int* curidx_ws = nullptr; double* partials_ws = nullptr; PairState* state_ws = nullptr;
   int nblocks_max = 0;
@@ -218,13 +220,13 @@ int ensure_desc(pwn_hip_ctx* ctx, int n) {
   HIPCHK(ctx, hipMalloc((void**)&ctx->frames_dev, B * sizeof(FrameDesc)), PWN_HIP_ERR_ALLOCATION);
   HIPCHK(ctx, hipMalloc((void**)&ctx->pairs_dev, B * sizeof(PairDesc)), PWN_HIP_ERR_ALLOCATION);
   HIPCHK(ctx, hipMalloc((void**)&ctx->raw_dev, B * sizeof(RawDesc)), PWN_HIP_ERR_ALLOCATION);
-  HIPCHK(ctx, hipMalloc((void**)&ctx->counts_dev, B * sizeof(int)), PWN_HIP_ERR_ALLOCATION);
+  HIPCHK(ctx, hipMalloc((void**)&ctx->counts_dev, (B + 1) * sizeof(int)), PWN_HIP_ERR_ALLOCATION);
   HIPCHK(ctx, hipMalloc((void**)&ctx->state_ws, B * sizeof(PairState)), PWN_HIP_ERR_ALLOCATION);
   HIPCHK(ctx, hipHostMalloc((void**)&ctx->frames_host, B * sizeof(FrameDesc)), PWN_HIP_ERR_ALLOCATION);
   HIPCHK(ctx, hipHostMalloc((void**)&ctx->pairs_host, B * sizeof(PairDesc)), PWN_HIP_ERR_ALLOCATION);
   HIPCHK(ctx, hipHostMalloc((void**)&ctx->raw_host, B * sizeof(RawDesc)), PWN_HIP_ERR_ALLOCATION);
   HIPCHK(ctx, hipHostMalloc((void**)&ctx->state_host, B * sizeof(PairState)), PWN_HIP_ERR_ALLOCATION);
-  HIPCHK(ctx, hipHostMalloc((void**)&ctx->counts_host, B * sizeof(int)), PWN_HIP_ERR_ALLOCATION);
+  HIPCHK(ctx, hipHostMalloc((void**)&ctx->counts_host, (B + 1) * sizeof(int)), PWN_HIP_ERR_ALLOCATION);
   if (ctx->match_dev) (void)hipFree(ctx->match_dev);
   if (ctx->match_host) (void)hipHostFree(ctx->match_host);
   ctx->match_dev = nullptr; ctx->match_host = nullptr;
@@ -242,13 +244,30 @@ int ensure_desc(pwn_hip_ctx* ctx, int n) {
 // launch sequence of the converter for the frames [base, base+n) of the uploaded descriptor array
 int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, hipStream_t st) {
   const FrameDesc* fr = ctx->frames_dev + base;
-  { StageTimer t(ctx, "unproject", st);          // ordered compaction: per-row counts and offsets
-    hipLaunchKernelGGL(k_row_count, dim3(cp.rows, n), dim3(256), 0, st, fr, cp);
-    hipLaunchKernelGGL(k_row_offsets, dim3(n), dim3(1024), 0, st, fr, cp.rows); }
-  { StageTimer t(ctx, "integral_rows", st);      // unProject + intervals + accumulate + row prefix, one pass over the depth
-    hipLaunchKernelGGL(k_unproject_integral_rows, dim3((cp.rows + kIR_Rows - 1) / kIR_Rows, n), dim3(256), 0, st, fr, cp); }
-  { StageTimer t(ctx, "integral_cols", st);
-    hipLaunchKernelGGL(k_integral_cols, dim3((cp.cols + 255) / 256, kIntegralChannels, n), dim3(256), 0, st, fr, cp.rows, cp.cols); }
+#ifndef PWN_SINGLE_PASS_MIN_FRAMES
+#define PWN_SINGLE_PASS_MIN_FRAMES 24     // measured crossover on MI355X at VGA: 16 frames 0.38 vs 0.36 ms, 32 frames 0.64 vs 0.70 ms
+#endif
+  if (n >= PWN_SINGLE_PASS_MIN_FRAMES) {
+    // throughput path: the integral planes are written once; a frame is a chain of strips * bands hand-over steps, so it
+    // needs several frames in flight to fill the device
+    { StageTimer t(ctx, "unproject", st);          // ordered compaction: valid pixels per (row, strip) and their offsets
+      hipLaunchKernelGGL(k_strip_count, dim3(cp.rows, n), dim3(256), 0, st, fr, cp);
+      hipLaunchKernelGGL(k_row_offsets, dim3(n), dim3(1024), 0, st, fr, cp.rows * strips_of(cp.cols)); }
+    { StageTimer t(ctx, "integral", st);           // unProject + intervals + the three integral-image passes
+      const unsigned epoch = ++ctx->convert_epoch;
+      if (epoch == 0) return fail(ctx, PWN_HIP_ERR_LAUNCH, "convert epoch wrapped: recreate the context");
+      hipLaunchKernelGGL(k_unproject_integral, dim3(8u * (unsigned)((n + 7) / 8) * (unsigned)strips_of(cp.cols)), dim3(256), 0, st, fr, cp, n,
+                         epoch, ctx->fault_dev); }
+  } else {
+    // latency path (single frames: tracker, makeCloud): three short, fully parallel kernels
+    { StageTimer t(ctx, "unproject", st);          // ordered compaction: per-row counts and offsets
+      hipLaunchKernelGGL(k_row_count, dim3(cp.rows, n), dim3(256), 0, st, fr, cp);
+      hipLaunchKernelGGL(k_row_offsets, dim3(n), dim3(1024), 0, st, fr, cp.rows); }
+    { StageTimer t(ctx, "integral_rows", st);      // unProject + intervals + accumulate + row prefix, one pass over the depth
+      hipLaunchKernelGGL(k_unproject_integral_rows, dim3((cp.rows + kIR_Rows - 1) / kIR_Rows, n), dim3(256), 0, st, fr, cp); }
+    { StageTimer t(ctx, "integral_cols", st);
+      hipLaunchKernelGGL(k_integral_cols, dim3((cp.cols + 255) / 256, kIntegralChannels, n), dim3(256), 0, st, fr, cp.rows, cp.cols); }
+  }
   { StageTimer t(ctx, "stats", st);
     const unsigned nblk = 8u * (unsigned)((n + 7) / 8) * (unsigned)cp.rows * (unsigned)((cp.cols + 255) / 256);
 #ifndef PWN_STATS_LDS
@@ -267,7 +286,8 @@ void fill_frame(pwn_hip_ctx* ctx, int entry, int slot, const float* depth_dev, c
   f.interval = ctx->interval_ws + (size_t)slot * ctx->N;
   f.integral = ctx->integral_ws + (size_t)slot * ctx->N * kIntegralChannels;
   (void)rows;
-  f.rowoff = ctx->rowoff_ws + (size_t)slot * (size_t)std::max(ctx->max_rows, ctx->max_cols);
+  f.rowoff = ctx->rowoff_ws + (size_t)slot * ctx->rowoff_slot;
+  f.carry = ctx->carry_ws + (size_t)slot * ctx->carry_slot;
   f.cloud = cl;
 }
 int ensure_stats(pwn_hip_ctx* ctx, pwn_hip_cloud* c) {
@@ -277,11 +297,15 @@ int ensure_stats(pwn_hip_ctx* ctx, pwn_hip_cloud* c) {
 int sync_and_counts(pwn_hip_ctx* ctx, pwn_hip_cloud* const* clouds, int n) {
   // frames_dev[0..n) must describe clouds[0..n)
   if (n > 0) {
-    hipLaunchKernelGGL(k_gather_counts, dim3((n + 255) / 256), dim3(256), 0, ctx->stream, ctx->frames_dev, n, ctx->counts_dev);
-    HIPCHK(ctx, hipMemcpyAsync(ctx->counts_host, ctx->counts_dev, sizeof(int) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
+    hipLaunchKernelGGL(k_gather_counts, dim3((n + 256) / 256), dim3(256), 0, ctx->stream, ctx->frames_dev, n, ctx->counts_dev, ctx->fault_dev);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->counts_host, ctx->counts_dev, sizeof(int) * (n + 1), hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
   }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
   collect_stage_times(ctx);
+  if (n > 0 && ctx->counts_host[n] != 0) {
+    (void)hipMemset(ctx->fault_dev, 0, sizeof(int));
+    return fail(ctx, PWN_HIP_ERR_LAUNCH, "integral image: strip hand-over timed out (results invalid)");
+  }
   for (int i = 0; i < n; ++i) {
     if (ctx->counts_host[i] > clouds[i]->d.capacity) return fail(ctx, PWN_HIP_ERR_CAPACITY, "cloud capacity smaller than the number of valid depth pixels");
     clouds[i]->n_host = ctx->counts_host[i];
@@ -408,7 +432,16 @@ int pwn_hip_ctx_create(pwn_hip_ctx** out, int device, int max_rows, int max_cols
   ALLOC(ctx->index_ws, B * N * sizeof(int));
   ALLOC(ctx->interval_ws, B * N * sizeof(int));
   ALLOC(ctx->integral_ws, B * N * kIntegralChannels * sizeof(float));
-  ALLOC(ctx->rowoff_ws, B * (size_t)std::max(max_rows, max_cols) * sizeof(int) + 64);
+  {   // any rows x cols image with rows*cols <= N and rows, cols <= M: rows*strips <= N/64 + M, strips*bands <= N/1024 + M/64 + M/16 + 1
+    const size_t M = (size_t)std::max(max_rows, max_cols);
+    ctx->rowoff_slot = N / 64 + M + 64;
+    ctx->carry_slot = (N / 1024 + M / 64 + M / 16 + 2) * (size_t)kII_Chains;
+  }
+  ALLOC(ctx->rowoff_ws, B * ctx->rowoff_slot * sizeof(int));
+  ALLOC(ctx->carry_ws, B * ctx->carry_slot * sizeof(unsigned long long));
+  ALLOC(ctx->fault_dev, sizeof(int));
+  if (hipMemset(ctx->carry_ws, 0, B * ctx->carry_slot * sizeof(unsigned long long)) != hipSuccess || hipMemset(ctx->fault_dev, 0, sizeof(int)) != hipSuccess) {
+    pwn_hip_ctx_destroy(ctx); return fail(nullptr, PWN_HIP_ERR_ALLOCATION, "hipMemset of the hand-over workspace failed"); }
   ALLOC(ctx->zref_ws, B * N * sizeof(unsigned long long));
   ALLOC(ctx->zcur_ws, B * N * sizeof(unsigned long long));
   ALLOC(ctx->curidx_ws, B * N * sizeof(int));
@@ -429,7 +462,7 @@ int pwn_hip_ctx_destroy(pwn_hip_ctx* ctx) {
   if (!ctx) return PWN_HIP_OK;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  void* dev[] = { ctx->depth_ws, ctx->raw_ws, ctx->index_ws, ctx->interval_ws, ctx->integral_ws, ctx->rowoff_ws, ctx->zref_ws, ctx->zcur_ws, ctx->curidx_ws,
+  void* dev[] = { ctx->depth_ws, ctx->raw_ws, ctx->index_ws, ctx->interval_ws, ctx->integral_ws, ctx->rowoff_ws, ctx->carry_ws, ctx->fault_dev, ctx->zref_ws, ctx->zcur_ws, ctx->curidx_ws,
                   ctx->partials_ws, ctx->state_ws, ctx->frames_dev, ctx->pairs_dev, ctx->raw_dev, ctx->counts_dev, ctx->solve_dev, ctx->counters_dev,
                   ctx->corr_ws, ctx->scratch_count, ctx->io_ws };
   for (void* p : dev) if (p) (void)hipFree(p);

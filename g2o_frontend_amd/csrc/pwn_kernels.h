@@ -60,7 +60,8 @@ struct FrameDesc {
   int* index;
   int* interval;
   float* integral;   // [10][rows*cols]
-  int* rowoff;       // [rows]
+  int* rowoff;       // [rows] (stand-alone unProject) or [rows][strips] (converter fast path)
+  unsigned long long* carry; // [strips][bands][160] strip-to-strip hand-over words of k_unproject_integral
   CloudDev cloud;
 };
 
@@ -221,9 +222,10 @@ __global__ void __launch_bounds__(1024) k_row_offsets(const FrameDesc* __restric
   if (threadIdx.x == 0) *f.cloud.count = carry;
 }
 // per-frame point counts -> one contiguous array (single D2H copy per batch)
-__global__ void k_gather_counts(const FrameDesc* __restrict__ frames, int n, int* __restrict__ out) {
+__global__ void k_gather_counts(const FrameDesc* __restrict__ frames, int n, int* __restrict__ out, const int* __restrict__ fault) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = *frames[i].cloud.count;
+  if (i == n) out[n] = *fault;      // time-out flag of k_unproject_integral rides along with the counts
 }
 // step 3: PinholePointProjector::unProject (pwn_core/pinholepointprojector.cpp:93-133) + projectIntervals (:135-147).
 // Point index = row-major rank of the valid pixel.  grid = (rows, frames), block = 256.
@@ -419,6 +421,182 @@ __global__ void __launch_bounds__(256) k_unproject_integral_rows(const FrameDesc
       }
     }
     __syncthreads();
+  }
+}
+// ------------------------------------------------------------------------------------------------------------------
+// Converter fast path, single pass: unProject + projectIntervals + PointIntegralImage::compute (all three passes of
+// pwn_core/pointintegralimage.cpp:16-43) with ONE write of the integral planes and no read of them.
+//
+// A workgroup owns one 64-column strip of one frame and walks it top to bottom in bands of 16 rows.  Per band:
+//   1. unproject the 16x64 pixels (as k_unproject; the point index comes from per-(row, strip) offsets, k_strip_count),
+//      10 channel values per pixel into LDS;
+//   2. x pass: 160 threads own the (channel, row) chains, continue them from the carry of the strip to the LEFT and hand the
+//      carry on to the strip to the right;
+//   3. y pass: 640 (channel, column) chains whose running sums live in registers from band to band; coalesced store.
+// Every chain is the reference's strictly sequential fp32 sum, so the planes are bit-identical to the three-kernel path.
+//
+// The strip-to-strip hand-over is one 64-bit word per (strip, band, chain) = launch epoch << 32 | float bits: value and
+// "ready" flag travel in the same single-copy-atomic store, so no fence is needed; a word is written once per launch (no
+// slot reuse inside a launch, hence no back-pressure), stale words carry an older epoch.  Forward progress: strip s waits
+// only for strip s-1 of the same frame, which has a smaller workgroup id and is therefore dispatched before it; the poll is
+// bounded (kSpinLimit), a starved chain raises *fault and finishes with garbage instead of hanging the device.
+// Workgroup -> (frame, strip) puts all strips of a frame on one XCD (ids are dealt round-robin over the 8 XCDs), so the
+// hand-over words stay in that XCD's L2.  grid = 8 * ceil(frames/8) * strips, block = 256.
+constexpr int kII_Chains = kIntegralChannels * kIR_Rows;     // 160
+constexpr int kSpinLimit = 1 << 20;      // polls of >= 64 cycles + one L2 round trip each: ~1 s, against hand-over waits of microseconds
+__host__ __device__ __forceinline__ int strips_of(int cols) { return (cols + kIR_Cols - 1) / kIR_Cols; }
+__host__ __device__ __forceinline__ int bands_of(int rows) { return (rows + kIR_Rows - 1) / kIR_Rows; }
+
+// valid pixels per (row, 64-column strip); k_row_offsets over rows*strips entries turns them into point-index offsets.
+// grid = (rows, frames), block = 256
+__global__ void __launch_bounds__(256) k_strip_count(const FrameDesc* __restrict__ frames, ConvertParams cp) {
+  const FrameDesc& f = frames[blockIdx.y];
+  const int r = blockIdx.x, S = strips_of(cp.cols);
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  for (int s = wave; s < S; s += 4) {
+    const int c = s * kIR_Cols + lane;
+    const float d = (c < cp.cols) ? frame_depth(f, (size_t)r * cp.cols + c) : 0.f;
+    const bool valid = c < cp.cols && !(d < cp.minD || d > cp.maxD);
+    const unsigned long long bal = __ballot(valid);
+    if (lane == 0) f.rowoff[r * S + s] = __popcll(bal);
+  }
+}
+
+// workgroup barrier that orders LDS traffic only: global stores stay in flight across it (a __syncthreads() would drain them)
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+  __builtin_amdgcn_s_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+__global__ void __launch_bounds__(256) k_unproject_integral(const FrameDesc* __restrict__ frames, ConvertParams cp, int nframes,
+                                                            unsigned epoch, int* __restrict__ fault) {
+  const int rows = cp.rows, cols = cp.cols;
+  const int S = strips_of(cols), NB = bands_of(rows);
+  const unsigned j = blockIdx.x >> 3;
+  const int fi = 8 * (int)(j / (unsigned)S) + (int)(blockIdx.x & 7u), s = (int)(j % (unsigned)S);
+  if (fi >= nframes) return;
+  const FrameDesc& f = frames[fi];
+  __shared__ float tile[kIntegralChannels * kIR_Rows * kIR_Stride];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const size_t N = (size_t)rows * cols;
+  const int x0 = s * kIR_Cols, c = x0 + lane;
+  const bool chain = tid < kII_Chains;
+  const unsigned long long* csrc = f.carry + (size_t)(s - 1) * NB * kII_Chains + tid;     // only dereferenced when s > 0
+  unsigned long long* cdst = f.carry + (size_t)s * NB * kII_Chains + tid;
+  float vcarry[3] = { 0.f, 0.f, 0.f };
+  bool starved = false;
+  // the band loop is software-pipelined by one band: depth and strip offsets of band b+1 and the (speculative) hand-over word of
+  // band b are requested before the arithmetic of band b, so that a band costs one memory latency, not three in a row
+  float dn[4]; int bn[4];
+#pragma unroll
+  for (int jj = 0; jj < 4; ++jj) {
+    const int r = wave + 4 * jj;
+    const bool in = r < rows && c < cols;
+    dn[jj] = in ? frame_depth(f, (size_t)r * cols + c) : 0.f;
+    bn[jj] = (r < rows) ? f.rowoff[r * S + s] : 0;
+  }
+  for (int band = 0; band < NB; ++band) {
+    const int r0 = band * kIR_Rows;
+    float d[4]; int base[4];
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) { d[jj] = dn[jj]; base[jj] = bn[jj]; }
+    unsigned long long w = 0;
+    if (chain && s > 0) w = __hip_atomic_load(csrc + (size_t)band * kII_Chains, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int r = r0 + kIR_Rows + wave + 4 * jj;
+      const bool in = r < rows && c < cols;
+      dn[jj] = in ? frame_depth(f, (size_t)r * cols + c) : 0.f;
+      bn[jj] = (r < rows) ? f.rowoff[r * S + s] : 0;
+    }
+    // 1. unproject: wave w owns rows r0 + w + 4j
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int lr = wave + 4 * jj;
+      const int r = r0 + lr;
+      const bool in = r < rows && c < cols;
+      const float dd = d[jj];
+      const bool valid = in && !(dd < cp.minD || dd > cp.maxD);
+      const unsigned long long bal = __ballot(valid);
+      float v[kIntegralChannels];
+#pragma unroll
+      for (int k = 0; k < kIntegralChannels; ++k) v[k] = 0.f;
+      if (in) {
+        int idx = -1, itv = -1;
+        if (valid) {
+          idx = base[jj] + __popcll(bal & ((1ull << lane) - 1ull));
+          const float a = (float)c * dd, b = (float)r * dd;
+          float4 p;
+          p.x = dot4seq(cp.iKRt(0,0), a, cp.iKRt(0,1), b, cp.iKRt(0,2), dd, cp.iKRt(0,3), 1.0f);
+          p.y = dot4seq(cp.iKRt(1,0), a, cp.iKRt(1,1), b, cp.iKRt(1,2), dd, cp.iKRt(1,3), 1.0f);
+          p.z = dot4seq(cp.iKRt(2,0), a, cp.iKRt(2,1), b, cp.iKRt(2,2), dd, cp.iKRt(2,3), 1.0f);
+          p.w = 0.f;
+          if (idx < f.cloud.capacity) {
+            f.cloud.P[idx] = p;
+            v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = 1.0f;
+            v[4] = p.x * p.x; v[5] = p.x * p.y; v[6] = p.x * p.z;
+            v[7] = p.y * p.y; v[8] = p.y * p.z; v[9] = p.z * p.z;
+          }
+          const float inv = 1.0f / dd;
+          const float px = cp.ivx * inv, py = cp.ivy * inv;
+          itv = (px > py) ? (int)px : (int)py;
+        }
+        f.index[(size_t)r * cols + c] = idx;
+        f.interval[(size_t)r * cols + c] = itv;
+      }
+#pragma unroll
+      for (int k = 0; k < kIntegralChannels; ++k) tile[(k * kIR_Rows + lr) * kIR_Stride + lane] = v[k];
+    }
+    lds_barrier();
+    // 2. x pass, chain (channel = tid / 16, row = tid % 16)
+    if (chain) {
+      float carry = 0.f;
+      if (s > 0) {
+        int spins = 0;
+        while ((unsigned)(w >> 32) != epoch && !starved) {      // after one time-out this chain stops waiting: the launch is lost anyway
+          if (++spins >= kSpinLimit) { atomicExch(fault, 1); starved = true; break; }
+          __builtin_amdgcn_s_sleep(1);
+          w = __hip_atomic_load(csrc + (size_t)band * kII_Chains, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        carry = __uint_as_float((unsigned)w);
+      }
+      float* t = &tile[tid * kIR_Stride];
+#pragma unroll 1
+      for (int c0 = 0; c0 < kIR_Cols; c0 += 16) {
+        float vals[16];
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) vals[cc] = t[c0 + cc];
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) { carry = vals[cc] + carry; vals[cc] = carry; }
+#pragma unroll
+        for (int cc = 0; cc < 16; ++cc) t[c0 + cc] = vals[cc];
+      }
+      if (s + 1 < S)
+        __hip_atomic_store(cdst + (size_t)band * kII_Chains, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(carry),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    lds_barrier();
+    // 3. y pass, chain q = (channel = q / 64, column = q % 64)
+#pragma unroll
+    for (int jj = 0; jj < 3; ++jj) {
+      const int q = tid + 256 * jj;
+      if (q < kIntegralChannels * kIR_Cols) {
+        const int ch = q >> 6;
+        float vals[kIR_Rows];
+#pragma unroll
+        for (int r = 0; r < kIR_Rows; ++r) vals[r] = tile[(ch * kIR_Rows + r) * kIR_Stride + lane];
+        float vc = vcarry[jj];
+#pragma unroll
+        for (int r = 0; r < kIR_Rows; ++r) { vc = vals[r] + vc; vals[r] = vc; }
+        vcarry[jj] = vc;
+        if (c < cols) {
+          float* dst = f.integral + (size_t)ch * N + (size_t)r0 * cols + c;
+#pragma unroll
+          for (int r = 0; r < kIR_Rows; ++r) if (r0 + r < rows) dst[(size_t)r * cols] = vals[r];
+        }
+      }
+    }
+    lds_barrier();
   }
 }
 // pass 3 (pwn_core/pointintegralimage.cpp:38-43): prefix-sum along image y inside each image column, sequential.

@@ -1,4 +1,4 @@
-for lib in build/variants/lib_ppt08.so build/variants/lib_ppt16.so; do
+for lib in build/variants/*.so; do
   PWN_HIP_LIB=$PWD/$lib timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-profile > gpurun_out/b.json 2>/dev/null
   python -c "
 import json; d=json.load(open('gpurun_out/b.json')); print('$lib', round(d['value']), 'single pair ms', round(d['single_pair_latency_ms'],3))"
