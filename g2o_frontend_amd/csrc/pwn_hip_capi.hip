@@ -256,7 +256,7 @@ int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, h
     { StageTimer t(ctx, "integral", st);           // unProject + intervals + the three integral-image passes
       const unsigned epoch = ++ctx->convert_epoch;
       if (epoch == 0) return fail(ctx, PWN_HIP_ERR_LAUNCH, "convert epoch wrapped: recreate the context");
-      hipLaunchKernelGGL(k_unproject_integral, dim3(8u * (unsigned)((n + 7) / 8) * (unsigned)strips_of(cp.cols)), dim3(256), 0, st, fr, cp, n,
+      hipLaunchKernelGGL(k_unproject_integral, dim3(8u * (unsigned)((n + 7) / 8) * (unsigned)strips_of(cp.cols)), dim3(kII_Threads), 0, st, fr, cp, n,
                          epoch, ctx->fault_dev); }
   } else {
     // latency path (single frames: tracker, makeCloud): three short, fully parallel kernels

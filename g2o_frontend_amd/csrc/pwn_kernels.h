@@ -120,6 +120,14 @@ __device__ __forceinline__ float wave_sum(float v) {
   return v;
 }
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// Pointers that reach a kernel inside a descriptor struct are generic to the compiler (flat_* instructions, 64-bit VALU address
+// arithmetic, and flat traffic ties the LDS counter to the vector-memory one).  They all point to hipMalloc'ed memory: as_global()
+// says so, which gives global_* instructions with a scalar base + 32-bit lane offset.
+template <typename T> using gptr = T __attribute__((address_space(1)))*;
+template <typename T> __device__ __forceinline__ gptr<T> as_global(T* p) { return (gptr<T>)(uintptr_t)p; }
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 load4(gptr<const v4f> p) { const v4f v = *p; return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void store4(gptr<v4f> p, const float4 v) { v4f t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *p = t; }
 // force a wave-uniform value into a scalar register
 __device__ __forceinline__ float uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ Mat4 uniform_iso(const Mat4& T) {
@@ -468,8 +476,16 @@ __device__ __forceinline__ void lds_barrier() {
   __builtin_amdgcn_s_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
-__global__ void __launch_bounds__(256) k_unproject_integral(const FrameDesc* __restrict__ frames, ConvertParams cp, int nframes,
-                                                            unsigned epoch, int* __restrict__ fault) {
+// Block = 4 compute waves + 1 loader wave.  gfx950 counts vector loads and stores in ONE in-order counter (vmcnt), so a wave that
+// waits for a load also waits for every store it issued before it; the compute waves issue ~60 KB of stores per band and must not
+// wait for memory at all.  The loader wave therefore does every global read of the block (depth and strip offsets of the NEXT
+// band, hand-over words of the current one) and passes the values on through LDS; it never stores to global memory.
+#ifndef PWN_II_X
+#define PWN_II_X 0   // timing experiments only: 1 = no plane stores, 2 = no point/index/interval stores, 4 = no hand-over wait
+#endif
+constexpr int kII_Threads = 320;
+__global__ void __launch_bounds__(kII_Threads) k_unproject_integral(const FrameDesc* __restrict__ frames, ConvertParams cp, int nframes,
+                                                                    unsigned epoch, int* __restrict__ fault) {
   const int rows = cp.rows, cols = cp.cols;
   const int S = strips_of(cols), NB = bands_of(rows);
   const unsigned j = blockIdx.x >> 3;
@@ -477,89 +493,133 @@ __global__ void __launch_bounds__(256) k_unproject_integral(const FrameDesc* __r
   if (fi >= nframes) return;
   const FrameDesc& f = frames[fi];
   __shared__ float tile[kIntegralChannels * kIR_Rows * kIR_Stride];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float stage[2][kIR_Rows * kIR_Cols];     // depth of the band (metres; 0 outside the image), double-buffered
+  __shared__ int sbase[2][kIR_Rows];                  // point-index offset of (row, strip)
+  __shared__ float cin[kII_Chains];                   // x-pass carries handed over by the strip to the left
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the role branches below are wave-uniform
   const size_t N = (size_t)rows * cols;
   const int x0 = s * kIR_Cols, c = x0 + lane;
+  const bool loader = wave == 4;
   const bool chain = tid < kII_Chains;
-  const unsigned long long* csrc = f.carry + (size_t)(s - 1) * NB * kII_Chains + tid;     // only dereferenced when s > 0
-  unsigned long long* cdst = f.carry + (size_t)s * NB * kII_Chains + tid;
+  const gptr<const float> gdepth = as_global(f.depth);
+  const gptr<const uint16_t> graw = as_global(f.raw);
+  const bool is_raw = f.raw != nullptr;
+  const float raw_scale = f.raw_scale;
+  const gptr<const int> growoff = as_global((const int*)f.rowoff);
+  const gptr<int> gindex = as_global(f.index), ginterval = as_global(f.interval);
+  const gptr<float> gintegral = as_global(f.integral);
+  const gptr<v4f> gP = as_global((v4f*)f.cloud.P);
+  const gptr<unsigned long long> gcarry = as_global(f.carry);
+  const int capacity = f.cloud.capacity;
   float vcarry[3] = { 0.f, 0.f, 0.f };
   bool starved = false;
-  // the band loop is software-pipelined by one band: depth and strip offsets of band b+1 and the (speculative) hand-over word of
-  // band b are requested before the arithmetic of band b, so that a band costs one memory latency, not three in a row
-  float dn[4]; int bn[4];
+
+  // loader: request depth + offsets of band b (all loads unconditional and in flight together; pixels outside the image read
+  // element 0 and are zeroed when staged), later convert and put them into stage[b & 1]
+  unsigned bits[kIR_Rows]; int off = 0;
+  auto request_band = [&](int b) {
+    const int r0 = b * kIR_Rows;
+    if (is_raw) {
 #pragma unroll
-  for (int jj = 0; jj < 4; ++jj) {
-    const int r = wave + 4 * jj;
-    const bool in = r < rows && c < cols;
-    dn[jj] = in ? frame_depth(f, (size_t)r * cols + c) : 0.f;
-    bn[jj] = (r < rows) ? f.rowoff[r * S + s] : 0;
-  }
+      for (int i = 0; i < kIR_Rows; ++i) {
+        const int r = r0 + i;
+        const unsigned pix = (r < rows && c < cols) ? (unsigned)(r * cols + c) : 0u;
+        bits[i] = graw[pix];
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < kIR_Rows; ++i) {
+        const int r = r0 + i;
+        const unsigned pix = (r < rows && c < cols) ? (unsigned)(r * cols + c) : 0u;
+        bits[i] = __float_as_uint(gdepth[pix]);
+      }
+    }
+    const int rr = r0 + (lane & (kIR_Rows - 1));
+    off = growoff[(rr < rows ? rr : 0) * S + s];
+  };
+  auto stage_band = [&](int b) {
+    const int r0 = b * kIR_Rows;
+#pragma unroll
+    for (int i = 0; i < kIR_Rows; ++i) {
+      float d;
+      if (is_raw) d = bits[i] ? raw_scale * (float)bits[i] : 0.0f;      // DepthImage_convert_16UC1_to_32FC1 (pwn_static.cpp:54-68)
+      else d = __uint_as_float(bits[i]);
+      stage[b & 1][i * kIR_Cols + lane] = (r0 + i < rows && c < cols) ? d : 0.f;
+    }
+    sbase[b & 1][lane & (kIR_Rows - 1)] = off;       // 4 lanes write the same value
+  };
+  if (loader) { request_band(0); stage_band(0); }
+  lds_barrier();
+
   for (int band = 0; band < NB; ++band) {
     const int r0 = band * kIR_Rows;
-    float d[4]; int base[4];
+    if (loader) {
+      const int nb = (band + 1 < NB) ? band + 1 : band;        // the last band re-reads itself (unconditional loads, result unused)
+      request_band(nb);
+      if (s > 0 && !(PWN_II_X & 4)) {
+        const gptr<unsigned long long> src = gcarry + ((size_t)(s - 1) * NB + band) * kII_Chains;
 #pragma unroll
-    for (int jj = 0; jj < 4; ++jj) { d[jj] = dn[jj]; base[jj] = bn[jj]; }
-    unsigned long long w = 0;
-    if (chain && s > 0) w = __hip_atomic_load(csrc + (size_t)band * kII_Chains, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int r = r0 + kIR_Rows + wave + 4 * jj;
-      const bool in = r < rows && c < cols;
-      dn[jj] = in ? frame_depth(f, (size_t)r * cols + c) : 0.f;
-      bn[jj] = (r < rows) ? f.rowoff[r * S + s] : 0;
-    }
-    // 1. unproject: wave w owns rows r0 + w + 4j
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int lr = wave + 4 * jj;
-      const int r = r0 + lr;
-      const bool in = r < rows && c < cols;
-      const float dd = d[jj];
-      const bool valid = in && !(dd < cp.minD || dd > cp.maxD);
-      const unsigned long long bal = __ballot(valid);
-      float v[kIntegralChannels];
-#pragma unroll
-      for (int k = 0; k < kIntegralChannels; ++k) v[k] = 0.f;
-      if (in) {
-        int idx = -1, itv = -1;
-        if (valid) {
-          idx = base[jj] + __popcll(bal & ((1ull << lane) - 1ull));
-          const float a = (float)c * dd, b = (float)r * dd;
-          float4 p;
-          p.x = dot4seq(cp.iKRt(0,0), a, cp.iKRt(0,1), b, cp.iKRt(0,2), dd, cp.iKRt(0,3), 1.0f);
-          p.y = dot4seq(cp.iKRt(1,0), a, cp.iKRt(1,1), b, cp.iKRt(1,2), dd, cp.iKRt(1,3), 1.0f);
-          p.z = dot4seq(cp.iKRt(2,0), a, cp.iKRt(2,1), b, cp.iKRt(2,2), dd, cp.iKRt(2,3), 1.0f);
-          p.w = 0.f;
-          if (idx < f.cloud.capacity) {
-            f.cloud.P[idx] = p;
-            v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = 1.0f;
-            v[4] = p.x * p.x; v[5] = p.x * p.y; v[6] = p.x * p.z;
-            v[7] = p.y * p.y; v[8] = p.y * p.z; v[9] = p.z * p.z;
+        for (int m = 0; m < 3; ++m) {
+          const int k = lane + 64 * m;
+          if (k < kII_Chains) {
+            unsigned long long w = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int spins = 0;
+            while ((unsigned)(w >> 32) != epoch && !starved) {    // after one time-out this lane stops waiting: the launch is lost anyway
+              if (++spins >= kSpinLimit) { atomicExch(fault, 1); starved = true; break; }
+              __builtin_amdgcn_s_sleep(1);
+              w = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            cin[k] = __uint_as_float((unsigned)w);
           }
-          const float inv = 1.0f / dd;
-          const float px = cp.ivx * inv, py = cp.ivy * inv;
-          itv = (px > py) ? (int)px : (int)py;
         }
-        f.index[(size_t)r * cols + c] = idx;
-        f.interval[(size_t)r * cols + c] = itv;
       }
+      stage_band(band + 1);
+    } else {
+      // 1. unproject: wave w owns rows r0 + w + 4j
 #pragma unroll
-      for (int k = 0; k < kIntegralChannels; ++k) tile[(k * kIR_Rows + lr) * kIR_Stride + lane] = v[k];
+      for (int jj = 0; jj < 4; ++jj) {
+        const int lr = wave + 4 * jj;
+        const int r = r0 + lr;
+        const bool in = r < rows && c < cols;
+        const float dd = stage[band & 1][lr * kIR_Cols + lane];
+        const bool valid = in && !(dd < cp.minD || dd > cp.maxD);
+        const unsigned long long bal = __ballot(valid);
+        float v[kIntegralChannels];
+#pragma unroll
+        for (int k = 0; k < kIntegralChannels; ++k) v[k] = 0.f;
+        if (in) {
+          int idx = -1, itv = -1;
+          if (valid) {
+            idx = sbase[band & 1][lr] + __popcll(bal & ((1ull << lane) - 1ull));
+            const float a = (float)c * dd, b = (float)r * dd;
+            float4 p;
+            p.x = dot4seq(cp.iKRt(0,0), a, cp.iKRt(0,1), b, cp.iKRt(0,2), dd, cp.iKRt(0,3), 1.0f);
+            p.y = dot4seq(cp.iKRt(1,0), a, cp.iKRt(1,1), b, cp.iKRt(1,2), dd, cp.iKRt(1,3), 1.0f);
+            p.z = dot4seq(cp.iKRt(2,0), a, cp.iKRt(2,1), b, cp.iKRt(2,2), dd, cp.iKRt(2,3), 1.0f);
+            p.w = 0.f;
+            if (idx < capacity) {
+              if (!(PWN_II_X & 2)) store4(gP + idx, p);
+              v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = 1.0f;
+              v[4] = p.x * p.x; v[5] = p.x * p.y; v[6] = p.x * p.z;
+              v[7] = p.y * p.y; v[8] = p.y * p.z; v[9] = p.z * p.z;
+            }
+            const float inv = 1.0f / dd;
+            const float px = cp.ivx * inv, py = cp.ivy * inv;
+            itv = (px > py) ? (int)px : (int)py;
+          }
+          if (!(PWN_II_X & 2) || idx == -12345) {
+          gindex[(unsigned)(r * cols + c)] = idx;
+          ginterval[(unsigned)(r * cols + c)] = itv; }
+        }
+#pragma unroll
+        for (int k = 0; k < kIntegralChannels; ++k) tile[(k * kIR_Rows + lr) * kIR_Stride + lane] = v[k];
+      }
     }
     lds_barrier();
     // 2. x pass, chain (channel = tid / 16, row = tid % 16)
     if (chain) {
-      float carry = 0.f;
-      if (s > 0) {
-        int spins = 0;
-        while ((unsigned)(w >> 32) != epoch && !starved) {      // after one time-out this chain stops waiting: the launch is lost anyway
-          if (++spins >= kSpinLimit) { atomicExch(fault, 1); starved = true; break; }
-          __builtin_amdgcn_s_sleep(1);
-          w = __hip_atomic_load(csrc + (size_t)band * kII_Chains, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        carry = __uint_as_float((unsigned)w);
-      }
+      float carry = (s > 0) ? cin[tid] : 0.f;
       float* t = &tile[tid * kIR_Stride];
 #pragma unroll 1
       for (int c0 = 0; c0 < kIR_Cols; c0 += 16) {
@@ -572,27 +632,30 @@ __global__ void __launch_bounds__(256) k_unproject_integral(const FrameDesc* __r
         for (int cc = 0; cc < 16; ++cc) t[c0 + cc] = vals[cc];
       }
       if (s + 1 < S)
-        __hip_atomic_store(cdst + (size_t)band * kII_Chains, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(carry),
+        __hip_atomic_store(gcarry + ((size_t)s * NB + band) * kII_Chains + tid,
+                           ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(carry),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     lds_barrier();
     // 3. y pass, chain q = (channel = q / 64, column = q % 64)
+    if (!loader) {
 #pragma unroll
-    for (int jj = 0; jj < 3; ++jj) {
-      const int q = tid + 256 * jj;
-      if (q < kIntegralChannels * kIR_Cols) {
-        const int ch = q >> 6;
-        float vals[kIR_Rows];
+      for (int jj = 0; jj < 3; ++jj) {
+        const int q = tid + 256 * jj;
+        if (q < kIntegralChannels * kIR_Cols) {
+          const int ch = q >> 6;
+          float vals[kIR_Rows];
 #pragma unroll
-        for (int r = 0; r < kIR_Rows; ++r) vals[r] = tile[(ch * kIR_Rows + r) * kIR_Stride + lane];
-        float vc = vcarry[jj];
+          for (int r = 0; r < kIR_Rows; ++r) vals[r] = tile[(ch * kIR_Rows + r) * kIR_Stride + lane];
+          float vc = vcarry[jj];
 #pragma unroll
-        for (int r = 0; r < kIR_Rows; ++r) { vc = vals[r] + vc; vals[r] = vc; }
-        vcarry[jj] = vc;
-        if (c < cols) {
-          float* dst = f.integral + (size_t)ch * N + (size_t)r0 * cols + c;
+          for (int r = 0; r < kIR_Rows; ++r) { vc = vals[r] + vc; vals[r] = vc; }
+          vcarry[jj] = vc;
+          if (c < cols && (!(PWN_II_X & 1) || vc == 12345.678f)) {
+            const gptr<float> dst = gintegral + ((size_t)ch * N + (size_t)r0 * cols + c);
 #pragma unroll
-          for (int r = 0; r < kIR_Rows; ++r) if (r0 + r < rows) dst[(size_t)r * cols] = vals[r];
+            for (int r = 0; r < kIR_Rows; ++r) if (r0 + r < rows) dst[(unsigned)(r * cols)] = vals[r];
+          }
         }
       }
     }
