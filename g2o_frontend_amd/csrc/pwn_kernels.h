@@ -1168,7 +1168,12 @@ __device__ __forceinline__ void candidate_consume(const PairDesc& pd, const Alig
 // usePrevTc: the acceptance tests run with the previous outer iteration's transform (Aligner::_computeStatistics re-linearizes
 // the finder's existing correspondences at the final transform, aligner.cpp:165-170).
 template <bool SAME_T>
-__global__ void __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_corr_linearize(const PairDesc* __restrict__ pairs, AlignParams ap, unsigned tag, int usePrevTc) {
+#ifdef PWN_CL_WAVES_EU
+#define PWN_CL_EU_ATTR __attribute__((amdgpu_waves_per_eu(PWN_CL_WAVES_EU, PWN_CL_WAVES_EU)))
+#else
+#define PWN_CL_EU_ATTR
+#endif
+__global__ void PWN_CL_EU_ATTR __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_corr_linearize(const PairDesc* __restrict__ pairs, AlignParams ap, unsigned tag, int usePrevTc) {
   const PairDesc& pd = pairs[blockIdx.y];
   const int N = ap.rows * ap.cols;
   const Mat4 Tc = uniform_iso(usePrevTc ? pd.state->invTcorrPrev : pd.state->invTcorr);
