@@ -946,8 +946,8 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
         const bool lastInner = (k == p->inner_iterations - 1);
         { StageTimer t(ctx, "corr_linearize", st);
           // first inner pass: the linearizer's transform is bitwise the finder's (aligner.cpp:79,84)
-          if (k == 0) hipLaunchKernelGGL(k_corr_linearize<true>, dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, tag, 0);
-          else hipLaunchKernelGGL(k_corr_linearize<false>, dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, tag, 0); }
+          if (k == 0) hipLaunchKernelGGL((k_corr_linearize<true, false>), dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, tag, 0);
+          else hipLaunchKernelGGL((k_corr_linearize<false, false>), dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, tag, 0); }
         { StageTimer t(ctx, "solve", st);
           hipLaunchKernelGGL(k_solve_update, dim3(m), dim3(256), 0, st, pr, ap, nb, lastInner ? 1 : 0); }
       }
@@ -956,7 +956,7 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
       // Aligner::_computeStatistics' extra Linearizer::update: the finder's correspondences of the last outer iteration
       // (tests with that iteration's transform) re-linearized at the final transform (aligner.cpp:165-170)
       StageTimer t(ctx, "statistics", st);
-      hipLaunchKernelGGL(k_corr_linearize<false>, dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, lastRefTag, 1);
+      hipLaunchKernelGGL((k_corr_linearize<false, true>), dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, lastRefTag, 1);   // full H for _computeStatistics
       hipLaunchKernelGGL(k_reduce_pairs, dim3(m), dim3(256), 0, st, pr, nb, ctx->stats_dev + base);
     }
     if (scores && p->outer_iterations > 0) {
@@ -1058,8 +1058,8 @@ int pwn_hip_align_with_priors(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p,
       hs.invT = invT;
       HIPCHK(ctx, hipMemcpyAsync(ctx->state_ws, &hs, sizeof(PairState), hipMemcpyHostToDevice, st), PWN_HIP_ERR_COPY);
       if (k == 0) hipLaunchKernelGGL(k_project, dim3((ref->d.capacity + 256 * kProjectPointsPerThread - 1) / (256 * kProjectPointsPerThread), 1), dim3(256), 0, st, ctx->pairs_dev, ap, 0, tag);
-      if (k == 0) hipLaunchKernelGGL(k_corr_linearize<true>, dim3(nb, 1), dim3(kAlignBlock), 0, st, ctx->pairs_dev, ap, tag, 0);
-      else hipLaunchKernelGGL(k_corr_linearize<false>, dim3(nb, 1), dim3(kAlignBlock), 0, st, ctx->pairs_dev, ap, tag, 0);
+      if (k == 0) hipLaunchKernelGGL((k_corr_linearize<true, true>), dim3(nb, 1), dim3(kAlignBlock), 0, st, ctx->pairs_dev, ap, tag, 0);
+      else hipLaunchKernelGGL((k_corr_linearize<false, true>), dim3(nb, 1), dim3(kAlignBlock), 0, st, ctx->pairs_dev, ap, tag, 0);
       hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, st, ctx->pairs_dev, nb, ctx->stats_dev);
       HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
       HIPCHK(ctx, hipMemcpyAsync(ctx->stats_host, ctx->stats_dev, sizeof(SolveOut), hipMemcpyDeviceToHost, st), PWN_HIP_ERR_COPY);

@@ -974,9 +974,19 @@ struct RegAcc {
 #ifndef PWN_LDS_ACC
 #define PWN_LDS_ACC 1
 #endif
-struct LdsAcc {
+// The Gauss-Newton step solves with Matrix6f::ldlt(), which reads the LOWER triangle of H only (aligner.cpp:112; Eigen's LDLT
+// default): the strictly upper entries of the Htt and Hrr blocks (sums 3, 6, 7 and 21, 24, 25) are never looked at, so the
+// iteration kernels do not accumulate them (FULL = false: 28 sums).  Aligner::_computeStatistics inverts the full H, the pass
+// that feeds it runs with FULL = true (34 sums).
+__host__ __device__ constexpr bool acc_is_upper(int k) { return k == 3 || k == 6 || k == 7 || k == 21 || k == 24 || k == 25; }
+__host__ __device__ constexpr int acc_slot_lower(int k) { return k - (k > 3) - (k > 6) - (k > 7) - (k > 21) - (k > 24) - (k > 25); }
+template <bool FULL> struct LdsAcc {
+  static constexpr int kSlots = FULL ? 34 : 28;
   float* base;      // &lds[threadIdx.x], stride kAlignBlock
-  __device__ __forceinline__ void add(int k, float v) const { base[k * kAlignBlock] += v; }
+  __device__ __forceinline__ void add(int k, float v) const {
+    if (!FULL && acc_is_upper(k)) return;
+    base[(FULL ? k : acc_slot_lower(k)) * kAlignBlock] += v;
+  }
 };
 // returns false if the term is rejected (non-robust kernel and chi2 above threshold)
 template <typename ACC>
@@ -1167,7 +1177,7 @@ __device__ __forceinline__ void candidate_consume(const PairDesc& pd, const Alig
 }
 // usePrevTc: the acceptance tests run with the previous outer iteration's transform (Aligner::_computeStatistics re-linearizes
 // the finder's existing correspondences at the final transform, aligner.cpp:165-170).
-template <bool SAME_T>
+template <bool SAME_T, bool FULL_H>
 #ifdef PWN_CL_WAVES_EU
 #define PWN_CL_EU_ATTR __attribute__((amdgpu_waves_per_eu(PWN_CL_WAVES_EU, PWN_CL_WAVES_EU)))
 #else
@@ -1179,10 +1189,11 @@ __global__ void PWN_CL_EU_ATTR __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_co
   const Mat4 Tc = uniform_iso(usePrevTc ? pd.state->invTcorrPrev : pd.state->invTcorr);
   const Mat4 Tl = uniform_iso(pd.state->invT);
 #if PWN_LDS_ACC
-  __shared__ float lacc[34 * kAlignBlock];            // 34 float sums per thread, column threadIdx.x (bank-conflict free)
+  constexpr int kSlots = LdsAcc<FULL_H>::kSlots;
+  __shared__ float lacc[kSlots * kAlignBlock];        // float sums of the thread in column threadIdx.x (bank-conflict free)
 #pragma unroll
-  for (int k = 0; k < 34; ++k) lacc[k * kAlignBlock + threadIdx.x] = 0.f;
-  const LdsAcc sums = { &lacc[threadIdx.x] };
+  for (int k = 0; k < kSlots; ++k) lacc[k * kAlignBlock + threadIdx.x] = 0.f;
+  const LdsAcc<FULL_H> sums = { &lacc[threadIdx.x] };
 #else
   float acc[kAccN];
 #pragma unroll
@@ -1212,7 +1223,8 @@ __global__ void PWN_CL_EU_ATTR __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_co
 #if PWN_LDS_ACC
   float acc[kAccN];
 #pragma unroll
-  for (int k = 0; k < 34; ++k) acc[k] = lacc[k * kAlignBlock + threadIdx.x];
+  for (int k = 0; k < 34; ++k)
+    acc[k] = (FULL_H || !acc_is_upper(k)) ? lacc[(FULL_H ? k : acc_slot_lower(k)) * kAlignBlock + threadIdx.x] : 0.f;
 #endif
   acc[36] = cnt[0]; acc[35] = cnt[1]; acc[34] = cnt[2];
   block_reduce_store(acc, pd.partials + (size_t)blockIdx.x * kAccN);
