@@ -63,7 +63,10 @@ struct pwn_hip_ctx {
   SolveOut* solve_dev = nullptr; int* counters_dev = nullptr; int2* corr_ws = nullptr; int* scratch_count = nullptr;
   float* io_ws = nullptr;   // N*16 floats staging for cloud up/download
   // images of the last single align
-  int img_rows = 0, img_cols = 0; bool img_valid = false; unsigned img_ref_tag = kZTag0;
+  int img_rows = 0, img_cols = 0; bool img_valid = false; unsigned img_ref_tag = kZTag0, img_cur_tag = kZTag0;
+  // z-buffer epoch tags are handed out in descending order ACROSS batch calls (a smaller tag wins, so whatever earlier calls left in
+  // the buffers reads as empty): the buffers are cleared only when the 12-bit tag space is used up, not once per alignment
+  unsigned ztag_next = 0;
   std::string err;
   bool profiling = false;
   std::map<std::string, StageAcc> stages;
@@ -201,6 +204,18 @@ int check_image(pwn_hip_ctx* ctx, int rows, int cols) {
   if (rows <= 0 || cols <= 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "image has zero size");
   if ((size_t)rows * cols > ctx->N || rows > std::max(ctx->max_rows, ctx->max_cols))
     return fail(ctx, PWN_HIP_ERR_CAPACITY, "image larger than the context was created for");
+  return PWN_HIP_OK;
+}
+// first (largest) of `need` consecutive descending z-buffer tags; clears every slot of both z-buffers when the tag space is used up
+int take_tags(pwn_hip_ctx* ctx, unsigned need, unsigned* first) {
+  if (need > kZTag0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "more projections per alignment than z-buffer epoch tags");
+  if (ctx->ztag_next < need) {
+    HIPCHK(ctx, hipMemsetAsync(ctx->zref_ws, 0xFF, (size_t)ctx->max_batch * ctx->N * 8, ctx->stream), PWN_HIP_ERR_COPY);
+    HIPCHK(ctx, hipMemsetAsync(ctx->zcur_ws, 0xFF, (size_t)ctx->max_batch * ctx->N * 8, ctx->stream), PWN_HIP_ERR_COPY);
+    ctx->ztag_next = kZTag0;
+  }
+  *first = ctx->ztag_next;
+  ctx->ztag_next -= need;
   return PWN_HIP_OK;
 }
 int align_nblocks(int N) { return (N + kAlignBlock * kPixPerThread - 1) / (kAlignBlock * kPixPerThread); }
@@ -923,7 +938,15 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
     HIPCHK(ctx, hipMemcpyAsync(ctx->state_ws, ctx->state_host, sizeof(PairState) * n, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
     if (scores) HIPCHK(ctx, hipMemsetAsync(ctx->match_dev, 0, sizeof(MatchAcc) * n, ctx->stream), PWN_HIP_ERR_COPY);
   }
-  const unsigned lastRefTag = kZTag0 - (unsigned)std::max(0, p->outer_iterations - 1);
+  // Every sub-batch takes its own block of tags (workspace slots are reused from sub-batch to sub-batch): tag0 for the
+  // current-cloud projection (its own buffer) and tag0 - i for the reference projection of outer iteration i.  A call with
+  // more sub-batches than the tag space holds falls back to the fixed tags and clears the slots of every sub-batch.
+  const unsigned tagsPerSub = (unsigned)std::max(1, p->outer_iterations);
+  const unsigned nsub = (unsigned)((n + sub - 1) / sub);
+  const bool rolling = (unsigned long long)nsub * tagsPerSub <= kZTag0;
+  unsigned tagBase = kZTag0;
+  if (rolling && nsub > 0) { if (int rc = take_tags(ctx, nsub * tagsPerSub, &tagBase)) return rc; }
+  unsigned tag0 = tagBase, lastRefTag = tag0 - (tagsPerSub - 1);
   if (int rc = plan_fork(ctx, plan)) return rc;
   for (int base = 0, kk = 0; base < n; base += sub, ++kk) {
     const int m = std::min(sub, n - base);
@@ -932,14 +955,18 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
     const size_t s0 = (size_t)plan.slot0(kk);
     int maxcap_ref = 0, maxcap_cur = 0;
     for (int i = 0; i < m; ++i) { maxcap_ref = std::max(maxcap_ref, refs[base + i]->d.capacity); maxcap_cur = std::max(maxcap_cur, curs[base + i]->d.capacity); }
-    // z-buffers start empty; slots are contiguous
-    HIPCHK(ctx, hipMemsetAsync(ctx->zref_ws + s0 * ctx->N, 0xFF, (size_t)m * ctx->N * 8, st), PWN_HIP_ERR_COPY);
-    HIPCHK(ctx, hipMemsetAsync(ctx->zcur_ws + s0 * ctx->N, 0xFF, (size_t)m * ctx->N * 8, st), PWN_HIP_ERR_COPY);
+    const unsigned subTag0 = rolling ? tagBase - (unsigned)kk * tagsPerSub : kZTag0;
+    if (!rolling) {      // z-buffers start empty; slots are contiguous
+      HIPCHK(ctx, hipMemsetAsync(ctx->zref_ws + s0 * ctx->N, 0xFF, (size_t)m * ctx->N * 8, st), PWN_HIP_ERR_COPY);
+      HIPCHK(ctx, hipMemsetAsync(ctx->zcur_ws + s0 * ctx->N, 0xFF, (size_t)m * ctx->N * 8, st), PWN_HIP_ERR_COPY);
+    }
+    if (s0 == 0 || kk == 0) { tag0 = subTag0; lastRefTag = subTag0 - (tagsPerSub - 1); }     // slot 0: what pwn_hip_align_images / pwn_hip_match_score read
+    const unsigned subLastRefTag = subTag0 - (tagsPerSub - 1);
     { StageTimer t(ctx, "project", st);
-      hipLaunchKernelGGL(k_project, dim3((maxcap_cur + 256 * kProjectPointsPerThread - 1) / (256 * kProjectPointsPerThread), m), dim3(256), 0, st, pr, ap, 1, kZTag0);
-      hipLaunchKernelGGL(k_resolve_cur, dim3(std::min((N + 255) / 256, 1024), m), dim3(256), 0, st, pr, N, kZTag0); }
+      hipLaunchKernelGGL(k_project, dim3((maxcap_cur + 256 * kProjectPointsPerThread - 1) / (256 * kProjectPointsPerThread), m), dim3(256), 0, st, pr, ap, 1, subTag0);
+      hipLaunchKernelGGL(k_resolve_cur, dim3(std::min((N + 255) / 256, 1024), m), dim3(256), 0, st, pr, N, subTag0); }
     for (int i = 0; i < p->outer_iterations; ++i) {
-      const unsigned tag = kZTag0 - (unsigned)i;      // epoch of this outer iteration's reference projection
+      const unsigned tag = subTag0 - (unsigned)i;      // epoch of this outer iteration's reference projection
       { StageTimer t(ctx, "project", st);
         hipLaunchKernelGGL(k_project, dim3((maxcap_ref + 256 * kProjectPointsPerThread - 1) / (256 * kProjectPointsPerThread), m), dim3(256), 0, st, pr, ap, 0, tag); }
       for (int k = 0; k < p->inner_iterations; ++k) {
@@ -956,12 +983,12 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
       // Aligner::_computeStatistics' extra Linearizer::update: the finder's correspondences of the last outer iteration
       // (tests with that iteration's transform) re-linearized at the final transform (aligner.cpp:165-170)
       StageTimer t(ctx, "statistics", st);
-      hipLaunchKernelGGL((k_corr_linearize<false, true>), dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, lastRefTag, 1);   // full H for _computeStatistics
+      hipLaunchKernelGGL((k_corr_linearize<false, true>), dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, subLastRefTag, 1);   // full H for _computeStatistics
       hipLaunchKernelGGL(k_reduce_pairs, dim3(m), dim3(256), 0, st, pr, nb, ctx->stats_dev + base);
     }
     if (scores && p->outer_iterations > 0) {
       StageTimer t(ctx, "match_score", st);     // the z-buffers of this sub-batch still hold the finder's last depth images
-      hipLaunchKernelGGL(k_match_score, dim3(std::min((N + 255) / 256, 256), m), dim3(256), 0, st, pr, N, lastRefTag, kZTag0, 1000.0f,
+      hipLaunchKernelGGL(k_match_score, dim3(std::min((N + 255) / 256, 256), m), dim3(256), 0, st, pr, N, subLastRefTag, subTag0, 1000.0f,
                          match_threshold, ctx->match_dev + base);
     }
     HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
@@ -998,7 +1025,7 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
   float ms = 0.f; (void)hipEventElapsedTime(&ms, ctx->t0, ctx->t1);
   for (int i = 0; i < n; ++i) results[i].total_time_ms = n > 0 ? ms / n : 0.f;
   ctx->img_rows = p->rows; ctx->img_cols = p->cols; ctx->img_valid = n > 0;
-  ctx->img_ref_tag = kZTag0 - (unsigned)std::max(0, p->outer_iterations - 1);
+  ctx->img_ref_tag = lastRefTag; ctx->img_cur_tag = tag0;
   collect_stage_times(ctx);
   return PWN_HIP_OK;
 }
@@ -1087,7 +1114,7 @@ int pwn_hip_align_with_priors(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p,
   if (it > 0) { result->error = result->chi2[it - 1]; result->inliers = result->iter_inliers[it - 1]; }
   result->n_reference = ref->n_host; result->n_current = cur->n_host;
   ctx->img_rows = p->rows; ctx->img_cols = p->cols; ctx->img_valid = true;
-  ctx->img_ref_tag = kZTag0 - (unsigned)std::max(0, p->outer_iterations - 1);
+  ctx->img_ref_tag = kZTag0 - (unsigned)std::max(0, p->outer_iterations - 1); ctx->img_cur_tag = kZTag0;
   return PWN_HIP_OK;
 }
 int pwn_hip_align_batch_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* refs, pwn_hip_cloud* const* curs,
@@ -1105,7 +1132,7 @@ int pwn_hip_match_score(pwn_hip_ctx* ctx, float threshold, pwn_hip_match_result*
   ctx->pairs_host[0].zref = ctx->zref_ws; ctx->pairs_host[0].zcur = ctx->zcur_ws;       // slot 0 = the pair of the last single align
   HIPCHK(ctx, hipMemcpyAsync(ctx->pairs_dev, ctx->pairs_host, sizeof(PairDesc), hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipMemsetAsync(ctx->match_dev, 0, sizeof(MatchAcc), ctx->stream), PWN_HIP_ERR_COPY);
-  hipLaunchKernelGGL(k_match_score, dim3(std::min((N + 255) / 256, 256), 1), dim3(256), 0, ctx->stream, ctx->pairs_dev, N, ctx->img_ref_tag, kZTag0, 1000.0f,
+  hipLaunchKernelGGL(k_match_score, dim3(std::min((N + 255) / 256, 256), 1), dim3(256), 0, ctx->stream, ctx->pairs_dev, N, ctx->img_ref_tag, ctx->img_cur_tag, 1000.0f,
                      threshold, ctx->match_dev);
   HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
   HIPCHK(ctx, hipMemcpyAsync(ctx->match_host, ctx->match_dev, sizeof(MatchAcc), hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
@@ -1129,7 +1156,7 @@ int pwn_hip_align_images(pwn_hip_ctx* ctx, int* ref_index, float* ref_depth, int
     int* di = oi ? (is_device_ptr(oi) ? oi : ctx->index_ws) : nullptr;
     float* dd = od ? (is_device_ptr(od) ? od : ctx->depth_ws) : nullptr;
     hipLaunchKernelGGL(k_zbuf_resolve, dim3((unsigned)std::min<size_t>((N + 255) / 256, 2048)), dim3(256), 0, ctx->stream, z, (int)N, di, dd,
-                       pass == 0 ? ctx->img_ref_tag : kZTag0);
+                       pass == 0 ? ctx->img_ref_tag : ctx->img_cur_tag);
     HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
     if (oi && di != oi) HIPCHK(ctx, hipMemcpyAsync(oi, di, N * 4, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
     if (od && dd != od) HIPCHK(ctx, hipMemcpyAsync(od, dd, N * 4, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);

@@ -56,9 +56,19 @@ def cloud_record(cp, depth):
 def make(name, seed):
     rows, cols, K, conv, alig = case_params(name)
     ref, cur, Ttrue, ref_mm, cur_mm = make_depth_pair(name, seed)
+    out = record(name, seed, rows, cols, K, conv, alig, ref_mm, cur_mm, Ttrue.tolist())
+    with open(os.path.join(HERE, f"pwn_{name}_seed{seed}.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    if name == "small":
+        np.savez_compressed(os.path.join(HERE, f"pwn_{name}_seed{seed}_depth.npz"), ref_mm=ref_mm, cur_mm=cur_mm)
+
+
+def record(name, seed, rows, cols, K, conv, alig, ref_mm, cur_mm, true_T):
+    """Oracle outputs of one depth pair (uint16 millimetre frames) as a JSON-able record."""
+    ref, cur = O.convert_16u_to_32f(ref_mm), O.convert_16u_to_32f(cur_mm)
     cp = O.converter_params(K=K, **conv)
     out = dict(case=name, seed=seed, rows=rows, cols=cols, K=list(K), converter=conv, aligner=alig,
-               depth_ref_sha256=sha(ref_mm), depth_cur_sha256=sha(cur_mm), true_T=Ttrue.tolist())
+               depth_ref_sha256=sha(ref_mm), depth_cur_sha256=sha(cur_mm), true_T=true_T)
     cr, out["reference"] = cloud_record(cp, ref)
     cc, out["current"] = cloud_record(cp, cur)
     pi, pd = O.project(K, np.eye(4), conv["min_distance"], conv["max_distance"], rows, cols, cr.arrays()["points"])
@@ -71,13 +81,42 @@ def make(name, seed):
             iterations=[dict(K=it["K"], C=it["C"], inliers=it["inliers"], chi2=hexf([it["chi2"]])[0], chi2_fp64=it["chi2_fp64"],
                              T_before=hexf(it["T_before"])) for it in r["iterations"]],
             cur_index_sha256=sha(r["cur_index"]), cur_depth_sha256=sha(r["cur_depth"]), ref_index_sha256=sha(r["ref_index"]))
-    with open(os.path.join(HERE, f"pwn_{name}_seed{seed}.json"), "w") as f:
-        json.dump(out, f, indent=1)
-    if name == "small":
-        np.savez_compressed(os.path.join(HERE, f"pwn_{name}_seed{seed}_depth.npz"), ref_mm=ref_mm, cur_mm=cur_mm)
     print(name, seed, "M", out["reference"]["M"], out["current"]["M"], "chi2", [it["chi2_fp64"] for it in r["iterations"]][::3])
+    return out
+
+
+# ---- real sensor data -------------------------------------------------------------------------------------------
+# The reference repository holds five 640x480 16-bit depth frames of a Kinect (g2o_frontend/PlaneEx_gui/test_images/*.pgm,
+# millimetres, the input format of pwn_simple_aligner.cpp:137); image_OLD_1 / image_OLD_2 are two views of the same scene about
+# 8 mm / 1.5 degrees apart.  They are DATA (inputs only: the reference holds no expected outputs for them), copied here as a
+# compressed array so that the parity tests also run on real sensor noise, holes and non-flat surfaces (25 000 points of
+# image_OLD_1 take the 1/lambda branch of informationmatrixcalculator.cpp:27-29, which the synthetic room hardly reaches).
+REAL_DIR = "/root/reference/g2o_frontend/PlaneEx_gui/test_images"
+REAL_PAIR = ("image_OLD_1.pgm", "image_OLD_2.pgm")
+
+
+def read_pgm16(path):
+    import re
+    b = open(path, "rb").read()
+    m = re.match(rb"P5\s+(\d+)\s+(\d+)\s+(\d+)\s", b)
+    w, h, mx = map(int, m.groups())
+    assert mx == 65535
+    return np.frombuffer(b[m.end():m.end() + 2 * w * h], dtype=">u2").reshape(h, w).astype(np.uint16)
+
+
+def make_real():
+    npz = os.path.join(HERE, "kinect_real_pair.npz")
+    if os.path.isdir(REAL_DIR):
+        ref_mm, cur_mm = (read_pgm16(os.path.join(REAL_DIR, f)) for f in REAL_PAIR)
+        np.savez_compressed(npz, ref_mm=ref_mm, cur_mm=cur_mm)
+    z = np.load(npz)
+    rows, cols, K, conv, alig = case_params("vga")
+    out = record("kinect", 0, rows, cols, K, conv, alig, z["ref_mm"], z["cur_mm"], None)
+    with open(os.path.join(HERE, "pwn_kinect_seed0.json"), "w") as f:
+        json.dump(out, f, indent=1)
 
 
 if __name__ == "__main__":
     make("small", 1)
     make("vga", 0)
+    make_real()

@@ -108,3 +108,32 @@ def test_identical_frames_give_identity(world):
     aligner.setReferenceCloud(world["refs"][0]); aligner.setCurrentCloud(world["refs"][0])
     r = aligner.align()
     assert np.abs(r["T"] - np.eye(4)).max() < 1e-5 and r["chi2"][-1] < 1e-3 * max(1.0, float(r["inliers"]))
+
+
+def test_zbuffer_epoch_tags_wrap_without_changing_results():
+    """The z-buffer epoch tags run down across calls and the buffers are cleared only when the 12-bit tag space is used up
+    (every ~372 alignments of 11 projections): results before, across and after a wrap are bitwise the same, also when the
+    image size changes in between (stale words of another geometry must read as empty)."""
+    from g2o_frontend_amd import api, synth
+    from test_gpu_parity import gpu_objects
+    rows, cols, K, _, _ = case_params("small")
+    ctx = api.Context(0, 2 * rows, 2 * cols, 4)
+    _, converter, aligner = gpu_objects(ctx, "small")
+    pairs = [synth.make_pair(300 + i, rows, cols, K) for i in range(3)]
+    refs = [api.Cloud(ctx, rows * cols) for _ in pairs]; curs = [api.Cloud(ctx, rows * cols) for _ in pairs]
+    converter.computeBatch(refs + curs, [p[0] for p in pairs] + [p[1] for p in pairs], raw_scale=0.001)
+    base = _digest(aligner.alignBatch(refs, curs))
+    for i in range(800):                      # > 2 wraps of the 4094-tag space at 11 tags per call
+        if i % 97 == 5:
+            # another image geometry on the same context in between: 2x the size, one pair
+            K2 = synth.scaled_K(synth.K_VGA, 2)
+            _, conv2, al2 = gpu_objects(ctx, "small")
+            conv2.projector().setCameraMatrix([[K2[0], 0, K2[2]], [0, K2[1], K2[3]], [0, 0, 1]]); conv2.projector().setImageSize(2 * rows, 2 * cols)
+            al2.projector().setImageSize(2 * rows, 2 * cols); al2.correspondenceFinder().setImageSize(2 * rows, 2 * cols)
+            big = synth.make_pair(7, 2 * rows, 2 * cols, K2)
+            a, b = api.Cloud(ctx, 4 * rows * cols), api.Cloud(ctx, 4 * rows * cols)
+            conv2.computeBatch([a, b], [big[0], big[1]], raw_scale=0.001)
+            r = al2.alignBatch([a], [b])[0]
+            assert r["iterations"] == 10 and r["inliers"] > 1000
+        assert _digest(aligner.alignBatch(refs, curs)) == base, i
+    ctx.close()
