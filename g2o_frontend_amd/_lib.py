@@ -109,6 +109,14 @@ PROTOTYPES = {
     "pwn_hip_iso_mul": (None, [_VP, _VP, _VP]),
     "pwn_hip_v2t": (None, [_VP, _VP]),
     "pwn_hip_t2v": (None, [_VP, _VP]),
+    "pwn_hip_cloud_gaussians": (_I, [_VP, _VP, _VP, _I, _I, _VP, _F, _F]),
+    "pwn_hip_cloud_num_gaussians": (_I, [_VP, _VP, C.POINTER(_I)]),
+    "pwn_hip_cloud_download_gaussians": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "pwn_hip_cloud_add": (_I, [_VP, _VP, _VP, _VP]),
+    "pwn_hip_merge": (_I, [_VP, _VP, _VP, _VP, _F, _F, _I, _I, _F, _F, _F, C.POINTER(_I), _VP]),
+    "pwn_hip_voxelize": (_I, [_VP, _VP, _F, C.POINTER(_I), _VP]),
+    "pwn_hip_cloud_save": (_I, [_VP, _VP, C.c_char_p, _VP, _I, _I]),
+    "pwn_hip_cloud_load": (_I, [_VP, _VP, C.c_char_p, _VP]),
     "pwn_hip_last_stage_ms": (_I, [_VP, C.c_char_p, C.POINTER(_F), C.POINTER(_I)]),
     "pwn_hip_set_profiling": (_I, [_VP, _I]),
 }

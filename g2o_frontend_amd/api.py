@@ -176,6 +176,37 @@ class Cloud:
         """pwn_core/cloud.cpp:173-186"""
         self.ctx.check(self.ctx._L.pwn_hip_cloud_transform_in_place(self.ctx.h, self.h, _ptr(_colmajor(T, 4))))
 
+    # ---- scene maintenance (pwn_core/cloud.cpp:11-171, gaussian3.h) ----
+    def numGaussians(self) -> int:
+        n = C.c_int(0)
+        self.ctx.check(self.ctx._L.pwn_hip_cloud_num_gaussians(self.ctx.h, self.h, C.byref(n)))
+        return n.value
+
+    def gaussians(self):
+        """Cloud::gaussians(): mean, cov (column-major 3x3), info_vec, info, flags (1 = moments valid, 2 = information form valid)"""
+        n = self.numGaussians()
+        out = dict(mean=np.empty((n, 3), np.float32), cov=np.empty((n, 9), np.float32), info_vec=np.empty((n, 3), np.float32),
+                   info=np.empty((n, 9), np.float32), flags=np.empty(n, np.int32))
+        self.ctx.check(self.ctx._L.pwn_hip_cloud_download_gaussians(self.ctx.h, self.h, _ptr(out["mean"]), _ptr(out["cov"]), _ptr(out["info_vec"]),
+                                                                    _ptr(out["info"]), _ptr(out["flags"])))
+        return out
+
+    def add(self, cloud: "Cloud", T=None):
+        """Cloud::add (cloud.cpp:145-171)"""
+        self.ctx.check(self.ctx._L.pwn_hip_cloud_add(self.ctx.h, self.h, cloud.h, _ptr(_colmajor(np.eye(4) if T is None else T, 4))))
+
+    def save(self, filename, T=None, step: int = 1, binary: bool = False) -> bool:
+        """Cloud::save (cloud.cpp:84-136)"""
+        self.ctx.check(self.ctx._L.pwn_hip_cloud_save(self.ctx.h, self.h, str(filename).encode(), _ptr(_colmajor(np.eye(4) if T is None else T, 4)),
+                                                      int(step), 1 if binary else 0))
+        return True
+
+    def load(self, filename):
+        """Cloud::load (cloud.cpp:25-82) -> the transform stored in the file"""
+        T = np.empty(16, np.float32)
+        self.ctx.check(self.ctx._L.pwn_hip_cloud_load(self.ctx.h, self.h, str(filename).encode(), _ptr(T)))
+        return _from_colmajor(T, 4)
+
 
 class PinholePointProjector:
     """pwn_core/pinholepointprojector.{h,cpp} + pointprojector.{h,cpp}: parameter holder; project /
@@ -187,6 +218,12 @@ class PinholePointProjector:
         self._transform = np.eye(4, dtype=np.float32)
         self._minDistance, self._maxDistance = 0.01, 6.0                        # pointprojector.cpp:9-10
         self._imageRows = self._imageCols = 0
+        self._baseline, self._alpha = 0.075, 0.1                                # pinholepointprojector.cpp:10-11 (sensor-noise Gaussians)
+
+    def baseline(self): return self._baseline
+    def setBaseline(self, v): self._baseline = float(v)
+    def alpha(self): return self._alpha
+    def setAlpha(self, v): self._alpha = float(v)
 
     def cameraMatrix(self): return self._K
     def setCameraMatrix(self, K): self._K = np.asarray(K, np.float32).reshape(3, 3).copy()
@@ -318,7 +355,7 @@ class DepthImageConverterIntegralImage:
         _set(p.sensor_offset, np.eye(4) if sensorOffset is None else sensorOffset, 4)
         return p
 
-    def compute(self, cloud: Cloud, depthImage, sensorOffset=None, keep_stats: bool = False, images: bool = True):
+    def compute(self, cloud: Cloud, depthImage, sensorOffset=None, keep_stats: bool = False, images: bool = True, gaussians: bool = False):
         ctx = cloud.ctx
         depth = depthImage if hasattr(depthImage, "data_ptr") else np.ascontiguousarray(depthImage, np.float32)
         rows, cols = depth.shape
@@ -330,6 +367,8 @@ class DepthImageConverterIntegralImage:
         itv = np.empty((rows, cols), np.int32) if images else None
         ctx.check(ctx._L.pwn_hip_convert(ctx.h, C.byref(p), _ptr(depth), rows, cols, cloud.h, _ptr(idx), _ptr(itv), 1 if keep_stats else 0))
         self._indexImage, self._intervalImage = idx, itv
+        if gaussians:      # the Gaussian half of unProject (pinholepointprojector.cpp:104-123); the reference always computes it
+            ctx.check(ctx._L.pwn_hip_cloud_gaussians(ctx.h, C.byref(p), _ptr(depth), rows, cols, cloud.h, self._projector._baseline, self._projector._alpha))
 
     @staticmethod
     def batchHandles(clouds, depthImages):
@@ -350,6 +389,68 @@ class DepthImageConverterIntegralImage:
             ctx.check(ctx._L.pwn_hip_convert_batch(ctx.h, C.byref(p), ptrs, n, rows, cols, handles))
         else:
             ctx.check(ctx._L.pwn_hip_convert_batch_u16(ctx.h, C.byref(p), ptrs, raw_scale, n, rows, cols, handles))
+
+
+class Merger:
+    """pwn_core/merger.{h,cpp}: merge(cloud, transform) fuses the points of a scene cloud that fall on the same pixel of a virtual
+    view (depth and normal compatible) through their sensor-noise Gaussians and drops the fused ones."""
+
+    def __init__(self):
+        self._distanceThreshold = 0.1                                          # merger.cpp:6-8
+        self._normalThreshold = float(np.cos(np.float32(10 * np.pi / 180.0)))
+        self._maxPointDepth = 10.0
+        self._depthImageConverter = None
+        self._rows = self._cols = 0
+        self._collapsedIndices = None
+
+    def distanceThreshold(self): return self._distanceThreshold
+    def setDistanceThreshold(self, v): self._distanceThreshold = float(v)
+    def normalThreshold(self): return self._normalThreshold
+    def setNormalThreshold(self, v): self._normalThreshold = float(v)
+    def maxPointDepth(self): return self._maxPointDepth
+    def setMaxPointDepth(self, v): self._maxPointDepth = float(v)
+    def depthImageConverter(self): return self._depthImageConverter
+    def setDepthImageConverter(self, c): self._depthImageConverter = c
+    def imageSize(self): return (self._rows, self._cols)
+    def setImageSize(self, r, c): self._rows, self._cols = int(r), int(c)
+    def collapsedIndices(self): return self._collapsedIndices
+
+    def merge(self, cloud: Cloud, transform=None):
+        assert self._rows > 0 and self._cols > 0, "Merger: _indexImage has zero size"
+        assert self._depthImageConverter is not None, "Merger: missing _depthImageConverter"
+        proj = self._depthImageConverter.projector()
+        T = np.eye(4, dtype=np.float32) if transform is None else np.asarray(transform, np.float32)
+        proj.setTransform(T)                                                    # merger.cpp:20-21 (side effect on the shared projector)
+        ctx = cloud.ctx
+        n = cloud.size()
+        collapsed = np.empty(max(n, 1), np.int32)
+        k = C.c_int(0)
+        ctx.check(ctx._L.pwn_hip_merge(ctx.h, cloud.h, _ptr(_colmajor(proj.cameraMatrix(), 3)), _ptr(_colmajor(T, 4)), proj.minDistance(),
+                                       proj.maxDistance(), self._rows, self._cols, self._distanceThreshold, self._normalThreshold,
+                                       self._maxPointDepth, C.byref(k), _ptr(collapsed)))
+        self._collapsedIndices = collapsed[:n]
+        return k.value
+
+
+class VoxelCalculator:
+    """pwn_core/voxelcalculator.{h,cpp}: keeps the first point of every voxel of side `resolution`."""
+
+    def __init__(self):
+        self._resolution = 0.01                                                 # voxelcalculator.h:53
+        self._kept = None
+
+    def resolution(self): return self._resolution
+    def setResolution(self, v): self._resolution = float(v)
+    def keptIndices(self): return self._kept
+
+    def compute(self, cloud: Cloud, resolution=None):
+        res = self._resolution if resolution is None else float(resolution)
+        ctx = cloud.ctx
+        kept = np.empty(max(cloud.size(), 1), np.int32)
+        k = C.c_int(0)
+        ctx.check(ctx._L.pwn_hip_voxelize(ctx.h, cloud.h, res, C.byref(k), _ptr(kept)))
+        self._kept = kept[:k.value].copy()
+        return k.value
 
 
 class CorrespondenceFinder:

@@ -6,7 +6,7 @@ import subprocess
 import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("pwn_hip_capi.hip", "pwn_kernels.h", "pwn_math.h")]
+SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("pwn_hip_capi.hip", "pwn_kernels.h", "pwn_math.h", "pwn_scene_kernels.h", "pwn_scene_capi.h", "pwn_stats.h")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "pwn_hip.h")
 OUT = os.path.join(_HERE, "libpwn_hip.so")
 # -ffp-contract=off: the kernels reproduce the CPU path's evaluation order; a fused multiply-add would change bits.

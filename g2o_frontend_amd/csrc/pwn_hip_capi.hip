@@ -8,6 +8,7 @@
 // returns PWN_HIP_ERR_NO_DEVICE.
 #include "../../include/pwn_hip.h"
 #include "pwn_kernels.h"
+#include "pwn_scene_kernels.h"
 #include "pwn_stats.h"
 
 #include <algorithm>
@@ -33,6 +34,11 @@ struct pwn_hip_cloud {
   CloudDev d;
   int n_host = 0;
   bool has_stats = false;
+  // scene stage (pwn_scene_capi.h): sensor-noise Gaussians, and a second set of arrays for compactions / reorderings
+  SceneBuffers sb = { nullptr, nullptr };
+  int n_gauss = 0;                       // Cloud::gaussians().size()
+  CloudDev back = {};
+  SceneBuffers sback = { nullptr, nullptr };
 };
 
 struct pwn_hip_ctx {
@@ -73,6 +79,10 @@ struct pwn_hip_ctx {
   std::vector<EventRec> pending;
   std::vector<hipEvent_t> event_pool;
   hipEvent_t t0 = nullptr, t1 = nullptr;
+  // scene-stage scratch (grown on demand)
+  int* scene_i[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr }; size_t scene_icap = 0;
+  unsigned long long* scene_k[3] = { nullptr, nullptr, nullptr }; size_t scene_kcap = 0;
+  int* scene_total = nullptr;
 };
 
 namespace {
@@ -346,6 +356,7 @@ int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, cons
     if (!c || !frames[i]) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null frame or cloud");
     if (keep_stats) { if (int rc = ensure_stats(ctx, c)) return rc; }
     c->has_stats = keep_stats != 0;
+    c->n_gauss = 0;                              // the cloud's Gaussians (if any) belonged to its previous content
     if (c->d.OmN) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH); (void)hipFree(c->d.OmN); c->d.OmN = nullptr; }
     make_omega_n_classes(p, c->d);
     const int slot = plan.slot0(i / sub) + i % sub;
@@ -490,6 +501,9 @@ int pwn_hip_ctx_destroy(pwn_hip_ctx* ctx) {
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+  for (int k = 0; k < 8; ++k) if (ctx->scene_i[k]) (void)hipFree(ctx->scene_i[k]);
+  for (int k = 0; k < 3; ++k) if (ctx->scene_k[k]) (void)hipFree(ctx->scene_k[k]);
+  if (ctx->scene_total) (void)hipFree(ctx->scene_total);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
@@ -553,7 +567,8 @@ int pwn_hip_cloud_create(pwn_hip_ctx* ctx, int capacity, pwn_hip_cloud** out) {
 int pwn_hip_cloud_destroy(pwn_hip_ctx* ctx, pwn_hip_cloud* c) {
   if (!c) return PWN_HIP_OK;
   if (ctx) (void)hipStreamSynchronize(ctx->stream);
-  void* p[] = { c->d.P, c->d.Nm, c->d.Om, c->d.OmN, c->d.St, c->d.count };
+  void* p[] = { c->d.P, c->d.Nm, c->d.Om, c->d.OmN, c->d.St, c->d.count, c->sb.G, c->sb.Gf,
+                c->back.P, c->back.Nm, c->back.Om, c->back.OmN, c->back.St, c->sback.G, c->sback.Gf };
   for (void* q : p) if (q) (void)hipFree(q);
   delete c;
   return PWN_HIP_OK;
@@ -672,9 +687,13 @@ int pwn_hip_cloud_transform_in_place(pwn_hip_ctx* ctx, pwn_hip_cloud* c, const f
     }
   }
   hipLaunchKernelGGL(k_cloud_transform, dim3((c->d.capacity + 255) / 256), dim3(256), 0, ctx->stream, c->d, m);
+  {   // StatsVector / Gaussian3fVector::transformInPlace (stats.h:125-131, gaussian3.h:65-73)
+    CloudDev d = c->d; if (!c->has_stats) d.St = nullptr;
+    const int ng = c->sb.G ? c->n_gauss : 0, cnt = std::max(c->n_host, ng);
+    if (cnt > 0 && (d.St || ng > 0)) hipLaunchKernelGGL(k_scene_transform, dim3((cnt + 255) / 256), dim3(256), 0, ctx->stream, d, c->sb, c->n_host, ng, m);
+  }
   HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
-  c->has_stats = false;
   return PWN_HIP_OK;
 }
 
@@ -1179,3 +1198,5 @@ void pwn_hip_v2t(const float v[6], float T[16]) { const Mat4 t = v2t(v); std::me
 void pwn_hip_t2v(const float T[16], float v[6]) { t2v(mat4_from(T), v); }
 
 }  // extern "C"
+
+#include "pwn_scene_capi.h"

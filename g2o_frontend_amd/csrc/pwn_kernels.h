@@ -16,6 +16,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "pwn_math.h"
 
 namespace pwnhip {
@@ -698,14 +699,14 @@ __device__ __forceinline__ int clampi(int v, int lo, int hi) { v = (v < lo) ? lo
 #endif
 // streamed-once data of k_stats (index / interval / point in, cloud out) uses non-temporal accesses so that it does not evict the
 // integral-image lines, which are the only data with reuse (each value is read by ~4 pixels)
-template <typename T> __device__ __forceinline__ T stream_load(const T* p) {
+template <typename PTR> __device__ __forceinline__ auto stream_load(PTR p) -> std::remove_cv_t<std::remove_reference_t<decltype(*p)>> {
 #if PWN_STATS_NT
   return __builtin_nontemporal_load(p);
 #else
   return *p;
 #endif
 }
-template <typename T> __device__ __forceinline__ void stream_store(T* p, T v) {
+template <typename PTR, typename T> __device__ __forceinline__ void stream_store(PTR p, T v) {
 #if PWN_STATS_NT
   __builtin_nontemporal_store(v, p);
 #else
@@ -726,12 +727,18 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
   if (c >= cp.cols) return;
   const int rows = cp.rows, cols = cp.cols;
   const size_t N = (size_t)rows * cols;
-  const size_t pix = (size_t)r * cols + c;
-  const int idx = stream_load(&f.index[pix]);
-  if (idx < 0 || idx >= f.cloud.capacity) return;
-  const int itv = stream_load(&f.interval[pix]);
+  // descriptor pointers are generic to the compiler; they all point to hipMalloc'ed memory: global_* instructions with a scalar
+  // base and a 32-bit lane offset instead of flat_* with 64-bit VALU address arithmetic (the kernel is VALU-bound)
+  const gptr<const int> gindex = as_global((const int*)f.index), ginterval = as_global((const int*)f.interval);
+  const gptr<const float> gintegral = as_global((const float*)f.integral);
+  const gptr<float> gP = as_global((float*)f.cloud.P), gN = as_global((float*)f.cloud.Nm), gOm = as_global(f.cloud.Om);
+  const int cap = f.cloud.capacity;
+  const unsigned upix = (unsigned)(r * cols + c);
+  const int idx = stream_load(gindex + upix);
+  if (idx < 0 || idx >= cap) return;
+  const int itv = stream_load(ginterval + upix);
   float4 P;
-  { const float* pp = reinterpret_cast<const float*>(&f.cloud.P[idx]); P.x = stream_load(pp); P.y = stream_load(pp + 1); P.z = stream_load(pp + 2); P.w = 0.f; }
+  { const gptr<const float> pp = gP + 4u * (unsigned)idx; P.x = stream_load(pp); P.y = stream_load(pp + 1); P.z = stream_load(pp + 2); P.w = 0.f; }
   float nx = 0.f, ny = 0.f, nz = 0.f;
   float curvature = 0.f;          // Stats() default: eigenvalues 0 -> curvature() = 0/(0+1e-9) = 0  (stats.h:21-27,98-103)
   int cls = 0;
@@ -749,16 +756,16 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
     // PointIntegralImage::getRegion (pointintegralimage.cpp:53-66)
     const int xmin = clampi(c - rad - 1, 0, cols - 1), xmax = clampi(c + rad - 1, 0, cols - 1);
     const int ymin = clampi(r - rad - 1, 0, rows - 1), ymax = clampi(r + rad - 1, 0, rows - 1);
-    const size_t oA = (size_t)ymax * cols + xmax, oB = (size_t)ymin * cols + xmin;
-    const size_t oC = (size_t)ymax * cols + xmin, oD = (size_t)ymin * cols + xmax;
+    const unsigned oA = (unsigned)(ymax * cols + xmax), oB = (unsigned)(ymin * cols + xmin);
+    const unsigned oC = (unsigned)(ymax * cols + xmin), oD = (unsigned)(ymin * cols + xmax);
     float a[kIntegralChannels];
 #pragma unroll
     for (int k = 0; k < kIntegralChannels; ++k) {
-      const float* pl = f.integral + k * N;
-      float v = pl[oA];
-      v = v + pl[oB];
-      v = v - pl[oC];
-      v = v - pl[oD];
+      const gptr<const char> pl = (gptr<const char>)(gintegral + (size_t)k * N);      // plane base: scalar; lane offsets: 32-bit bytes
+      float v = *(gptr<const float>)(pl + 4u * oA);
+      v = v + *(gptr<const float>)(pl + 4u * oB);
+      v = v - *(gptr<const float>)(pl + 4u * oC);
+      v = v - *(gptr<const float>)(pl + 4u * oD);
       a[k] = v;
     }
     const int n = (int)a[3];
@@ -847,13 +854,12 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
   }
   P.w = curvature;
   {
-    float* pp = reinterpret_cast<float*>(&f.cloud.P[idx]); float* np_ = reinterpret_cast<float*>(&f.cloud.Nm[idx]);
+    const gptr<float> pp = gP + 4u * (unsigned)idx, np_ = gN + 4u * (unsigned)idx;
     stream_store(pp, P.x); stream_store(pp + 1, P.y); stream_store(pp + 2, P.z); stream_store(pp + 3, P.w);
     stream_store(np_, nx); stream_store(np_ + 1, ny); stream_store(np_ + 2, nz); stream_store(np_ + 3, __int_as_float(cls));
   }
-  const int cap = f.cloud.capacity;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) stream_store(&f.cloud.Om[(size_t)k * cap + idx], om[k]);
+  for (int k = 0; k < 9; ++k) stream_store((gptr<float>)((gptr<char>)(gOm + (size_t)k * (size_t)cap) + 4u * (unsigned)idx), om[k]);
 }
 
 // Cloud::transformInPlace on an existing device cloud (cloud.cpp:173-186); grid = ceil(cap/256)

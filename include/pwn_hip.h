@@ -270,6 +270,34 @@ int pwn_hip_align_with_priors(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p,
 void pwn_hip_compute_statistics(const float H[36], const float T[16], float mean[6], float omega[36],
                                 float* translational_eigen_ratio, float* rotational_eigen_ratio);
 
+/* ---- scene maintenance (what follows the registration path in pwn_aligner.cpp:205-208 / pwn_merger.cpp:91-94) ---------------- */
+/* The Gaussian half of PinholePointProjector::unProject(points, gaussians, index, depth) (pinholepointprojector.cpp:104-123; baseline
+ * and alpha defaults :10-11) for a cloud made by pwn_hip_convert from the same depth image and parameters, followed by
+ * Gaussian3fVector::transformInPlace(sensor_offset) (cloud.cpp:180).  The reference computes them inside every
+ * DepthImageConverter::compute; only Merger::merge consumes them, so here they are produced on request. */
+int pwn_hip_cloud_gaussians(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float* depth, int rows, int cols,
+                            pwn_hip_cloud* cloud, float baseline, float alpha);
+int pwn_hip_cloud_num_gaussians(pwn_hip_ctx* ctx, const pwn_hip_cloud* cloud, int* n);       /* Cloud::gaussians().size() */
+/* host arrays: mean n*3, cov n*9 (column-major 3x3), info_vec n*3, info n*9, flags n (1 = moments valid, 2 = information form valid:
+ * the two lazily evaluated forms of basemath/gaussian.h:9-94); any pointer may be NULL */
+int pwn_hip_cloud_download_gaussians(pwn_hip_ctx* ctx, const pwn_hip_cloud* cloud, float* mean, float* cov, float* info_vec, float* info,
+                                     int* flags);
+/* Cloud::add (cloud.cpp:145-171): append a copy of `src` transformed by T (Cloud::transformInPlace) to `dst` */
+int pwn_hip_cloud_add(pwn_hip_ctx* ctx, pwn_hip_cloud* dst, const pwn_hip_cloud* src, const float T[16]);
+/* Merger::merge (merger.cpp:15-119).  K, min/max_distance: the projector of the merger's DepthImageConverter (merger.cpp:20-23),
+ * T: its pose; thresholds: merger.cpp:6-8.  collapsed (optional, host, old size) receives Merger::_collapsedIndices. */
+int pwn_hip_merge(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud, const float K[9], const float T[16], float min_distance, float max_distance,
+                  int rows, int cols, float distance_threshold, float normal_threshold, float max_point_depth, int* new_size,
+                  int* collapsed);
+/* VoxelCalculator::compute (voxelcalculator.cpp:15-73): the first point of every voxel survives, output sorted by voxel indices
+ * (the intended lexicographic order; the reference's IndexComparator, voxelcalculator.h:41-48, is not a strict weak ordering).
+ * kept (optional, host) receives the original indices of the survivors in output order. */
+int pwn_hip_voxelize(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud, float resolution, int* new_size, int* kept);
+/* Cloud::save / Cloud::load (cloud.cpp:11-136): "PWNCLOUD n binary" header, t2v(T) line, POINTWITHSTATS text records or the
+ * reference's 176-byte binary records (object layout of Point / Normal / Stats, non-data bytes zeroed) */
+int pwn_hip_cloud_save(pwn_hip_ctx* ctx, const pwn_hip_cloud* cloud, const char* filename, const float T[16], int step, int binary);
+int pwn_hip_cloud_load(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud, const char* filename, float T_out[16]);
+
 /* ------------------------------------------------------------------ helpers ------------------ */
 /* PinholePointProjector::_updateMatrices (pinholepointprojector.cpp:17-31): KRt, iKRt (4x4), iK (3x3) */
 void pwn_hip_projector_matrices(const float K[9], const float T[16], float KRt[16], float iKRt[16], float iK[9]);

@@ -92,6 +92,19 @@ def lib():
         L.orc_iso_inverse.argtypes = [C.c_void_p] * 2
         L.orc_iso_mul.argtypes = [C.c_void_p] * 3
         L.orc_match_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 4
+        L.orc_set_gaussians.argtypes = [C.c_int, C.c_float, C.c_float]
+        L.orc_cloud_num_gaussians.argtypes = [C.c_void_p]; L.orc_cloud_num_gaussians.restype = C.c_int
+        L.orc_cloud_get_gaussians.argtypes = [C.c_void_p] * 6
+        L.orc_cloud_transform_in_place.argtypes = [C.c_void_p, C.c_void_p]
+        L.orc_cloud_add.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_merge.restype = C.c_int
+        L.orc_merge.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]
+        L.orc_voxelize.restype = C.c_int
+        L.orc_voxelize.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_void_p]
+        L.orc_cloud_save.restype = C.c_int
+        L.orc_cloud_save.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int]
+        L.orc_cloud_load.restype = C.c_int
+        L.orc_cloud_load.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p]
         _lib = L
     return _lib
 
@@ -197,6 +210,36 @@ class Cloud:
         lib().orc_cloud_get(self.h, _p(out["points"]), _p(out["normals"]), _p(out["curvature"]), _p(st), _p(ev), _p(npts),
                             _p(out["omega_p"]), _p(out["omega_n"]))
         return out
+
+    # ---- scene maintenance ----
+    def num_gaussians(self):
+        return lib().orc_cloud_num_gaussians(self.h)
+
+    def gaussians(self):
+        n = self.num_gaussians()
+        out = dict(mean=np.empty((n, 3), np.float32), cov=np.empty((n, 9), np.float32), info_vec=np.empty((n, 3), np.float32),
+                   info=np.empty((n, 9), np.float32), flags=np.empty(n, np.int32))
+        lib().orc_cloud_get_gaussians(self.h, _p(out["mean"]), _p(out["cov"]), _p(out["info_vec"]), _p(out["info"]), _p(out["flags"]))
+        return out
+
+    def transform_in_place(self, T):
+        Tc = _f32(np.asarray(T, np.float32).T.reshape(-1))
+        lib().orc_cloud_transform_in_place(self.h, _p(Tc))
+
+    def add(self, other: "Cloud", T=None):
+        """Cloud::add (cloud.cpp:145-171)"""
+        Tc = _f32(np.asarray(np.eye(4) if T is None else T, np.float32).T.reshape(-1))
+        lib().orc_cloud_add(self.h, other.h, _p(Tc))
+
+    def save(self, filename, T=None, step=1, binary=False):
+        Tc = _f32(np.asarray(np.eye(4) if T is None else T, np.float32).T.reshape(-1))
+        return bool(lib().orc_cloud_save(self.h, str(filename).encode(), _p(Tc), int(step), int(bool(binary))))
+
+    @staticmethod
+    def load(filename):
+        c = Cloud(); T = np.empty(16, np.float32)
+        ok = bool(lib().orc_cloud_load(c.h, str(filename).encode(), _p(T)))
+        return (c if ok else None), T.reshape(4, 4).T.copy()
 
     @staticmethod
     def from_arrays(points, normals, curvature, omega_p, omega_n):
@@ -309,6 +352,29 @@ def align(p: AlignerParams, ref: Cloud, cur: Cloud, images=False):
     if images:
         out.update(ref_index=ri, ref_depth=rd, cur_index=ci, cur_depth=cd)
     return out
+
+
+def set_gaussians(enabled: bool, baseline=0.075, alpha=0.1):
+    """convert() also produces the sensor-noise Gaussians (pinholepointprojector.cpp:10-11 defaults)"""
+    lib().orc_set_gaussians(1 if enabled else 0, baseline, alpha)
+
+
+def merge(cloud: "Cloud", K, T, min_distance, max_distance, rows, cols, distance_threshold=0.1,
+          normal_threshold=float(np.cos(np.float32(10 * np.pi / 180.0))), max_point_depth=10.0):
+    """Merger::merge (merger.cpp:15-119; defaults :6-8) -> (new size, _collapsedIndices)"""
+    Kc = np.array([K[0], 0, 0, 0, K[1], 0, K[2], K[3], 1], np.float32)
+    Tc = _f32(np.asarray(T, np.float32).T.reshape(-1))
+    collapsed = np.empty(len(cloud), np.int32)
+    k = lib().orc_merge(cloud.h, _p(Kc), _p(Tc), min_distance, max_distance, rows, cols, distance_threshold, normal_threshold,
+                        max_point_depth, _p(collapsed))
+    return k, collapsed
+
+
+def voxelize(cloud: "Cloud", resolution=0.01, literal=False):
+    """VoxelCalculator::compute -> (new size, original indices of the survivors in output order)"""
+    kept = np.empty(max(1, len(cloud)), np.int32)
+    k = lib().orc_voxelize(cloud.h, resolution, 1 if literal else 0, _p(kept))
+    return k, kept[:k].copy()
 
 
 def match_score(ref_depth, cur_depth, threshold=50.0):

@@ -401,10 +401,41 @@ struct Projector {
 
 }  // namespace
 
+/* basemath/gaussian.h:9-94 (Gaussian<float,3>): moments and information form, each cached lazily behind a flag */
+struct Gauss {
+  M3 cov, info; float mean[3], infoVec[3]; bool momentsUpdated, infoUpdated;
+  void updateMoments() {                               /* gaussian.h:73-79 */
+    if (momentsUpdated) return;
+    cov = m3_inverse(info);
+    m3_mul_v3(cov, infoVec, mean);
+    momentsUpdated = true;
+  }
+  void updateInfo() {                                  /* gaussian.h:81-87 */
+    if (infoUpdated) return;
+    info = m3_inverse(cov);
+    m3_mul_v3(info, mean, infoVec);
+    infoUpdated = true;
+  }
+  void addInformation(Gauss& g) {                      /* gaussian.h:47-53 (g's information form is computed and cached in g) */
+    updateInfo();
+    g.updateInfo();
+    for (int k = 0; k < 9; ++k) info.m[k] = info.m[k] + g.info.m[k];
+    for (int k = 0; k < 3; ++k) infoVec[k] = infoVec[k] + g.infoVec[k];
+    momentsUpdated = false;
+  }
+  static Gauss fromMoments(const float m[3], const M3& c) {   /* gaussian.h:34-45, useInfoForm = false */
+    Gauss g; std::memset(&g, 0, sizeof(g));
+    for (int k = 0; k < 3; ++k) g.mean[k] = m[k];
+    g.cov = c; g.momentsUpdated = true; g.infoUpdated = false;
+    return g;
+  }
+};
+
 struct orc_cloud {
   std::vector<V4> points, normals;
   std::vector<Stats> stats;
   std::vector<M4> omegaP, omegaN;
+  std::vector<Gauss> gaussians;      /* sensor-noise Gaussians of unProject (pinholepointprojector.cpp:114-123); empty unless requested */
 };
 
 namespace {
@@ -547,6 +578,17 @@ void cloud_transform_in_place(orc_cloud* c, const float Tin[16]) {
   for (size_t i = 0; i < M; ++i) { V4 p = m4_mul_v4(m, c->points[i]); p.v[3] = 1.0f; c->points[i] = p; }
   for (size_t i = 0; i < c->normals.size(); ++i) { V4 n = m4_mul_v4(m, c->normals[i]); n.v[3] = 0.0f; c->normals[i] = n; }
   for (size_t i = 0; i < c->stats.size(); ++i) c->stats[i].m = m4_mul(m, c->stats[i].m);   /* stats.h:125-131 */
+  {                                                                                        /* gaussian3.h:65-73 */
+    M3 R; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R(i,j) = m(i,j);
+    M3 Rt; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rt(i,j) = R(j,i);
+    for (size_t i = 0; i < c->gaussians.size(); ++i) {
+      Gauss& g = c->gaussians[i];
+      g.updateMoments();
+      float mu[3]; m3_mul_v3(R, g.mean, mu);
+      for (int k = 0; k < 3; ++k) mu[k] = mu[k] + m(k,3);
+      g = Gauss::fromMoments(mu, m3_mul(m3_mul(R, g.cov), Rt));
+    }
+  }
   M4 T = m; for (int i = 0; i < 4; ++i) { T(3,i) = 0.f; T(i,3) = 0.f; }
   const M4 Tt = m4_transpose(T);
   for (size_t i = 0; i < c->omegaP.size(); ++i) { M4 o = m4_mul(m4_mul(T, c->omegaP[i]), Tt); info_zero_border(o); c->omegaP[i] = o; }   /* informationmatrix.h:111-121 */
@@ -735,8 +777,9 @@ void orc_cloud_get(const orc_cloud* c, float* points, float* normals, float* cur
     if (stats) std::memcpy(stats + 16 * i, c->stats[i].m.m, 64);
     if (eigenvalues) std::memcpy(eigenvalues + 3 * i, c->stats[i].eig, 12);
     if (npoints) npoints[i] = c->stats[i].n;
-    if (omega_p) std::memcpy(omega_p + 16 * i, c->omegaP[i].m, 64);
-    if (omega_n) std::memcpy(omega_n + 16 * i, c->omegaN[i].m, 64);
+    /* a loaded cloud has no information matrices (cloud.cpp:25-82 fills points, normals and stats only): report zeros */
+    if (omega_p) { if (i < c->omegaP.size()) std::memcpy(omega_p + 16 * i, c->omegaP[i].m, 64); else std::memset(omega_p + 16 * i, 0, 64); }
+    if (omega_n) { if (i < c->omegaN.size()) std::memcpy(omega_n + 16 * i, c->omegaN[i].m, 64); else std::memset(omega_n + 16 * i, 0, 64); }
   }
 }
 void orc_cloud_set(orc_cloud* c, int n, const float* points, const float* normals, const float* curvature,
@@ -749,6 +792,32 @@ void orc_cloud_set(orc_cloud* c, int n, const float* points, const float* normal
     std::memcpy(c->omegaP[i].m, omega_p + 16 * i, 64);
     std::memcpy(c->omegaN[i].m, omega_n + 16 * i, 64);
   }
+}
+
+/* The Gaussian part of PinholePointProjector::unProject(points, gaussians, index, depth) (pinholepointprojector.cpp:104-123,
+ * baseline / alpha defaults :10-11): per valid pixel the sensor-noise covariance (iK J) diag(3, 3, zVariation) (iK J)^T around the point. */
+static int g_with_gaussians = 0;
+static float g_baseline = 0.075f, g_alpha = 0.1f;
+static void unproject_gaussians(const orc_converter_params* p, const float* depth, int rows, int cols, const std::vector<V4>& points,
+                                std::vector<Gauss>& gaussians) {
+  const M4 I = m4_identity();
+  Projector pr = make_projector(p->K, I.m, p->min_distance, p->max_distance);
+  gaussians.resize(points.size());
+  const float fB = g_baseline * pr.K(0,0);
+  size_t count = 0;
+  for (int r = 0; r < rows; ++r)
+    for (int c = 0; c < cols; ++c) {
+      const float z = depth[(size_t)r * cols + c];
+      if (z < pr.minD || z > pr.maxD) continue;
+      const float zVariation = (g_alpha * z * z) / (fB + z * g_alpha);
+      M3 J; J(0,0) = z; J(0,1) = 0.f; J(0,2) = (float)c; J(1,0) = 0.f; J(1,1) = z; J(1,2) = (float)r; J(2,0) = 0.f; J(2,1) = 0.f; J(2,2) = 1.f;
+      J = m3_mul(pr.iK, J);
+      const float d[3] = { 3.0f, 3.0f, zVariation };
+      M3 JD; for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) JD(i,k) = J(i,k) * d[k];
+      M3 Jt; for (int i = 0; i < 3; ++i) for (int k = 0; k < 3; ++k) Jt(i,k) = J(k,i);
+      gaussians[count] = Gauss::fromMoments(points[count].v, m3_mul(JD, Jt));
+      ++count;
+    }
 }
 
 int orc_unproject(const orc_converter_params* p, const float* depth, int rows, int cols, float* points, int* index_image) {
@@ -784,6 +853,8 @@ void orc_convert(const orc_converter_params* p, const float* depth, int rows, in
   cloud->points.resize(N);
   const int M = orc_unproject(p, depth, rows, cols, reinterpret_cast<float*>(cloud->points.data()), idx.data());
   cloud->points.resize(M);
+  cloud->gaussians.clear();
+  if (g_with_gaussians) unproject_gaussians(p, depth, rows, cols, cloud->points, cloud->gaussians);
   orc_project_intervals(p, depth, rows, cols, itv.data());
   stats_compute(p, idx.data(), itv.data(), rows, cols, cloud->points, cloud->normals, cloud->stats);
   info_compute(p, cloud->stats, cloud->normals, cloud->omegaP, cloud->omegaN);
@@ -1059,6 +1130,205 @@ int orc_num_threads(void) {
 #else
   return 1;
 #endif
+}
+
+}  // extern "C"
+
+/* =============================================================================================================
+ * Scene maintenance: Cloud::add, Merger::merge, VoxelCalculator::compute, Cloud::save/load
+ * ============================================================================================================= */
+#include <fstream>
+#include <sstream>
+#include <map>
+#include <string>
+
+extern "C" {
+
+/* convert() also fills the cloud's Gaussians (the reference always does: depthimageconverterintegralimage.cpp:39; here it is a
+ * switch so that the timed CPU baseline measures the same work as the GPU path, which produces them on request only) */
+void orc_set_gaussians(int enabled, float baseline, float alpha) { g_with_gaussians = enabled ? 1 : 0; g_baseline = baseline; g_alpha = alpha; }
+int orc_cloud_num_gaussians(const orc_cloud* c) { return (int)c->gaussians.size(); }
+/* per Gaussian: mean[3] cov[9] (column-major) infoVec[3] info[9] flags (1 = moments valid, 2 = information valid); any pointer may be NULL */
+void orc_cloud_get_gaussians(const orc_cloud* c, float* mean, float* cov, float* info_vec, float* info, int* flags) {
+  for (size_t i = 0; i < c->gaussians.size(); ++i) {
+    const Gauss& g = c->gaussians[i];
+    if (mean) std::memcpy(mean + 3 * i, g.mean, 12);
+    if (cov) std::memcpy(cov + 9 * i, g.cov.m, 36);
+    if (info_vec) std::memcpy(info_vec + 3 * i, g.infoVec, 12);
+    if (info) std::memcpy(info + 9 * i, g.info.m, 36);
+    if (flags) flags[i] = (g.momentsUpdated ? 1 : 0) | (g.infoUpdated ? 2 : 0);
+  }
+}
+void orc_cloud_transform_in_place(orc_cloud* c, const float T[16]) { cloud_transform_in_place(c, T); }
+
+/* Cloud::add (cloud.cpp:145-171): append a transformed copy */
+void orc_cloud_add(orc_cloud* dst, const orc_cloud* src, const float T[16]) {
+  orc_cloud tmp = *src;
+  cloud_transform_in_place(&tmp, T);
+  const size_t k = dst->points.size();
+  dst->points.resize(k + tmp.points.size()); dst->normals.resize(k + tmp.normals.size()); dst->stats.resize(k + tmp.stats.size());
+  dst->omegaP.resize(k + tmp.omegaP.size()); dst->omegaN.resize(k + tmp.omegaN.size());
+  dst->gaussians.resize(k + tmp.gaussians.size());
+  for (size_t i = 0; i < tmp.points.size(); ++i) {
+    dst->points[k + i] = tmp.points[i]; dst->normals[k + i] = tmp.normals[i]; dst->stats[k + i] = tmp.stats[i];
+    if (!tmp.omegaP.empty()) { dst->omegaP[k + i] = tmp.omegaP[i]; dst->omegaN[k + i] = tmp.omegaN[i]; }
+    if (!tmp.gaussians.empty()) dst->gaussians[k + i] = tmp.gaussians[i];
+  }
+}
+
+/* Merger::merge (merger.cpp:15-119).  K, min/max distance: the converter's projector; T: the projector pose.  collapsed (optional,
+ * size of the cloud before the merge) receives _collapsedIndices.  Returns the new size.  As in the reference the Gaussian vector is
+ * compacted in place but NOT resized (merger.cpp:108-112): its tail keeps stale entries. */
+int orc_merge(orc_cloud* c, const float K[9], const float T[16], float min_distance, float max_distance, int rows, int cols,
+              float distance_threshold, float normal_threshold, float max_point_depth, int* collapsed_out) {
+  Projector pr = make_projector(K, T, min_distance, max_distance);
+  const int n = (int)c->points.size();
+  std::vector<int> indexImage((size_t)rows * cols); std::vector<float> depthImage((size_t)rows * cols);
+  project_points(pr, rows, cols, c->points.data(), n, indexImage.data(), depthImage.data());
+  std::vector<int> collapsed(n, -1);
+  for (int i = 0; i < n; ++i) {
+    const V4 currentPoint = c->points[i];
+    const V4 currentNormal = c->normals[i];
+    int r = -1, cc = -1; float depth = 0.0f;
+    pr.project(cc, r, depth, currentPoint);
+    if (depth < 0 || depth > max_point_depth || r < 0 || r >= rows || cc < 0 || cc >= cols) continue;
+    const float targetZ = depthImage[(size_t)r * cols + cc];
+    const int targetIndex = indexImage[(size_t)r * cols + cc];
+    if (targetIndex < 0) continue;
+    const V4& targetNormal = c->normals[targetIndex];
+    if (targetIndex == i) collapsed[i] = i;
+    else if (std::fabs(depth - targetZ) < distance_threshold && dot4(currentNormal, targetNormal) > normal_threshold) {
+      c->gaussians[targetIndex].addInformation(c->gaussians[i]);
+      collapsed[i] = targetIndex;
+    }
+  }
+  int k = 0;
+  for (int i = 0; i < n; ++i) {
+    const int ci = collapsed[i];
+    if (ci == i) { Gauss& g = c->gaussians[i]; g.updateMoments(); for (int a = 0; a < 3; ++a) c->points[i].v[a] = g.mean[a]; }
+    if (ci < 0 || ci == i) {
+      c->points[k] = c->points[i]; c->normals[k] = c->normals[i]; c->stats[k] = c->stats[i];
+      c->omegaP[k] = c->omegaP[i]; c->omegaN[k] = c->omegaN[i]; c->gaussians[k] = c->gaussians[i];
+      ++k;
+    }
+  }
+  c->points.resize(k); c->normals.resize(k); c->stats.resize(k); c->omegaP.resize(k); c->omegaN.resize(k);
+  if (collapsed_out) std::memcpy(collapsed_out, collapsed.data(), sizeof(int) * (size_t)n);
+  return k;
+}
+
+/* VoxelCalculator::compute (voxelcalculator.cpp:15-73): keeps the first point (lowest index) that falls into each voxel, in the
+ * iteration order of a std::map keyed by the voxel indices.
+ * literal = 1: std::map with the reference's IndexComparator (voxelcalculator.h:41-48), which is NOT a strict weak ordering (its third
+ *   clause lacks indeces[0] == s.indeces[0]); what the map then does is a property of libstdc++'s red-black tree, reproduced here by
+ *   using that very container.  It can fail to find an existing voxel, so more than one point per voxel can survive.
+ * literal = 0 (canonical, what the GPU path implements): the intended lexicographic order (one point per voxel).
+ * kept (optional) receives the original indices of the surviving points, in output order.  Returns the new size. */
+}  // extern "C"
+struct VoxelKeyLiteral { int i[3]; bool operator<(const VoxelKeyLiteral& s) const {
+  if (i[0] < s.i[0]) return true;
+  if (i[0] == s.i[0] && i[1] < s.i[1]) return true;
+  if (i[1] == s.i[1] && i[2] < s.i[2]) return true;
+  return false; } };
+struct VoxelKeyCanonical { int i[3]; bool operator<(const VoxelKeyCanonical& s) const {
+  if (i[0] != s.i[0]) return i[0] < s.i[0];
+  if (i[1] != s.i[1]) return i[1] < s.i[1];
+  return i[2] < s.i[2]; } };
+template <typename KEY> static void voxel_survivors(const orc_cloud* c, float res, std::vector<int>& kept) {
+  std::map<KEY, int> acc;
+  const float inverseResolution = 1.0f / res;
+  for (size_t i = 0; i < c->points.size(); ++i) {
+    KEY s; for (int a = 0; a < 3; ++a) s.i[a] = (int)(c->points[i].v[a] * inverseResolution);
+    if (acc.find(s) == acc.end()) acc.insert(std::make_pair(s, (int)i));
+  }
+  kept.clear();
+  for (auto it = acc.begin(); it != acc.end(); ++it) kept.push_back(it->second);
+}
+extern "C" {
+int orc_voxelize(orc_cloud* c, float resolution, int literal, int* kept_out) {
+  std::vector<int> kept;
+  if (literal) voxel_survivors<VoxelKeyLiteral>(c, resolution, kept); else voxel_survivors<VoxelKeyCanonical>(c, resolution, kept);
+  orc_cloud t;
+  const bool info = c->omegaP.size() == c->points.size() && c->omegaN.size() == c->points.size();     /* voxelcalculator.cpp:54-58 */
+  const bool gauss = c->gaussians.size() == c->points.size();                                         /* :62-64 */
+  for (int idx : kept) {
+    t.points.push_back(c->points[idx]); t.normals.push_back(c->normals[idx]); t.stats.push_back(c->stats[idx]);
+    if (info) { t.omegaP.push_back(c->omegaP[idx]); t.omegaN.push_back(c->omegaN[idx]); }
+    if (gauss) t.gaussians.push_back(c->gaussians[idx]);
+  }
+  *c = t;
+  if (kept_out) std::memcpy(kept_out, kept.data(), sizeof(int) * kept.size());
+  return (int)kept.size();
+}
+
+/* Cloud::save (cloud.cpp:84-136).  Text records exactly as the reference writes them (operator<< on floats, precision 6).  The
+ * reference's binary records are raw dumps of Point / Normal / Stats objects (32 + 32 + 112 bytes on x86-64 Itanium ABI, including
+ * each object's vptr and padding); here the same offsets are written with the non-data bytes zeroed. */
+static void put_obj(std::ostream& os, const float* v4) { char rec[32]; std::memset(rec, 0, 32); std::memcpy(rec + 16, v4, 16); os.write(rec, 32); }
+static void put_stats(std::ostream& os, const Stats& st) {
+  char rec[112]; std::memset(rec, 0, 112);
+  std::memcpy(rec + 16, st.m.m, 64); std::memcpy(rec + 80, &st.n, 4); std::memcpy(rec + 84, st.eig, 12);
+  rec[96] = st.curvatureComputed ? 1 : 0; std::memcpy(rec + 100, &st.curv, 4);
+  os.write(rec, 112);
+}
+int orc_cloud_save(const orc_cloud* c, const char* filename, const float T[16], int step, int binary) {
+  std::ofstream os(filename);
+  if (!os) return 0;
+  os << "PWNCLOUD " << c->points.size() / step << " " << (binary ? true : false) << std::endl;
+  float tv[6]; t2v(m4_load(T), tv);
+  os << tv[0] << " " << tv[1] << " " << tv[2] << " " << tv[3] << " " << tv[4] << " " << tv[5] << " " << std::endl;
+  for (size_t i = 0; i < c->points.size(); i += step) {
+    if (!binary) {
+      os << "POINTWITHSTATS ";
+      for (int k = 0; k < 3; ++k) os << c->points[i].v[k] << " ";
+      for (int k = 0; k < 3; ++k) os << c->normals[i].v[k] << " ";
+      for (int r = 0; r < 4; ++r) for (int cc = 0; cc < 4; ++cc) os << c->stats[i].m(r, cc) << " ";
+      os << std::endl;
+    } else {
+      put_obj(os, c->points[i].v); put_obj(os, c->normals[i].v); put_stats(os, c->stats[i]);
+    }
+  }
+  return os.good() ? 1 : 0;
+}
+/* Cloud::load (cloud.cpp:25-82) */
+int orc_cloud_load(orc_cloud* c, const char* filename, float T_out[16]) {
+  std::ifstream is(filename);
+  if (!is) return 0;
+  c->points.clear(); c->normals.clear();
+  char buf[1024];
+  is.getline(buf, 1024);
+  std::istringstream ls(buf);
+  std::string tag; size_t numPoints = 0; bool binary = false;
+  ls >> tag;
+  if (tag != "PWNCLOUD") return 0;
+  ls >> numPoints >> binary;
+  c->points.assign(numPoints, V4{ {0, 0, 0, 1} }); c->normals.assign(numPoints, V4{ {0, 0, 0, 0} }); c->stats.assign(numPoints, Stats());
+  is.getline(buf, 1024);
+  std::istringstream lst(buf);
+  float tv[6] = {0, 0, 0, 0, 0, 0};
+  lst >> tv[0] >> tv[1] >> tv[2] >> tv[3] >> tv[4] >> tv[5];
+  const M4 T = v2t(tv); std::memcpy(T_out, T.m, sizeof(T.m));
+  size_t k = 0;
+  while (k < c->points.size() && is.good()) {
+    if (!binary) {
+      is.getline(buf, 1024);
+      std::istringstream l2(buf);
+      std::string s2; l2 >> s2;
+      if (s2 != "POINTWITHSTATS") continue;
+      for (int i = 0; i < 3 && l2; ++i) l2 >> c->points[k].v[i];
+      for (int i = 0; i < 3 && l2; ++i) l2 >> c->normals[k].v[i];
+      for (int r = 0; r < 4 && l2; ++r) for (int cc = 0; cc < 4 && l2; ++cc) l2 >> c->stats[k].m(r, cc);
+    } else {
+      char rec[176];
+      is.read(rec, 176);
+      std::memcpy(c->points[k].v, rec + 16, 16); std::memcpy(c->normals[k].v, rec + 32 + 16, 16);
+      const char* st = rec + 64; Stats& S = c->stats[k];
+      std::memcpy(S.m.m, st + 16, 64); std::memcpy(&S.n, st + 80, 4); std::memcpy(S.eig, st + 84, 12);
+      S.curvatureComputed = st[96] != 0; std::memcpy(&S.curv, st + 100, 4);
+    }
+    ++k;
+  }
+  return is.good() ? 1 : 0;
 }
 
 }  // extern "C"

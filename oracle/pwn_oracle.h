@@ -162,6 +162,27 @@ void orc_eigen3(const float A[9], float evals[3], float evecs[9]);
 /* pivoted LDLT solve of a 6x6 (col-major) system, fp32 */
 void orc_ldlt_solve6(const float H[36], const float b[6], float x[6]);
 
+/* ---- scene maintenance ---- */
+/* orc_convert also fills the cloud's sensor-noise Gaussians (pinholepointprojector.cpp:104-123); off by default so that the timed
+ * CPU baseline does the same work as the GPU path (which produces them on request) */
+void orc_set_gaussians(int enabled, float baseline, float alpha);
+int  orc_cloud_num_gaussians(const orc_cloud* c);
+/* per Gaussian: mean[3], cov[9] column-major, info_vec[3], info[9], flags (1 = moments valid, 2 = information form valid) */
+void orc_cloud_get_gaussians(const orc_cloud* c, float* mean, float* cov, float* info_vec, float* info, int* flags);
+/* Cloud::transformInPlace (cloud.cpp:173-186) incl. Gaussian3fVector::transformInPlace (gaussian3.h:65-73) */
+void orc_cloud_transform_in_place(orc_cloud* c, const float T[16]);
+/* Cloud::add (cloud.cpp:145-171) */
+void orc_cloud_add(orc_cloud* dst, const orc_cloud* src, const float T[16]);
+/* Merger::merge (merger.cpp:15-119); collapsed (optional) = _collapsedIndices; returns the new cloud size */
+int  orc_merge(orc_cloud* c, const float K[9], const float T[16], float min_distance, float max_distance, int rows, int cols,
+               float distance_threshold, float normal_threshold, float max_point_depth, int* collapsed);
+/* VoxelCalculator::compute (voxelcalculator.cpp:15-73); literal = 1: std::map with the reference's comparator (not a strict weak
+ * order), literal = 0: the intended lexicographic order.  kept (optional) = original indices of the survivors in output order */
+int  orc_voxelize(orc_cloud* c, float resolution, int literal, int* kept);
+/* Cloud::save / Cloud::load (cloud.cpp:11-136) */
+int  orc_cloud_save(const orc_cloud* c, const char* filename, const float T[16], int step, int binary);
+int  orc_cloud_load(orc_cloud* c, const char* filename, float T_out[16]);
+
 /* number of OpenMP threads the parallel (results-identical) loops will use */
 int  orc_num_threads(void);
 void orc_set_num_threads(int n);
