@@ -357,7 +357,7 @@ __global__ void k_set_count(int* count, const int* total) { *count = *total; }
 
 // ------------------------------------------------------------------------------------------------------------------
 // VoxelCalculator::compute (voxelcalculator.cpp:15-73), canonical semantics (the intended lexicographic order of the voxel
-// indices; see oracle/pwn_oracle.cpp orc_voxelize for what the reference's comparator does to a std::map): the FIRST point
+// indices; the reference's IndexComparator, voxelcalculator.h:41-48, is not a strict weak ordering -- DESIGN.md): the FIRST point
 // (lowest index) of every voxel survives; survivors come out sorted by (ix, iy, iz).
 // Keys: the three truncated indices biased into 21 bits each -> one 63-bit word, so integer order == lexicographic order.
 constexpr int kVoxelBits = 21, kVoxelBias = 1 << 20;
