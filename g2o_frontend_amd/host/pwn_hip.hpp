@@ -108,6 +108,14 @@ class Cloud {
   std::vector<float> pointInformationMatrix() const { std::vector<float> v(size() * 16); _ctx->check(pwn_hip_cloud_download(_ctx->handle(), _h, nullptr, nullptr, nullptr, v.data(), nullptr)); return v; }
   std::vector<float> normalInformationMatrix() const { std::vector<float> v(size() * 16); _ctx->check(pwn_hip_cloud_download(_ctx->handle(), _h, nullptr, nullptr, nullptr, nullptr, v.data())); return v; }
   void transformInPlace(const Isometry3f& T) { _ctx->check(pwn_hip_cloud_transform_in_place(_ctx->handle(), _h, T.data())); }   // cloud.cpp:173-186
+  // scene maintenance (cloud.cpp:11-171)
+  void add(const Cloud& cloud, const Isometry3f& T = Isometry3f::Identity()) { _ctx->check(pwn_hip_cloud_add(_ctx->handle(), _h, cloud.handle(), T.data())); }
+  bool save(const char* filename, const Isometry3f& T = Isometry3f::Identity(), int step = 1, bool binary = false) const {
+    return pwn_hip_cloud_save(_ctx->handle(), _h, filename, T.data(), step, binary ? 1 : 0) == PWN_HIP_OK;
+  }
+  bool load(Isometry3f& T, const char* filename) { return pwn_hip_cloud_load(_ctx->handle(), _h, filename, T.data()) == PWN_HIP_OK; }
+  size_t numGaussians() const { int n = 0; _ctx->check(pwn_hip_cloud_num_gaussians(_ctx->handle(), _h, &n)); return (size_t)n; }
+  Context* context() const { return _ctx; }
  private:
   Context* _ctx; pwn_hip_cloud* _h = nullptr;
 };
@@ -210,6 +218,45 @@ class DepthImageConverterIntegralImage : public DepthImageConverter {
     _ctx->check(pwn_hip_convert(_ctx->handle(), &p, depthImage.data.data(), depthImage.rows, depthImage.cols, cloud.handle(),
                                 _indexImage.data.data(), nullptr, 0));
   }
+};
+
+// merger.{h,cpp} (defaults merger.cpp:6-8)
+class Merger {
+ public:
+  float distanceThreshold() const { return _distanceThreshold; }  void setDistanceThreshold(float v) { _distanceThreshold = v; }
+  float normalThreshold() const { return _normalThreshold; }      void setNormalThreshold(float v) { _normalThreshold = v; }
+  float maxPointDepth() const { return _maxPointDepth; }          void setMaxPointDepth(float v) { _maxPointDepth = v; }
+  DepthImageConverter* depthImageConverter() const { return _depthImageConverter; }
+  void setDepthImageConverter(DepthImageConverter* c) { _depthImageConverter = c; }
+  void setImageSize(int r, int c) { _rows = r; _cols = c; }
+  const std::vector<int>& collapsedIndices() const { return _collapsedIndices; }
+  // needs the cloud's sensor-noise Gaussians (pwn_hip_cloud_gaussians after every convert that feeds the scene)
+  void merge(Cloud* cloud, Isometry3f transform = Isometry3f::Identity()) {
+    if (_rows <= 0 || _cols <= 0) throw Error(PWN_HIP_ERR_INVALID_ARGUMENT, "Merger: _indexImage has zero size");
+    if (!_depthImageConverter || !_depthImageConverter->projector()) throw Error(PWN_HIP_ERR_INVALID_ARGUMENT, "Merger: missing _depthImageConverter / projector");
+    PinholePointProjector* pp = _depthImageConverter->projector();
+    pp->setTransform(transform);                                                 // merger.cpp:20-21
+    _collapsedIndices.assign(cloud->size(), -1);
+    int k = 0;
+    Context* ctx = cloud->context();
+    ctx->check(pwn_hip_merge(ctx->handle(), cloud->handle(), pp->cameraMatrix().data(), transform.data(), pp->minDistance(), pp->maxDistance(), _rows, _cols,
+                             _distanceThreshold, _normalThreshold, _maxPointDepth, &k, _collapsedIndices.empty() ? nullptr : _collapsedIndices.data()));
+  }
+ protected:
+  float _distanceThreshold = 0.1f, _normalThreshold = std::cos(10 * (float)M_PI / 180.0f), _maxPointDepth = 10.0f;
+  DepthImageConverter* _depthImageConverter = nullptr;
+  int _rows = 0, _cols = 0;
+  std::vector<int> _collapsedIndices;
+};
+
+// voxelcalculator.{h,cpp}
+class VoxelCalculator {
+ public:
+  float resolution() const { return _resolution; }  void setResolution(float r) { _resolution = r; }
+  void compute(Cloud& cloud, float res) { const float old = _resolution; _resolution = res; compute(cloud); _resolution = old; }
+  void compute(Cloud& cloud) { int k = 0; Context* ctx = cloud.context(); ctx->check(pwn_hip_voxelize(ctx->handle(), cloud.handle(), _resolution, &k, nullptr)); }
+ protected:
+  float _resolution = 0.01f;
 };
 
 // correspondencefinder.{h,cpp} (defaults .cpp:9-18)

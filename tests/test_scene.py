@@ -264,3 +264,53 @@ def test_merge_on_real_sensor_frames(gctx, oracle):
     assert merger.merge(gscene, T) == ok and np.array_equal(merger.collapsedIndices(), ocol)
     assert ok < 0.9 * (len(o0) + len(o1))                                       # the overlap really fused (measured: 81.5 % left)
     _same_cloud(oscene, gscene)
+
+
+@pytest.mark.gpu
+def test_incremental_scene_harness(gctx, oracle):
+    """The mapping loop of pwn_aligner.cpp:150-208 on a 5-frame synthetic stream (imageScale-4 configuration): render the scene
+    into the current view, convert that rendering to a sub-scene, align the new frame against it, add the frame to the scene,
+    merge.  The HIP side is teacher-forced with the oracle's poses, so after every frame the scene clouds, the rendered depth
+    images and the sub-scene clouds are bit-identical; the HIP aligner's own relative motion matches the oracle's to 2e-4."""
+    from g2o_frontend_amd import api, synth
+    from test_gpu_parity import gpu_objects, oracle_params
+    name = "small"
+    rows, cols, K, conv, alig = case_params(name)
+    n_frames = 5
+    poses = synth.trajectory(3, n_frames)
+    depths = [oracle.convert_16u_to_32f(synth.render_depth_mm(3, poses[k], rows, cols, K, hole_stream=k)) for k in range(n_frames)]
+    cp, ap = oracle_params(oracle, name, accumulate_fp64=1)
+    proj, converter, aligner = gpu_objects(gctx, name)
+    merger = api.Merger(); merger.setDepthImageConverter(converter); merger.setImageSize(rows, cols)
+    oscene = oracle.Cloud(); gscene = api.Cloud(gctx, n_frames * rows * cols)
+    sceneT = np.eye(4, dtype=np.float32)
+    I = np.eye(4, dtype=np.float32)
+    oracle.set_gaussians(True)
+    try:
+        for k, d in enumerate(depths):
+            oc, _, _ = oracle.convert(cp, d)
+            gc = api.Cloud(gctx, rows * cols); converter.compute(gc, d, keep_stats=True, gaussians=True)
+            if k > 0:
+                # converter.projector()->setTransform(sceneT * sensorOffset); project(scaledIndexImage, scaledDepth, referenceScene->points())
+                oidx, odep = oracle.project(K, sceneT, conv["min_distance"], conv["max_distance"], rows, cols, oscene.arrays()["points"])
+                proj.setImageSize(rows, cols); proj.setTransform(sceneT)
+                gidx, gdep = proj.project(gscene)
+                assert np.array_equal(oidx, gidx) and np.array_equal(odep.view(np.uint32), gdep.view(np.uint32)), k
+                osub, _, _ = oracle.convert(cp, odep)
+                gsub = api.Cloud(gctx, rows * cols); converter.compute(gsub, gdep, keep_stats=True, gaussians=True)
+                _same_cloud(osub, gsub)
+                o = oracle.align(ap, osub, oc)
+                aligner.setReferenceCloud(gsub); aligner.setCurrentCloud(gc); aligner.setInitialGuess(I)
+                g = aligner.align()
+                assert np.abs(g["T"] - o["T"]).max() < 2e-4, (k, np.abs(g["T"] - o["T"]).max())
+                sceneT = oracle.iso_mul(sceneT, o["T"])                       # teacher-forced: the oracle's pose on both sides
+                sceneT[3] = (0, 0, 0, 1)
+                true = np.linalg.inv(poses[0]) @ poses[k]
+                assert np.abs(sceneT[:3, 3] - true[:3, 3]).max() < 0.02, k   # the loop tracks the synthetic camera
+            oscene.add(oc, sceneT); gscene.add(gc, sceneT)
+            ok, ocol = oracle.merge(oscene, K, sceneT, conv["min_distance"], conv["max_distance"], rows, cols)
+            assert merger.merge(gscene, sceneT) == ok and np.array_equal(merger.collapsedIndices(), ocol), k
+            _same_cloud(oscene, gscene)
+    finally:
+        oracle.set_gaussians(False)
+    assert len(oscene) < 0.6 * sum(int(((d >= conv["min_distance"]) & (d <= conv["max_distance"])).sum()) for d in depths)
