@@ -628,7 +628,7 @@ int pwn_hip_cloud_download(pwn_hip_ctx* ctx, const pwn_hip_cloud* c, float* poin
     if (omega_p) hop.assign((size_t)n * 16, 0.f);
     if (omega_n) hon.assign((size_t)n * 16, 0.f);
     for (int i = 0; i < n; ++i) {
-      int cls; std::memcpy(&cls, &Nm[4 * i + 3], 4);
+      int cls; std::memcpy(&cls, &Nm[4 * i + 3], 4); cls &= kClsMask;
       for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) {
         if (omega_p) hop[(size_t)16 * i + r + 4 * q] = Om[(size_t)(3 * r + q) * cap + i];
         if (omega_n) {

@@ -43,6 +43,8 @@ __host__ __device__ __forceinline__ float zkey_depth(unsigned long long k, unsig
   return ((unsigned)(k >> 52) == tag) ? __builtin_bit_cast(float, (unsigned)((k >> kZIndexBits) & 0x7fffffffu)) : FLT_MAX;
 }
 
+constexpr int kClsMask = 3;      // Nm[i].w: class of the normal information matrix (0 zero, 1 flat, 2 non-flat)
+
 struct CloudDev {
   float4* P;
   float4* Nm;
@@ -120,6 +122,23 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
   return v;
 }
+// Butterfly sum of the 64 lanes in the order xor 1, 2, 4, 8, 16, 32 with DPP operands instead of ds_bpermute (no LDS crossbar, no
+// lgkmcnt waits): after each step all lanes of a group hold the group's sum, so quad_perm / row_half_mirror / row_mirror bring
+// "the other half's sum" exactly like an xor shuffle would, and row_bcast15 / row_bcast31 add the neighbouring rows' sums
+// (a + b == b + a bitwise): the fixed tree ((..(l0+l1)+(l2+l3)..)) of a wave, so results stay bitwise reproducible.
+// The total is valid in lane 63 only.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_f32(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_sum_dpp_lane63(float v) {
+  v += dpp_f32<0xB1, 0xF>(v);       // quad_perm [1,0,3,2]  (xor 1)
+  v += dpp_f32<0x4E, 0xF>(v);       // quad_perm [2,3,0,1]  (xor 2)
+  v += dpp_f32<0x141, 0xF>(v);      // row_half_mirror      (the other quad of the 8)
+  v += dpp_f32<0x140, 0xF>(v);      // row_mirror           (the other 8 of the row)
+  v += dpp_f32<0x142, 0xA>(v);      // row_bcast15 -> rows 1 and 3
+  v += dpp_f32<0x143, 0xC>(v);      // row_bcast31 -> rows 2 and 3
+  return v;
+}
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // Pointers that reach a kernel inside a descriptor struct are generic to the compiler (flat_* instructions, 64-bit VALU address
 // arithmetic, and flat traffic ties the LDS counter to the vector-memory one).  They all point to hipMalloc'ed memory: as_global()
@@ -136,6 +155,16 @@ __device__ __forceinline__ Mat4 uniform_iso(const Mat4& T) {
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     r(0,c) = uniform(T(0,c)); r(1,c) = uniform(T(1,c)); r(2,c) = uniform(T(2,c));
+  }
+  r(3,0) = 0.f; r(3,1) = 0.f; r(3,2) = 0.f; r(3,3) = 1.f;
+  return r;
+}
+
+__device__ __forceinline__ Mat4 uniform_iso_global(gptr<const float> m) {      // column-major 4x4 in global memory -> SGPRs
+  Mat4 r;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    r(0,c) = uniform(m[4 * c]); r(1,c) = uniform(m[4 * c + 1]); r(2,c) = uniform(m[4 * c + 2]);
   }
   r(3,0) = 0.f; r(3,1) = 0.f; r(3,2) = 0.f; r(3,3) = 1.f;
   return r;
@@ -875,7 +904,7 @@ __global__ void __launch_bounds__(256) k_cloud_transform(CloudDev cl, Mat4 m) {
   const float ty = dot4seq(m(1,0), Nm.x, m(1,1), Nm.y, m(1,2), Nm.z, m(1,3), 0.0f);
   const float tz = dot4seq(m(2,0), Nm.x, m(2,1), Nm.y, m(2,2), Nm.z, m(2,3), 0.0f);
   Nm.x = tx; Nm.y = ty; Nm.z = tz;
-  cl.P[i] = P; cl.Nm[i] = Nm;
+  int word = __float_as_int(Nm.w) & kClsMask;
   for (int pass = 0; pass < 2; ++pass) {
     float* base = pass == 0 ? cl.Om : cl.OmN;
     if (!base) continue;
@@ -885,6 +914,8 @@ __global__ void __launch_bounds__(256) k_cloud_transform(CloudDev cl, Mat4 m) {
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) om[3 * a + b] = dot3seq(t1[3 * a], m(b,0), t1[3 * a + 1], m(b,1), t1[3 * a + 2], m(b,2));
     for (int k = 0; k < 9; ++k) base[(size_t)k * cl.capacity + i] = om[k];
   }
+  Nm.w = __int_as_float(word);
+  cl.P[i] = P; cl.Nm[i] = Nm;
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1100,12 +1131,13 @@ __device__ __forceinline__ bool correspondence_test(const AlignParams& ap, const
 }
 
 // block-level reduction of kAccN fp32 accumulators -> fp64 partial record of the block
-__device__ __forceinline__ void block_reduce_store(float* acc, double* out) {
+__device__ __forceinline__ void block_reduce_store(float* acc, double* out_generic) {
+  const gptr<double> out = as_global(out_generic);
   __shared__ float red[kAlignBlock / 64][kAccN];
 #pragma unroll
   for (int k = 0; k < kAccN; ++k) {
-    const float v = wave_sum(acc[k]);
-    if (lane_id() == 0) red[threadIdx.x >> 6][k] = v;
+    const float v = wave_sum_dpp_lane63(acc[k]);
+    if (lane_id() == 63) red[threadIdx.x >> 6][k] = v;
   }
   __syncthreads();
   if (threadIdx.x < kAccN) {
@@ -1137,20 +1169,38 @@ struct Candidate {
   int ci;
   bool valid;
 };
-__device__ __forceinline__ void candidate_load(const PairDesc& pd, int ri, int ci, int nref, int ncur, Candidate& c) {
+// The descriptor's pointers are generic to the compiler: flat_* loads, which count on BOTH the vector-memory and the LDS counter, so
+// every wait for an LDS accumulator update would also wait for the gathers of the next pixel that are meant to stay in flight.
+// They all point to hipMalloc'ed memory: as_global() -> global_* loads (vmcnt only).
+struct PairPtrs {
+  gptr<const v4f> refP, refN, curP, curN;
+  gptr<const float> curOm, curOmN;
+  gptr<const unsigned long long> zref;
+  gptr<const int> curidx;
+  unsigned cap;      // capacity of the current cloud (plane stride)
+};
+__device__ __forceinline__ PairPtrs pair_ptrs(const PairDesc& pd) {
+  PairPtrs q;
+  q.refP = as_global((const v4f*)pd.ref.P); q.refN = as_global((const v4f*)pd.ref.Nm);
+  q.curP = as_global((const v4f*)pd.cur.P); q.curN = as_global((const v4f*)pd.cur.Nm);
+  q.curOm = as_global((const float*)pd.cur.Om); q.curOmN = as_global((const float*)pd.cur.OmN);
+  q.zref = as_global((const unsigned long long*)pd.zref); q.curidx = as_global((const int*)pd.curidx);
+  q.cap = (unsigned)pd.cur.capacity;
+  return q;
+}
+__device__ __forceinline__ void candidate_load(const PairPtrs& q, int ri, int ci, int nref, int ncur, Candidate& c) {
   c.valid = !(ri < 0 || ci < 0 || ri >= nref || ci >= ncur);
   c.ci = ci;
   if (c.valid) {
-    c.rP = pd.ref.P[ri]; c.rN = pd.ref.Nm[ri]; c.cP = pd.cur.P[ci]; c.cN = pd.cur.Nm[ci];
+    c.rP = load4(q.refP + (unsigned)ri); c.rN = load4(q.refN + (unsigned)ri); c.cP = load4(q.curP + (unsigned)ci); c.cN = load4(q.curN + (unsigned)ci);
 #if PWN_OMEGA_PREFETCH
-    const size_t cap = (size_t)pd.cur.capacity;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) c.oP[k] = pd.cur.Om[k * cap + ci];
+    for (int k = 0; k < 9; ++k) c.oP[k] = q.curOm[(size_t)k * q.cap + (unsigned)ci];
 #endif
   }
 }
 template <bool SAME_T, typename ACC>
-__device__ __forceinline__ void candidate_consume(const PairDesc& pd, const AlignParams& ap, const Mat4& Tc, const Mat4& Tl,
+__device__ __forceinline__ void candidate_consume(const PairDesc& pd, const PairPtrs& q, const AlignParams& ap, const Mat4& Tc, const Mat4& Tl,
                                                   const Candidate& c, const ACC acc, float* cnt /* K, C, inliers */) {
   if (!c.valid) return;
   cnt[0] += 1.f;
@@ -1158,24 +1208,26 @@ __device__ __forceinline__ void candidate_consume(const PairDesc& pd, const Alig
   if (!correspondence_test(ap, Tc, c.rP, c.rN, c.cP, c.cN, rp, rn)) return;
   cnt[1] += 1.f;
   float oN[9];
-  const int cls = __float_as_int(c.cN.w);
+  const int word = __float_as_int(c.cN.w);
+  const int cls = word & kClsMask;
   if (pd.cur.OmN) {
-    const size_t cap = (size_t)pd.cur.capacity;
 #pragma unroll
-    for (int k = 0; k < 9; ++k) oN[k] = pd.cur.OmN[k * cap + c.ci];
+    for (int k = 0; k < 9; ++k) oN[k] = q.curOmN[(size_t)k * q.cap + (unsigned)c.ci];
   } else {
 #pragma unroll
     for (int k = 0; k < 9; ++k) oN[k] = (cls == 1) ? pd.cur.omN[0][k] : ((cls == 2) ? pd.cur.omN[1][k] : 0.f);
   }
   if (!SAME_T) { rp = iso_point(Tl, c.rP); rn = iso_normal(Tl, c.rN); }   // inner iterations > 0: the linearizer's transform moved on
-#if PWN_OMEGA_PREFETCH
-  const float* oP = c.oP;
-#else
   float oP[9];
-  {
-    const size_t cap = (size_t)pd.cur.capacity;
+#if PWN_OMEGA_PREFETCH
 #pragma unroll
-    for (int k = 0; k < 9; ++k) oP[k] = pd.cur.Om[k * cap + c.ci];
+  for (int k = 0; k < 9; ++k) oP[k] = c.oP[k];
+#else
+  {
+    const size_t cap = (size_t)q.cap;
+    const unsigned ci = (unsigned)c.ci;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) oP[k] = q.curOm[k * cap + ci];
   }
 #endif
   if (linearize_term(rp, rn, make_float3(c.cP.x, c.cP.y, c.cP.z), make_float3(c.cN.x, c.cN.y, c.cN.z), oP, oN, ap.maxChi2, ap.robust, acc))
@@ -1192,8 +1244,9 @@ template <bool SAME_T, bool FULL_H>
 __global__ void PWN_CL_EU_ATTR __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_corr_linearize(const PairDesc* __restrict__ pairs, AlignParams ap, unsigned tag, int usePrevTc) {
   const PairDesc& pd = pairs[blockIdx.y];
   const int N = ap.rows * ap.cols;
-  const Mat4 Tc = uniform_iso(usePrevTc ? pd.state->invTcorrPrev : pd.state->invTcorr);
-  const Mat4 Tl = uniform_iso(pd.state->invT);
+  const PairState* stp = pd.state;
+  const Mat4 Tc = uniform_iso_global(as_global((const float*)(usePrevTc ? stp->invTcorrPrev.m : stp->invTcorr.m)));
+  const Mat4 Tl = uniform_iso_global(as_global((const float*)stp->invT.m));
 #if PWN_LDS_ACC
   constexpr int kSlots = LdsAcc<FULL_H>::kSlots;
   __shared__ float lacc[kSlots * kAlignBlock];        // float sums of the thread in column threadIdx.x (bank-conflict free)
@@ -1207,24 +1260,25 @@ __global__ void PWN_CL_EU_ATTR __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_co
   const RegAcc sums = { acc };
 #endif
   float cnt[3] = { 0.f, 0.f, 0.f };
-  const int nref = min(*pd.ref.count, pd.ref.capacity), ncur = min(*pd.cur.count, pd.cur.capacity);
+  const int nref = min(*as_global((const int*)pd.ref.count), pd.ref.capacity), ncur = min(*as_global((const int*)pd.cur.count), pd.cur.capacity);
   const int pix0 = blockIdx.x * kPixPerThread * kAlignBlock + threadIdx.x;
+  const PairPtrs q = pair_ptrs(pd);
   auto load_indices = [&](int j, int& ri, int& ci) {
     const int pix = pix0 + j * kAlignBlock;
     ri = -1; ci = -1;
-    if (j < kPixPerThread && pix < N) { ri = zkey_index(pd.zref[pix], tag); ci = pd.curidx[pix]; }
+    if (j < kPixPerThread && pix < N) { ri = zkey_index(q.zref[(unsigned)pix], tag); ci = q.curidx[(unsigned)pix]; }
   };
   int ri1, ci1, ri2, ci2;
   load_indices(0, ri1, ci1);
   load_indices(1, ri2, ci2);
   Candidate nxt;
-  candidate_load(pd, ri1, ci1, nref, ncur, nxt);
+  candidate_load(q, ri1, ci1, nref, ncur, nxt);
 #pragma unroll 1
   for (int j = 0; j < kPixPerThread; ++j) {
     const Candidate cur = nxt;
-    candidate_load(pd, ri2, ci2, nref, ncur, nxt);       // gathers of pixel j+1: in flight during the arithmetic below
+    candidate_load(q, ri2, ci2, nref, ncur, nxt);        // gathers of pixel j+1: in flight during the arithmetic below
     load_indices(j + 2, ri2, ci2);                        // indices of pixel j+2
-    candidate_consume<SAME_T>(pd, ap, Tc, Tl, cur, sums, cnt);
+    candidate_consume<SAME_T>(pd, q, ap, Tc, Tl, cur, sums, cnt);
   }
 #if PWN_LDS_ACC
   float acc[kAccN];
@@ -1269,7 +1323,7 @@ __global__ void __launch_bounds__(kAlignBlock) k_linearize_list(CloudDev ref, Cl
     acc[35] += 1.f;
     const float4 rP = ref.P[c.x], rN = ref.Nm[c.x], cP = cur.P[c.y], cN = cur.Nm[c.y];
     float oP[9], oN[9];
-    load_omegas(cur, c.y, __float_as_int(cN.w), oP, oN);
+    load_omegas(cur, c.y, __float_as_int(cN.w) & kClsMask, oP, oN);
     const float3 rp = iso_point(Tl, rP), rn = iso_normal(Tl, rN);
     if (linearize_term(rp, rn, make_float3(cP.x, cP.y, cP.z), make_float3(cN.x, cN.y, cN.z), oP, oN, ap.maxChi2, ap.robust, RegAcc{ acc })) acc[34] += 1.f;
   }

@@ -133,7 +133,7 @@ __global__ void __launch_bounds__(256) k_cloud_append(CloudDev dst, SceneBuffers
   const int o = k + i;
   float4 P = src.P[i]; float4 Nm = src.Nm[i];
   float omP[9], omN[9];
-  const int cls = __float_as_int(Nm.w);
+  const int cls = __float_as_int(Nm.w) & kClsMask;
 #pragma unroll
   for (int q = 0; q < 9; ++q) omP[q] = src.Om[(size_t)q * src.capacity + i];
   if (src.OmN) {
@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(256) k_scene_transform(CloudDev cl, SceneBuffe
 __global__ void __launch_bounds__(256) k_expand_omega_n(CloudDev cl, float* __restrict__ out, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const int cls = __float_as_int(cl.Nm[i].w);
+  const int cls = __float_as_int(cl.Nm[i].w) & kClsMask;
 #pragma unroll
   for (int q = 0; q < 9; ++q) out[(size_t)q * cl.capacity + i] = (cls == 1) ? cl.omN[0][q] : ((cls == 2) ? cl.omN[1][q] : 0.f);
 }
