@@ -284,7 +284,9 @@ def main():
         if os.path.exists(tfile):
             try:
                 # measured per pair-iteration by the PMC passes (profiles/), scaled to the pairs one launch of this run covers
-                traffic = json.load(open(tfile)).get("k_corr_linearize_bytes_per_pair_iteration") * (P * n_it * args.steps / launches)
+                tj = json.load(open(tfile))
+                # measured at VGA; every term of the kernel's traffic is per pixel / per point, so other frame sizes scale with the pixel count
+                traffic = tj.get("k_corr_linearize_bytes_per_pair_iteration") * (N / tj.get("pixels_per_frame", 307200)) * (P * n_it * args.steps / launches)
             except Exception:
                 traffic = None
         out = {

@@ -1011,6 +1011,9 @@ struct RegAcc {
 #ifndef PWN_LDS_ACC
 #define PWN_LDS_ACC 1
 #endif
+#ifndef PWN_LDS_ATOMIC_ACC
+#define PWN_LDS_ATOMIC_ACC 0
+#endif
 // The Gauss-Newton step solves with Matrix6f::ldlt(), which reads the LOWER triangle of H only (aligner.cpp:112; Eigen's LDLT
 // default): the strictly upper entries of the Htt and Hrr blocks (sums 3, 6, 7 and 21, 24, 25) are never looked at, so the
 // iteration kernels do not accumulate them (FULL = false: 28 sums).  Aligner::_computeStatistics inverts the full H, the pass
@@ -1022,7 +1025,12 @@ template <bool FULL> struct LdsAcc {
   float* base;      // &lds[threadIdx.x], stride kAlignBlock
   __device__ __forceinline__ void add(int k, float v) const {
     if (!FULL && acc_is_upper(k)) return;
+#if PWN_LDS_ATOMIC_ACC
+    // the thread's own slot: an LDS float add without return (ds_add_f32) instead of ds_read + v_add + ds_write -- no wait for read data
+    (void)__hip_atomic_fetch_add(&base[(FULL ? k : acc_slot_lower(k)) * kAlignBlock], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
     base[(FULL ? k : acc_slot_lower(k)) * kAlignBlock] += v;
+#endif
   }
 };
 // returns false if the term is rejected (non-robust kernel and chi2 above threshold)
