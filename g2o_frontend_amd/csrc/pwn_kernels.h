@@ -1209,7 +1209,7 @@ __device__ __forceinline__ void candidate_load(const PairPtrs& q, int ri, int ci
 }
 template <bool SAME_T, typename ACC>
 __device__ __forceinline__ void candidate_consume(const PairDesc& pd, const PairPtrs& q, const AlignParams& ap, const Mat4& Tc, const Mat4& Tl,
-                                                  const Candidate& c, const ACC acc, float* cnt /* K, C, inliers */) {
+                                                  const Candidate& c, const ACC acc, float* cnt /* K, C, inliers */, const float* omNtab /* LDS [3][9] */) {
   if (!c.valid) return;
   cnt[0] += 1.f;
   float3 rp, rn;
@@ -1222,8 +1222,11 @@ __device__ __forceinline__ void candidate_consume(const PairDesc& pd, const Pair
 #pragma unroll
     for (int k = 0; k < 9; ++k) oN[k] = q.curOmN[(size_t)k * q.cap + (unsigned)c.ci];
   } else {
+    // class -> matrix through a 27-float LDS table (row 0 = zero matrix): one broadcast read per entry.  Selecting from the descriptor
+    // compiled into a tree of exec-masked branches with a scalar load and a wait inside each, 18 of them per correspondence.
+    const float* t = omNtab + 9 * (cls > 2 ? 0 : cls);
 #pragma unroll
-    for (int k = 0; k < 9; ++k) oN[k] = (cls == 1) ? pd.cur.omN[0][k] : ((cls == 2) ? pd.cur.omN[1][k] : 0.f);
+    for (int k = 0; k < 9; ++k) oN[k] = t[k];
   }
   if (!SAME_T) { rp = iso_point(Tl, c.rP); rn = iso_normal(Tl, c.rN); }   // inner iterations > 0: the linearizer's transform moved on
   float oP[9];
@@ -1267,6 +1270,9 @@ __global__ void PWN_CL_EU_ATTR __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_co
   for (int k = 0; k < kAccN; ++k) acc[k] = 0.f;
   const RegAcc sums = { acc };
 #endif
+  __shared__ float omNtab[27];
+  if (threadIdx.x < 27) omNtab[threadIdx.x] = threadIdx.x < 9 ? 0.f : pd.cur.omN[(threadIdx.x - 9) / 9][(threadIdx.x - 9) % 9];
+  __syncthreads();
   float cnt[3] = { 0.f, 0.f, 0.f };
   const int nref = min(*as_global((const int*)pd.ref.count), pd.ref.capacity), ncur = min(*as_global((const int*)pd.cur.count), pd.cur.capacity);
   const int pix0 = blockIdx.x * kPixPerThread * kAlignBlock + threadIdx.x;
@@ -1286,7 +1292,7 @@ __global__ void PWN_CL_EU_ATTR __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_co
     const Candidate cur = nxt;
     candidate_load(q, ri2, ci2, nref, ncur, nxt);        // gathers of pixel j+1: in flight during the arithmetic below
     load_indices(j + 2, ri2, ci2);                        // indices of pixel j+2
-    candidate_consume<SAME_T>(pd, q, ap, Tc, Tl, cur, sums, cnt);
+    candidate_consume<SAME_T>(pd, q, ap, Tc, Tl, cur, sums, cnt, omNtab);
   }
 #if PWN_LDS_ACC
   float acc[kAccN];
