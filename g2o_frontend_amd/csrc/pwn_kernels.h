@@ -1034,6 +1034,16 @@ template <bool FULL> struct LdsAcc {
   }
 };
 // returns false if the term is rejected (non-robust kernel and chi2 above threshold)
+// a*b + c*d of the H / b products.  PWN_LIN_FMA=1 (experiment) contracts it to fma(a, b, c*d): fewer VALU instructions, last-bit
+// differences in H and b (chi2, the acceptance tests and the counters are not touched).
+#ifndef PWN_LIN_FMA
+#define PWN_LIN_FMA 0
+#endif
+#if PWN_LIN_FMA
+#define MAD2(a, b, c, d) fmaf((a), (b), (c) * (d))
+#else
+#define MAD2(a, b, c, d) ((a) * (b) + (c) * (d))
+#endif
 template <typename ACC>
 __device__ __forceinline__ bool linearize_term(const float3 rp, const float3 rn, const float3 cp, const float3 cn,
                                                const float* oP, const float* oN, float maxChi2, int robust, const ACC acc) {
@@ -1054,33 +1064,33 @@ __device__ __forceinline__ bool linearize_term(const float3 rp, const float3 rn,
   const float ptx = 2 * rp.x, pty = 2 * rp.y, ptz = 2 * rp.z;
   const float ntx = 2 * rn.x, nty = 2 * rn.y, ntz = 2 * rn.z;
   // Sp^T ep + Sn^T en
-  const float s0 = ((-ptz) * ep[1] + pty * ep[2]) + ((-ntz) * en[1] + nty * en[2]);
-  const float s1 = (ptz * ep[0] + (-ptx) * ep[2]) + (ntz * en[0] + (-ntx) * en[2]);
-  const float s2 = ((-pty) * ep[0] + ptx * ep[1]) + ((-nty) * en[0] + ntx * en[1]);
+  const float s0 = (MAD2((-ptz), ep[1], pty, ep[2])) + (MAD2((-ntz), en[1], nty, en[2]));
+  const float s1 = (MAD2(ptz, ep[0], (-ptx), ep[2])) + (MAD2(ntz, en[0], (-ntx), en[2]));
+  const float s2 = (MAD2((-pty), ep[0], ptx, ep[1])) + (MAD2((-nty), en[0], ntx, en[1]));
   // Row by row (keeps few values live): Htt += omegaP ; Htr += omegaP*Sp ; Hrr += (Sp^T omegaP Sp + Sn^T omegaN Sn).
   // accumulators are column-major 3x3 blocks: acc[base + i + 3*j]
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const float a0 = oP[3 * i], a1 = oP[3 * i + 1], a2 = oP[3 * i + 2];
     acc.add(0 + i, a0); acc.add(0 + i + 3, a1); acc.add(0 + i + 6, a2);
-    acc.add(9 + i, a1 * (-ptz) + a2 * pty);                    // (omegaP * Sp)(i, 0..2)
-    acc.add(9 + i + 3, a0 * ptz + a2 * (-ptx));
-    acc.add(9 + i + 6, a0 * (-pty) + a1 * ptx);
+    acc.add(9 + i, MAD2(a1, (-ptz), a2, pty));                    // (omegaP * Sp)(i, 0..2)
+    acc.add(9 + i + 3, MAD2(a0, ptz, a2, (-ptx)));
+    acc.add(9 + i + 6, MAD2(a0, (-pty), a1, ptx));
     // row i of Sp^T*omegaP and of Sn^T*omegaN
     float p0, p1, p2, q0, q1, q2;
     if (i == 0) {
-      p0 = (-ptz) * oP[3] + pty * oP[6]; p1 = (-ptz) * oP[4] + pty * oP[7]; p2 = (-ptz) * oP[5] + pty * oP[8];
-      q0 = (-ntz) * oN[3] + nty * oN[6]; q1 = (-ntz) * oN[4] + nty * oN[7]; q2 = (-ntz) * oN[5] + nty * oN[8];
+      p0 = MAD2((-ptz), oP[3], pty, oP[6]); p1 = MAD2((-ptz), oP[4], pty, oP[7]); p2 = MAD2((-ptz), oP[5], pty, oP[8]);
+      q0 = MAD2((-ntz), oN[3], nty, oN[6]); q1 = MAD2((-ntz), oN[4], nty, oN[7]); q2 = MAD2((-ntz), oN[5], nty, oN[8]);
     } else if (i == 1) {
-      p0 = ptz * oP[0] + (-ptx) * oP[6]; p1 = ptz * oP[1] + (-ptx) * oP[7]; p2 = ptz * oP[2] + (-ptx) * oP[8];
-      q0 = ntz * oN[0] + (-ntx) * oN[6]; q1 = ntz * oN[1] + (-ntx) * oN[7]; q2 = ntz * oN[2] + (-ntx) * oN[8];
+      p0 = MAD2(ptz, oP[0], (-ptx), oP[6]); p1 = MAD2(ptz, oP[1], (-ptx), oP[7]); p2 = MAD2(ptz, oP[2], (-ptx), oP[8]);
+      q0 = MAD2(ntz, oN[0], (-ntx), oN[6]); q1 = MAD2(ntz, oN[1], (-ntx), oN[7]); q2 = MAD2(ntz, oN[2], (-ntx), oN[8]);
     } else {
-      p0 = (-pty) * oP[0] + ptx * oP[3]; p1 = (-pty) * oP[1] + ptx * oP[4]; p2 = (-pty) * oP[2] + ptx * oP[5];
-      q0 = (-nty) * oN[0] + ntx * oN[3]; q1 = (-nty) * oN[1] + ntx * oN[4]; q2 = (-nty) * oN[2] + ntx * oN[5];
+      p0 = MAD2((-pty), oP[0], ptx, oP[3]); p1 = MAD2((-pty), oP[1], ptx, oP[4]); p2 = MAD2((-pty), oP[2], ptx, oP[5]);
+      q0 = MAD2((-nty), oN[0], ntx, oN[3]); q1 = MAD2((-nty), oN[1], ntx, oN[4]); q2 = MAD2((-nty), oN[2], ntx, oN[5]);
     }
-    acc.add(18 + i, (p1 * (-ptz) + p2 * pty) + (q1 * (-ntz) + q2 * nty));
-    acc.add(18 + i + 3, (p0 * ptz + p2 * (-ptx)) + (q0 * ntz + q2 * (-ntx)));
-    acc.add(18 + i + 6, (p0 * (-pty) + p1 * ptx) + (q0 * (-nty) + q1 * ntx));
+    acc.add(18 + i, (MAD2(p1, (-ptz), p2, pty)) + (MAD2(q1, (-ntz), q2, nty)));
+    acc.add(18 + i + 3, (MAD2(p0, ptz, p2, (-ptx))) + (MAD2(q0, ntz, q2, (-ntx))));
+    acc.add(18 + i + 6, (MAD2(p0, (-pty), p1, ptx)) + (MAD2(q0, (-nty), q1, ntx)));
   }
   acc.add(27, kscale * ep[0]); acc.add(28, kscale * ep[1]); acc.add(29, kscale * ep[2]);
   acc.add(30, kscale * s0); acc.add(31, kscale * s1); acc.add(32, kscale * s2);
