@@ -1149,11 +1149,16 @@ __device__ __forceinline__ bool correspondence_test(const AlignParams& ap, const
 }
 
 // block-level reduction of kAccN fp32 accumulators -> fp64 partial record of the block
+template <bool FULL = true>
 __device__ __forceinline__ void block_reduce_store(float* acc, double* out_generic) {
   const gptr<double> out = as_global(out_generic);
   __shared__ float red[kAlignBlock / 64][kAccN];
 #pragma unroll
   for (int k = 0; k < kAccN; ++k) {
+    if (!FULL && k < 34 && acc_is_upper(k)) {            // sums the lower-triangle passes do not accumulate: exact zeros, no reduction
+      if (lane_id() == 63) red[threadIdx.x >> 6][k] = 0.f;
+      continue;
+    }
     const float v = wave_sum_dpp_lane63(acc[k]);
     if (lane_id() == 63) red[threadIdx.x >> 6][k] = v;
   }
@@ -1256,7 +1261,7 @@ __device__ __forceinline__ void candidate_consume(const PairDesc& pd, const Pair
 }
 // usePrevTc: the acceptance tests run with the previous outer iteration's transform (Aligner::_computeStatistics re-linearizes
 // the finder's existing correspondences at the final transform, aligner.cpp:165-170).
-template <bool SAME_T, bool FULL_H>
+template <bool SAME_T, bool FULL_H, int PPT = kPixPerThread>
 #ifdef PWN_CL_WAVES_EU
 #define PWN_CL_EU_ATTR __attribute__((amdgpu_waves_per_eu(PWN_CL_WAVES_EU, PWN_CL_WAVES_EU)))
 #else
@@ -1285,12 +1290,12 @@ __global__ void PWN_CL_EU_ATTR __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_co
   __syncthreads();
   float cnt[3] = { 0.f, 0.f, 0.f };
   const int nref = min(*as_global((const int*)pd.ref.count), pd.ref.capacity), ncur = min(*as_global((const int*)pd.cur.count), pd.cur.capacity);
-  const int pix0 = blockIdx.x * kPixPerThread * kAlignBlock + threadIdx.x;
+  const int pix0 = blockIdx.x * PPT * kAlignBlock + threadIdx.x;
   const PairPtrs q = pair_ptrs(pd);
   auto load_indices = [&](int j, int& ri, int& ci) {
     const int pix = pix0 + j * kAlignBlock;
     ri = -1; ci = -1;
-    if (j < kPixPerThread && pix < N) { ri = zkey_index(q.zref[(unsigned)pix], tag); ci = q.curidx[(unsigned)pix]; }
+    if (j < PPT && pix < N) { ri = zkey_index(q.zref[(unsigned)pix], tag); ci = q.curidx[(unsigned)pix]; }
   };
   int ri1, ci1, ri2, ci2;
   load_indices(0, ri1, ci1);
@@ -1298,7 +1303,7 @@ __global__ void PWN_CL_EU_ATTR __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_co
   Candidate nxt;
   candidate_load(q, ri1, ci1, nref, ncur, nxt);
 #pragma unroll 1
-  for (int j = 0; j < kPixPerThread; ++j) {
+  for (int j = 0; j < PPT; ++j) {
     const Candidate cur = nxt;
     candidate_load(q, ri2, ci2, nref, ncur, nxt);        // gathers of pixel j+1: in flight during the arithmetic below
     load_indices(j + 2, ri2, ci2);                        // indices of pixel j+2
@@ -1311,7 +1316,7 @@ __global__ void PWN_CL_EU_ATTR __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_co
     acc[k] = (FULL_H || !acc_is_upper(k)) ? lacc[(FULL_H ? k : acc_slot_lower(k)) * kAlignBlock + threadIdx.x] : 0.f;
 #endif
   acc[36] = cnt[0]; acc[35] = cnt[1]; acc[34] = cnt[2];
-  block_reduce_store(acc, pd.partials + (size_t)blockIdx.x * kAccN);
+  block_reduce_store<FULL_H>(acc, pd.partials + (size_t)blockIdx.x * kAccN);
 }
 
 // CorrespondenceFinder::compute as a per-pixel pair image (compacted on the host in row-major order).
