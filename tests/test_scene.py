@@ -314,3 +314,60 @@ def test_incremental_scene_harness(gctx, oracle):
     finally:
         oracle.set_gaussians(False)
     assert len(oscene) < 0.6 * sum(int(((d >= conv["min_distance"]) & (d <= conv["max_distance"])).sum()) for d in depths)
+
+
+@pytest.mark.gpu
+def test_scene_edge_cases_and_error_paths(gctx, oracle):
+    """empty clouds, missing Gaussians, capacity overflow, all-invalid frames: status codes, no crash, same behaviour as the oracle"""
+    from g2o_frontend_amd import api
+    from g2o_frontend_amd._lib import PwnHipError
+    rows, cols, K, conv, depths, Ttrue, (o0, _) = _oracle_scene(oracle)
+    proj, converter, (g0,) = _gpu_convert(gctx, "small", depths[:1])
+    merger = api.Merger(); merger.setDepthImageConverter(converter); merger.setImageSize(rows, cols)
+    # empty scene: merge and voxelize are no-ops
+    empty = api.Cloud(gctx, 16)
+    assert empty.size() == 0 and api.VoxelCalculator().compute(empty, 0.05) == 0
+    # Merger::merge without Gaussians is refused (the reference would read an empty vector)
+    nog = api.Cloud(gctx, rows * cols)
+    converter.compute(nog, depths[0])
+    with pytest.raises(PwnHipError):
+        merger.merge(nog, np.eye(4))
+    # Cloud::add beyond the destination capacity is a status code, and leaves the destination untouched
+    small = api.Cloud(gctx, g0.size() + 10)
+    small.add(g0, np.eye(4))
+    before = small.arrays()["points"].copy()
+    with pytest.raises(PwnHipError):
+        small.add(g0, np.eye(4))
+    assert small.size() == g0.size() and np.array_equal(small.arrays()["points"], before)
+    with pytest.raises(PwnHipError):
+        small.add(small, np.eye(4))
+    # a frame without a single valid pixel: empty cloud, empty Gaussians, add / merge still fine
+    blank = np.zeros((rows, cols), np.float32)
+    oracle.set_gaussians(True)
+    try:
+        ob, _, _ = oracle.convert(oracle.converter_params(K=K, **conv), blank)
+    finally:
+        oracle.set_gaussians(False)
+    gb = api.Cloud(gctx, rows * cols)
+    converter.compute(gb, blank, keep_stats=True, gaussians=True)
+    assert len(ob) == gb.size() == 0 and gb.numGaussians() == 0
+    scene = api.Cloud(gctx, 2 * rows * cols); oscene = oracle.Cloud()
+    scene.add(gb, Ttrue); oscene.add(ob, Ttrue)
+    scene.add(g0, Ttrue); oscene.add(o0, Ttrue)
+    ok, ocol = oracle.merge(oscene, K, Ttrue, conv["min_distance"], conv["max_distance"], rows, cols)
+    assert merger.merge(scene, Ttrue) == ok and np.array_equal(merger.collapsedIndices(), ocol)
+    _same_cloud(oscene, scene)
+    # a view that sees nothing (looking away): every point keeps _collapsedIndices = -1, the cloud is unchanged
+    away = np.array([[-1, 0, 0, 0], [0, 1, 0, 0], [0, 0, -1, -10], [0, 0, 0, 1]], np.float32)
+    ok2, ocol2 = oracle.merge(oscene, K, away, conv["min_distance"], conv["max_distance"], rows, cols)
+    assert merger.merge(scene, away) == ok2 == ok and np.all(ocol2 == -1) and np.array_equal(merger.collapsedIndices(), ocol2)
+    _same_cloud(oscene, scene)
+    # voxel grid: a NaN point is reported, not silently hashed
+    bad = api.Cloud(gctx, 8)
+    P = np.zeros((4, 4), np.float32); P[:, 3] = 1; P[2, 0] = np.nan
+    bad.upload(P, np.zeros((4, 4), np.float32), np.zeros(4, np.float32), np.zeros((4, 16), np.float32), np.zeros((4, 16), np.float32))
+    with pytest.raises(PwnHipError):
+        api.VoxelCalculator().compute(bad, 0.01)
+    # unreadable / foreign files
+    with pytest.raises(PwnHipError):
+        api.Cloud(gctx, 8).load("/nonexistent/file.pwn")
