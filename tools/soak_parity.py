@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""Parity soak: many seeded pairs, random sensor offsets and converter settings -- converter arrays bit for bit, first-iteration
+counters exactly, chi2 from the same iterate to 1e-5, free-running pose; scene add + merge bit for bit.  Prints a summary line per case
+and a final JSON; exits non-zero on the first mismatch.  (The committed tests cover fixed seeds; this is the wide net.)"""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    if a.dtype != np.float32:
+        return a
+    a = a.copy(); a[a == 0] = 0
+    return a.view(np.uint32)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--vga", type=int, default=16)
+    ap.add_argument("--small", type=int, default=60)
+    args = ap.parse_args()
+    from conftest import case_params
+    from g2o_frontend_amd import api, synth
+    from oracle import oracle as O
+    from test_gpu_parity import gpu_objects
+    ctx = api.Context(0, 480, 640, 4)
+    rng = np.random.default_rng(2024)
+    stats = dict(cases=0, worst_chi2_rel=0.0, worst_pose=0.0, points=0, merged=0)
+    for name, count in (("small", args.small), ("vga", args.vga)):
+        rows, cols, K, conv0, alig = case_params(name)
+        for seed in range(1000, 1000 + count):
+            conv = dict(conv0)
+            offset = None
+            if seed % 3 == 1:      # random sensor mounting
+                q = rng.uniform(-0.3, 0.3, 3); t = rng.uniform(-0.2, 0.2, 3)
+                offset = synth.v2t(np.concatenate([t, q])).astype(np.float32)
+            if seed % 4 == 2:      # other window / threshold settings
+                conv["min_image_radius"] = int(rng.integers(2, 12)); conv["max_image_radius"] = conv["min_image_radius"] + int(rng.integers(1, 20))
+                conv["min_points"] = int(rng.integers(5, 80)); conv["stats_curvature_threshold"] = float(rng.uniform(0.01, 0.3))
+            ref_mm, cur_mm, Ttrue = synth.make_pair(seed, rows, cols, K, holes=float(rng.uniform(0.0, 0.2)))
+            ref, cur = O.convert_16u_to_32f(ref_mm), O.convert_16u_to_32f(cur_mm)
+            O.set_gaussians(True)
+            cp = O.converter_params(K=K, sensor_offset=offset, **conv)
+            oref, oidx, oitv = O.convert(cp, ref); ocur, _, _ = O.convert(cp, cur)
+            O.set_gaussians(False)
+            proj, converter, aligner = gpu_objects(ctx, name, sensor_offset=offset)
+            st = converter._stats
+            st.setMinImageRadius(conv["min_image_radius"]); st.setMaxImageRadius(conv["max_image_radius"]); st.setMinPoints(conv["min_points"])
+            st.setCurvatureThreshold(conv["stats_curvature_threshold"])
+            gref, gcur = api.Cloud(ctx, rows * cols), api.Cloud(ctx, rows * cols)
+            converter.compute(gref, ref, sensorOffset=offset, keep_stats=True, gaussians=True)
+            assert np.array_equal(converter.indexImage(), oidx) and np.array_equal(converter.intervalImage(), oitv), (name, seed, "images")
+            converter.compute(gcur, cur, sensorOffset=offset, keep_stats=True, gaussians=True)
+            for o, g in ((oref, gref), (ocur, gcur)):
+                oa, ga = o.arrays(stats=True), g.arrays(stats=True)
+                for k in oa:
+                    assert np.array_equal(bits(oa[k]), bits(ga[k])), (name, seed, k)
+                og, gg = o.gaussians(), g.gaussians()
+                assert np.array_equal(bits(og["cov"]), bits(gg["cov"])) and np.array_equal(bits(og["mean"]), bits(gg["mean"])), (name, seed, "gaussians")
+            apar = O.aligner_params(rows, cols, K=K, accumulate_fp64=1, reference_sensor_offset=offset, current_sensor_offset=offset, **alig)
+            o = O.align(apar, oref, ocur)
+            aligner.setReferenceCloud(gref); aligner.setCurrentCloud(gcur)
+            g = aligner.align()
+            it0 = o["iterations"][0]
+            assert (int(g["K"][0]), int(g["C"][0]), int(g["iter_inliers"][0])) == (it0["K"], it0["C"], it0["inliers"]), (name, seed, "counters")
+            rel = abs(float(g["chi2"][0]) - it0["chi2_fp64"]) / max(it0["chi2_fp64"], 1e-30)
+            assert rel <= 1e-5, (name, seed, "chi2", rel)
+            pose = float(np.abs(g["T"] - o["T"]).max())
+            assert pose <= (2e-5 if name == "vga" else 5e-4), (name, seed, "pose", pose)
+            # scene: add both views, merge in the first view
+            oscene = O.Cloud(); gscene = api.Cloud(ctx, 2 * rows * cols)
+            oscene.add(oref, np.eye(4)); gscene.add(gref, np.eye(4)); oscene.add(ocur, o["T"]); gscene.add(gcur, o["T"])
+            so = np.eye(4, dtype=np.float32) if offset is None else offset
+            merger = api.Merger(); merger.setDepthImageConverter(converter); merger.setImageSize(rows, cols)
+            ok, ocol = O.merge(oscene, K, so, conv["min_distance"], conv["max_distance"], rows, cols)
+            assert merger.merge(gscene, so) == ok and np.array_equal(merger.collapsedIndices(), ocol), (name, seed, "merge")
+            oa, ga = oscene.arrays(stats=True), gscene.arrays(stats=True)
+            for k in oa:
+                assert np.array_equal(bits(oa[k]), bits(ga[k])), (name, seed, "scene", k)
+            stats["cases"] += 1; stats["worst_chi2_rel"] = max(stats["worst_chi2_rel"], rel); stats["worst_pose"] = max(stats["worst_pose"], pose)
+            stats["points"] += len(oref) + len(ocur); stats["merged"] += int(((ocol >= 0) & (ocol != np.arange(len(ocol)))).sum())
+            print(f"{name} seed {seed}: M {len(oref)}/{len(ocur)} offset {offset is not None} chi2 rel {rel:.1e} pose {pose:.1e} merged {ok}", flush=True)
+    print(json.dumps(stats))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
