@@ -461,7 +461,7 @@ int pwn_hip_ctx_create(pwn_hip_ctx** out, int device, int max_rows, int max_cols
   {   // any rows x cols image with rows*cols <= N and rows, cols <= M: rows*strips <= N/64 + M, strips*bands <= N/1024 + M/64 + M/16 + 1
     const size_t M = (size_t)std::max(max_rows, max_cols);
     ctx->rowoff_slot = N / 64 + M + 64;
-    ctx->carry_slot = (N / 1024 + M / 64 + M / 16 + 2) * (size_t)kII_Chains;
+    ctx->carry_slot = (N / ((size_t)kIR_Cols * kIR_Rows) + M / kIR_Cols + M / kIR_Rows + 2) * (size_t)kII_Chains;
   }
   ALLOC(ctx->rowoff_ws, B * ctx->rowoff_slot * sizeof(int));
   ALLOC(ctx->carry_ws, B * ctx->carry_slot * sizeof(unsigned long long));

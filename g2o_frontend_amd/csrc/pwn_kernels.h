@@ -317,7 +317,11 @@ __global__ void __launch_bounds__(256) k_unproject(const FrameDesc* __restrict__
 // the covariance downstream differences these sums, so every chain keeps the reference's strictly sequential
 // left-to-right order: one thread per (row, channel) chain, tiles staged through LDS so that all global
 // traffic is row-coalesced.  grid = (ceil(rows/16), frames), block = 256.
-constexpr int kIR_Rows = 16, kIR_Cols = 64, kIR_Stride = kIR_Cols + 1;
+#ifndef PWN_IR_ROWS
+#define PWN_IR_ROWS 16      // band height of the integral-image kernels (a multiple of 4: one row per compute wave and step)
+#endif
+constexpr int kIR_Rows = PWN_IR_ROWS, kIR_Cols = 64, kIR_Stride = kIR_Cols + 1;
+static_assert(kIR_Rows % 4 == 0 && (kIR_Rows & (kIR_Rows - 1)) == 0 && kIR_Rows <= 64, "band height");
 __global__ void __launch_bounds__(256) k_integral_rows(const FrameDesc* __restrict__ frames, int rows, int cols) {
   const FrameDesc& f = frames[blockIdx.y];
   const int r0 = blockIdx.x * kIR_Rows;
@@ -330,7 +334,7 @@ __global__ void __launch_bounds__(256) k_integral_rows(const FrameDesc* __restri
   for (int x0 = 0; x0 < cols; x0 += kIR_Cols) {
     // phase 1: 1024 pixels, 4 per thread, lanes along x
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < kIR_Rows / 4; ++j) {
       const int q = tid + 256 * j;
       const int lr = q / kIR_Cols, lc = q % kIR_Cols;
       const int r = r0 + lr, c = x0 + lc;
@@ -364,7 +368,7 @@ __global__ void __launch_bounds__(256) k_integral_rows(const FrameDesc* __restri
     __syncthreads();
     // phase 3: coalesced write-back, plane by plane
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < kIR_Rows / 4; ++j) {
       const int q = tid + 256 * j;
       const int lr = q / kIR_Cols, lc = q % kIR_Cols;
       const int r = r0 + lr, c = x0 + lc;
@@ -391,12 +395,12 @@ __global__ void __launch_bounds__(256) k_unproject_integral_rows(const FrameDesc
   const size_t N = (size_t)rows * cols;
   const int srow = tid % kIR_Rows, sch = tid / kIR_Rows;
   float carry = 0.f;
-  int base[4];
+  int base[kIR_Rows / 4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) { const int r = r0 + wave + 4 * j; base[j] = (r < rows) ? f.rowoff[r] : 0; }
+  for (int j = 0; j < kIR_Rows / 4; ++j) { const int r = r0 + wave + 4 * j; base[j] = (r < rows) ? f.rowoff[r] : 0; }
   for (int x0 = 0; x0 < cols; x0 += kIR_Cols) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < kIR_Rows / 4; ++j) {
       const int lr = wave + 4 * j, lc = lane;
       const int r = r0 + lr, c = x0 + lc;
       const bool in = r < rows && c < cols;
@@ -449,7 +453,7 @@ __global__ void __launch_bounds__(256) k_unproject_integral_rows(const FrameDesc
     }
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < kIR_Rows / 4; ++j) {
       const int lr = wave + 4 * j, lc = lane;
       const int r = r0 + lr, c = x0 + lc;
       if (r < rows && c < cols) {
@@ -608,7 +612,7 @@ __global__ void __launch_bounds__(kII_Threads) k_unproject_integral(const FrameD
     } else {
       // 1. unproject: wave w owns rows r0 + w + 4j
 #pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
+      for (int jj = 0; jj < kIR_Rows / 4; ++jj) {
         const int lr = wave + 4 * jj;
         const int r = r0 + lr;
         const bool in = r < rows && c < cols;
