@@ -37,6 +37,13 @@ def build_tools(force: bool = False) -> str:
     if force or (not os.path.exists(out)) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", root, src, "-o", out, "-L", _HERE, "-lpwn_hip",
                                "-Wl,-rpath,$ORIGIN/../g2o_frontend_amd"])
+    # the mapping loop of pwn_aligner.cpp (Cloud::add + Merger::merge + Cloud::save) over the same mirror
+    src2 = os.path.join(root, "tools", "pwn_hip_scene_aligner.cpp")
+    out2 = os.path.join(root, "tools", "pwn_hip_scene_aligner")
+    deps2 = [src2] + deps[1:]
+    if force or (not os.path.exists(out2)) or any(os.path.getmtime(d) > os.path.getmtime(out2) for d in deps2):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", root, src2, "-o", out2, "-L", _HERE, "-lpwn_hip",
+                               "-Wl,-rpath,$ORIGIN/../g2o_frontend_amd"])
     return out
 
 

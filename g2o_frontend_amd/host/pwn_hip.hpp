@@ -44,6 +44,7 @@ struct Isometry3f {
   const float* data() const { return m; }
   float* data() { return m; }
   void forceLastRow() { m[3] = 0.f; m[7] = 0.f; m[11] = 0.f; m[15] = 1.f; }
+  Isometry3f inverse() const { Isometry3f r; pwn_hip_iso_inverse(m, r.m); return r; }       // Isometry3f::inverse(): R^T, -R^T t
   // Isometry3f * Isometry3f (linear = Ra*Rb, translation = Ra*tb + ta), float, left-to-right sums
   Isometry3f operator*(const Isometry3f& b) const {
     Isometry3f r;
@@ -132,6 +133,8 @@ class PinholePointProjector {
   float maxDistance() const { return _maxDistance; }  void setMaxDistance(float v) { _maxDistance = v; }
   int imageRows() const { return _imageRows; }  int imageCols() const { return _imageCols; }
   void setImageSize(int r, int c) { _imageRows = r; _imageCols = c; }
+  float baseline() const { return _baseline; }  void setBaseline(float v) { _baseline = v; }        // sensor-noise model of unProject's Gaussians
+  float alpha() const { return _alpha; }        void setAlpha(float v) { _alpha = v; }
   void scale(float s) {                                                                                  // pinholepointprojector.cpp:149-154
     for (int c = 0; c < 3; ++c) { _cameraMatrix(0,c) *= s; _cameraMatrix(1,c) *= s; }
     _imageRows = (int)(_imageRows * s); _imageCols = (int)(_imageCols * s);
@@ -144,6 +147,7 @@ class PinholePointProjector {
  private:
   Matrix3f _cameraMatrix; Isometry3f _transform;
   float _minDistance = 0.01f, _maxDistance = 6.0f;                                                        // pointprojector.cpp:9-10
+  float _baseline = 0.075f, _alpha = 0.1f;                                                                // pinholepointprojector.cpp:10-11
   int _imageRows = 0, _imageCols = 0;
 };
 
@@ -182,6 +186,9 @@ class DepthImageConverter {
   virtual ~DepthImageConverter() {}
   PinholePointProjector* projector() { return _projector; }
   IntImage& indexImage() { return _indexImage; }
+  // The reference fills Cloud::gaussians() inside every compute() (depthimageconverterintegralimage.cpp:39); only Merger::merge reads
+  // them, so here they are produced when asked for (clouds that will enter a scene).
+  bool computeGaussians() const { return _computeGaussians; }  void setComputeGaussians(bool v) { _computeGaussians = v; }
   virtual void compute(Cloud& cloud, const DepthImage& depthImage, const Isometry3f& sensorOffset = Isometry3f::Identity()) = 0;
   pwn_hip_converter_params params(const Isometry3f& sensorOffset) const {
     if (!_projector || !_statsCalculator || !_pointInformationMatrixCalculator || !_normalInformationMatrixCalculator)
@@ -205,6 +212,7 @@ class DepthImageConverter {
   Context* _ctx; PinholePointProjector* _projector; StatsCalculatorIntegralImage* _statsCalculator;
   PointInformationMatrixCalculator* _pointInformationMatrixCalculator; NormalInformationMatrixCalculator* _normalInformationMatrixCalculator;
   IntImage _indexImage;
+  bool _computeGaussians = false;
 };
 class DepthImageConverterIntegralImage : public DepthImageConverter {
  public:
@@ -216,7 +224,10 @@ class DepthImageConverterIntegralImage : public DepthImageConverter {
     _projector->setTransform(Isometry3f::Identity());                           // :38
     _indexImage.create(depthImage.rows, depthImage.cols);
     _ctx->check(pwn_hip_convert(_ctx->handle(), &p, depthImage.data.data(), depthImage.rows, depthImage.cols, cloud.handle(),
-                                _indexImage.data.data(), nullptr, 0));
+                                _indexImage.data.data(), nullptr, _computeGaussians ? 1 : 0));      // scene clouds keep their Stats (Cloud::save)
+    if (_computeGaussians)
+      _ctx->check(pwn_hip_cloud_gaussians(_ctx->handle(), &p, depthImage.data.data(), depthImage.rows, depthImage.cols, cloud.handle(),
+                                          _projector->baseline(), _projector->alpha()));
   }
 };
 

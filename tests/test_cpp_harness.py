@@ -83,3 +83,70 @@ def test_sequential_odometry_harness_matches_oracle(tmp_path, oracle):
     # and the chained odometry follows the true camera motion
     true = np.linalg.inv(poses[0]) @ poses[n - 1]
     assert np.abs(G[:3, 3] - true[:3, 3]).max() < 0.02
+
+
+@pytest.mark.gpu
+def test_scene_mapping_harness_matches_oracle(tmp_path, oracle):
+    """tools/pwn_hip_scene_aligner.cpp (the mapping loop of pwn_aligner.cpp:150-262 over the C++ mirror: render scene -> sub-scene ->
+    align -> Cloud::add -> Merger::merge -> Cloud::save every chunkStep frames) against the same loop run through the oracle.  Both sides
+    run free (each on its own poses: a pose that differs in the last bits moves merges and the rendered sub-scene, which feeds back), so the
+    comparison is to tolerance: trajectory 1e-3 (a twentieth of the per-frame motion; measured 2.6e-4 after 5 frames at 120x160), scene sizes
+    within 0.5 %; the bit-exact version of this loop is tests/test_scene.py::test_incremental_scene_harness; the saved .pwn
+    files are read back with the oracle's Cloud::load."""
+    from g2o_frontend_amd import build, synth
+    build.build_tools()
+    exe = os.path.join(ROOT, "tools", "pwn_hip_scene_aligner")
+    n = 5
+    poses = synth.trajectory(11, n)
+    frames = [synth.render_depth_mm(11, poses[k], 480, 640, synth.K_VGA, hole_stream=k) for k in range(n)]
+    lst = []
+    for k, f in enumerate(frames):
+        p = tmp_path / f"d{k}.pgm"
+        write_pgm16(str(p), f)
+        lst.append(f"{k * 0.033:.3f} {p}")
+    (tmp_path / "conf.txt").write_text(CONF + "chunkStep 3\n")
+    (tmp_path / "list.txt").write_text("\n".join(lst) + "\n")
+    prefix = str(tmp_path / "run")
+    subprocess.check_call([exe, str(tmp_path / "conf.txt"), str(tmp_path / "list.txt"), prefix], timeout=300)
+    got = np.loadtxt(prefix + "_trajectory.txt")
+    assert got.shape == (n, 8)
+    # the same loop through the oracle
+    K4 = synth.scaled_K(synth.K_VGA, 4)
+    conv, alig = oracle.QVGA4_CONF_CONVERTER, oracle.QVGA4_CONF_ALIGNER
+    cp = oracle.converter_params(K=K4, **conv)
+    ap = oracle.aligner_params(120, 160, K=K4, accumulate_fp64=1, **alig)
+    G = np.eye(4, dtype=np.float32); S = np.eye(4, dtype=np.float32)
+    scene = oracle.Cloud(); counter = 0; saved = {}
+    oracle.set_gaussians(True)
+    try:
+        for k, f in enumerate(frames):
+            d = oracle.depth_scale(oracle.convert_16u_to_32f(f), 4)
+            c, _, _ = oracle.convert(cp, d)
+            if k > 0:
+                _, rendered = oracle.project(K4, S, conv["min_distance"], conv["max_distance"], 120, 160, scene.arrays()["points"])
+                sub, _, _ = oracle.convert(cp, rendered)
+                r = oracle.align(ap, sub, c)
+                G = oracle.iso_mul(G, r["T"]); G[3] = (0, 0, 0, 1)
+                S = oracle.iso_mul(S, r["T"]); S[3] = (0, 0, 0, 1)
+                c0 = counter; counter += 1
+                if c0 % 3 == 0:
+                    saved[counter] = len(scene)
+                    S = np.eye(4, dtype=np.float32); scene = oracle.Cloud()
+            scene.add(c, S)
+            oracle.merge(scene, K4, S, conv["min_distance"], conv["max_distance"], 120, 160)
+            v = oracle.t2v(G)
+            assert np.abs(got[k, 1:4] - v[:3]).max() < 1e-3 and np.abs(got[k, 4:7] - v[3:]).max() < 1e-3, (k, got[k], v)
+            assert abs(got[k, 7] - len(scene)) <= max(5, 0.005 * len(scene)), (k, got[k, 7], len(scene))
+        saved[counter] = len(scene)
+    finally:
+        oracle.set_gaussians(False)
+    # every scene file the harness wrote: readable by the oracle's loader, point count as reported / as the oracle's own loop
+    for cnt, size in saved.items():
+        path = f"{prefix}_scene-{cnt:03d}.pwn"
+        assert os.path.exists(path), path
+        cl, T = oracle.Cloud.load(path)
+        assert cl is not None and abs(len(cl) - size) <= max(5, 0.005 * size), (cnt, len(cl), size)
+        a = cl.arrays()
+        assert np.isfinite(a["points"]).all() and np.abs(np.linalg.norm(a["normals"][:, :3], axis=1)[np.abs(a["normals"][:, :3]).sum(1) > 0] - 1).max() < 1e-3
+    true = np.linalg.inv(poses[0]) @ poses[n - 1]
+    assert np.abs(G[:3, 3] - true[:3, 3]).max() < 0.02
