@@ -39,6 +39,12 @@ struct pwn_hip_cloud {
   int n_gauss = 0;                       // Cloud::gaussians().size()
   CloudDev back = {};
   SceneBuffers sback = { nullptr, nullptr };
+  // The index image DepthImageConverter::compute produced for this cloud (written here directly instead of into a workspace), with what
+  // it was made from.  Projecting a cloud with the very projector it was unprojected with (same K, size, range, identity pose) returns
+  // this image: every point falls back on its own pixel (the round trip moves it by < 0.01 pixel and its depth not at all), so batch
+  // alignments take it as the current index image and skip that projection.  Anything that changes the points invalidates it.
+  int* idximg = nullptr; size_t idx_cap = 0; bool idx_valid = false;
+  int idx_rows = 0, idx_cols = 0; float idx_K[9] = { 0 }; float idx_minD = 0.f, idx_maxD = 0.f;
 };
 
 struct pwn_hip_ctx {
@@ -363,6 +369,16 @@ int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, cons
     const float* depth_dev = nullptr;
     if (!raw) depth_dev = reinterpret_cast<const float*>(frames[i]);         // patched below if it is a host pointer
     fill_frame(ctx, i, slot, depth_dev, c->d, rows);
+    if (c->idx_cap < N) {
+      HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+      if (c->idximg) (void)hipFree(c->idximg);
+      c->idximg = nullptr; c->idx_cap = 0;
+      HIPCHK(ctx, hipMalloc((void**)&c->idximg, N * sizeof(int)), PWN_HIP_ERR_ALLOCATION);
+      c->idx_cap = N;
+    }
+    ctx->frames_host[i].index = c->idximg;                    // the index image stays with the cloud
+    c->idx_valid = cp.hasOffset == 0;
+    c->idx_rows = rows; c->idx_cols = cols; std::memcpy(c->idx_K, p->K, sizeof(c->idx_K)); c->idx_minD = p->min_distance; c->idx_maxD = p->max_distance;
     if (raw) {                                                                // uint16 frames are converted on the fly by the kernels
       ctx->frames_host[i].raw = reinterpret_cast<const uint16_t*>(frames[i]); // patched below if it is a host pointer
       ctx->frames_host[i].raw_scale = depth_scale;
@@ -568,7 +584,7 @@ int pwn_hip_cloud_destroy(pwn_hip_ctx* ctx, pwn_hip_cloud* c) {
   if (!c) return PWN_HIP_OK;
   if (ctx) (void)hipStreamSynchronize(ctx->stream);
   void* p[] = { c->d.P, c->d.Nm, c->d.Om, c->d.OmN, c->d.St, c->d.count, c->sb.G, c->sb.Gf,
-                c->back.P, c->back.Nm, c->back.Om, c->back.OmN, c->back.St, c->sback.G, c->sback.Gf };
+                c->back.P, c->back.Nm, c->back.Om, c->back.OmN, c->back.St, c->sback.G, c->sback.Gf, c->idximg };
   for (void* q : p) if (q) (void)hipFree(q);
   delete c;
   return PWN_HIP_OK;
@@ -607,7 +623,7 @@ int pwn_hip_cloud_upload(pwn_hip_ctx* ctx, pwn_hip_cloud* c, int n, const float*
   HIPCHK(ctx, hipMemcpy(c->d.Om, Om.data(), Om.size() * 4, hipMemcpyHostToDevice), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipMemcpy(c->d.OmN, OmN.data(), OmN.size() * 4, hipMemcpyHostToDevice), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipMemcpy(c->d.count, &n, sizeof(int), hipMemcpyHostToDevice), PWN_HIP_ERR_COPY);
-  c->n_host = n; c->has_stats = false;
+  c->n_host = n; c->has_stats = false; c->idx_valid = false;
   return PWN_HIP_OK;
 }
 int pwn_hip_cloud_download(pwn_hip_ctx* ctx, const pwn_hip_cloud* c, float* points, float* normals, float* curvature, float* omega_p, float* omega_n) {
@@ -686,6 +702,7 @@ int pwn_hip_cloud_transform_in_place(pwn_hip_ctx* ctx, pwn_hip_cloud* c, const f
       std::memcpy(om, o2, sizeof(o2));
     }
   }
+  c->idx_valid = false;
   hipLaunchKernelGGL(k_cloud_transform, dim3((c->d.capacity + 255) / 256), dim3(256), 0, ctx->stream, c->d, m);
   {   // StatsVector / Gaussian3fVector::transformInPlace (stats.h:125-131, gaussian3.h:65-73)
     CloudDev d = c->d; if (!c->has_stats) d.St = nullptr;
@@ -750,6 +767,7 @@ int pwn_hip_unproject(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const
   if (!ctx || !p || !depth || !cloud) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if (int rc = check_image(ctx, rows, cols)) return rc;
   const size_t N = (size_t)rows * cols;
+  cloud->idx_valid = false;                      // the cloud gets new points
   const ConvertParams cp = make_convert_params(p, T, rows, cols, 0);
   const float* d = nullptr;
   if (int rc = stage_depth(ctx, depth, N, &d)) return rc;
@@ -927,6 +945,10 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
   const int sub = plan.sub;
   if (int rc = ensure_desc(ctx, n)) return rc;
   HIPCHK(ctx, hipEventRecord(ctx->t0, ctx->stream), PWN_HIP_ERR_LAUNCH);
+  // Batch calls that do not need the current depth image afterwards (no matchClouds score, no finder images: those belong to single
+  // alignments) skip the projection of a current cloud whose own index image is that projection's result.
+  const bool batch_shortcut = n > 1 && !scores && is_identity(forced(p->current_sensor_offset));
+  std::vector<char> own_index((size_t)std::max(n, 1), 0);
   // descriptors + initial states of all pairs; workspace slots are reused round-robin across sub-batches
   for (int i = 0; i < n; ++i) {
     const pwn_hip_cloud* r = refs[i]; const pwn_hip_cloud* c = curs[i];
@@ -937,6 +959,9 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
     pd.zref = ctx->zref_ws + (size_t)slot * ctx->N;
     pd.zcur = ctx->zcur_ws + (size_t)slot * ctx->N;
     pd.curidx = ctx->curidx_ws + (size_t)slot * ctx->N;
+    // the converter's own index image is what projecting the current cloud would give (see pwn_hip_cloud::idximg)
+    own_index[i] = batch_shortcut && c->idx_valid && c->idx_rows == p->rows && c->idx_cols == p->cols && c->idx_minD == p->min_distance &&
+                   c->idx_maxD == p->max_distance && std::memcmp(c->idx_K, p->K, sizeof(c->idx_K)) == 0;
     pd.partials = ctx->partials_ws + (size_t)slot * ctx->nblocks_max * kAccN;
     pd.state = ctx->state_ws + i;
     // initial state: aligner.cpp:60-64,72-73,79,84
@@ -952,6 +977,11 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
     projector_matrices(ap.K, mat4_from(p->current_sensor_offset), st.KRtCur, iKRt, iK);
     st.it = 0;
   }
+  // a sub-batch skips the projection kernels only if every pair of it can
+  std::vector<char> sub_own((size_t)(n + sub - 1) / sub + 1, 1);
+  for (int i = 0; i < n; ++i) if (!own_index[i]) sub_own[i / sub] = 0;
+  bool any_own = false;
+  for (int i = 0; i < n; ++i) if (sub_own[i / sub]) { ctx->pairs_host[i].curidx = curs[i]->idximg; any_own = true; }
   if (n > 0) {
     HIPCHK(ctx, hipMemcpyAsync(ctx->pairs_dev, ctx->pairs_host, sizeof(PairDesc) * n, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
     HIPCHK(ctx, hipMemcpyAsync(ctx->state_ws, ctx->state_host, sizeof(PairState) * n, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
@@ -981,7 +1011,8 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
     }
     if (s0 == 0 || kk == 0) { tag0 = subTag0; lastRefTag = subTag0 - (tagsPerSub - 1); }     // slot 0: what pwn_hip_align_images / pwn_hip_match_score read
     const unsigned subLastRefTag = subTag0 - (tagsPerSub - 1);
-    { StageTimer t(ctx, "project", st);
+    if (!sub_own[kk]) {
+      StageTimer t(ctx, "project", st);
       hipLaunchKernelGGL(k_project, dim3((maxcap_cur + 256 * kProjectPointsPerThread - 1) / (256 * kProjectPointsPerThread), m), dim3(256), 0, st, pr, ap, 1, subTag0);
       hipLaunchKernelGGL(k_resolve_cur, dim3(std::min((N + 255) / 256, 1024), m), dim3(256), 0, st, pr, N, subTag0); }
     for (int i = 0; i < p->outer_iterations; ++i) {
@@ -1043,7 +1074,7 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
   HIPCHK(ctx, hipEventSynchronize(ctx->t1), PWN_HIP_ERR_LAUNCH);
   float ms = 0.f; (void)hipEventElapsedTime(&ms, ctx->t0, ctx->t1);
   for (int i = 0; i < n; ++i) results[i].total_time_ms = n > 0 ? ms / n : 0.f;
-  ctx->img_rows = p->rows; ctx->img_cols = p->cols; ctx->img_valid = n > 0;
+  ctx->img_rows = p->rows; ctx->img_cols = p->cols; ctx->img_valid = n > 0 && !any_own;      // no current z-buffer after a skipped projection
   ctx->img_ref_tag = lastRefTag; ctx->img_cur_tag = tag0;
   collect_stage_times(ctx);
   return PWN_HIP_OK;

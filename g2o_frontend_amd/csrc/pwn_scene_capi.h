@@ -178,7 +178,7 @@ int pwn_hip_cloud_add(pwn_hip_ctx* ctx, pwn_hip_cloud* dst, const pwn_hip_cloud*
     if (k > dst->n_gauss) HIPCHK(ctx, hipMemset(dst->sb.Gf + dst->n_gauss, 0, sizeof(int) * (size_t)(k - dst->n_gauss)), PWN_HIP_ERR_COPY);
     dst->n_gauss = std::min(newg, dst->d.capacity);
   }
-  dst->n_host = total;
+  dst->n_host = total; dst->idx_valid = false;
   return PWN_HIP_OK;
 }
 
@@ -221,7 +221,7 @@ int pwn_hip_merge(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud, const float K[9], cons
   if (cloud->n_gauss > k) hipLaunchKernelGGL(k_gauss_copy_tail, dim3((cloud->n_gauss - k + 255) / 256), dim3(256), 0, st, cloud->sb, cloud->sback, k, cloud->n_gauss);
   HIPCHK(ctx, hipStreamSynchronize(st), PWN_HIP_ERR_LAUNCH);
   swap_back(cloud);
-  cloud->n_host = k;
+  cloud->n_host = k; cloud->idx_valid = false;
   ctx->img_valid = false;                 // slot 0 of the z-buffer was used
   if (new_size) *new_size = k;
   return PWN_HIP_OK;
@@ -273,7 +273,7 @@ int pwn_hip_voxelize(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud, float resolution, i
   if (kept && m > 0) HIPCHK(ctx, hipMemcpyAsync(kept, d_idxA, sizeof(int) * (size_t)m, hipMemcpyDeviceToHost, st), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipStreamSynchronize(st), PWN_HIP_ERR_LAUNCH);
   swap_back(cloud);
-  cloud->n_host = m;
+  cloud->n_host = m; cloud->idx_valid = false;
   cloud->n_gauss = withGauss ? m : 0;
   if (new_size) *new_size = m;
   return PWN_HIP_OK;
@@ -391,7 +391,7 @@ int pwn_hip_cloud_load(pwn_hip_ctx* ctx, pwn_hip_cloud* c, const char* filename,
     HIPCHK(ctx, hipMemset(c->d.Om, 0, (size_t)c->d.capacity * 9 * sizeof(float)), PWN_HIP_ERR_COPY);
   }
   HIPCHK(ctx, hipMemcpy(c->d.count, &n, sizeof(int), hipMemcpyHostToDevice), PWN_HIP_ERR_COPY);
-  c->n_host = n; c->has_stats = true; c->n_gauss = 0;
+  c->n_host = n; c->has_stats = true; c->n_gauss = 0; c->idx_valid = false;
   if (!ok) return fail(ctx, PWN_HIP_ERR_COPY, "read error / truncated PWNCLOUD file");
   return PWN_HIP_OK;
 }
