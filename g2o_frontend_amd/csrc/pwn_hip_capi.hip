@@ -948,7 +948,8 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
   // Batch calls that do not need the current depth image afterwards (no matchClouds score, no finder images: those belong to single
   // alignments) skip the projection of a current cloud whose own index image is that projection's result.
   const bool batch_shortcut = n > 1 && !scores && is_identity(forced(p->current_sensor_offset));
-  std::vector<char> own_index((size_t)std::max(n, 1), 0);
+  std::vector<char> own_index((size_t)std::max(n, 1), 0), own_ref((size_t)std::max(n, 1), 0);
+  const bool ident_ref = is_identity(forced(p->reference_sensor_offset));
   // descriptors + initial states of all pairs; workspace slots are reused round-robin across sub-batches
   for (int i = 0; i < n; ++i) {
     const pwn_hip_cloud* r = refs[i]; const pwn_hip_cloud* c = curs[i];
@@ -960,6 +961,7 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
     pd.zcur = ctx->zcur_ws + (size_t)slot * ctx->N;
     pd.curidx = ctx->curidx_ws + (size_t)slot * ctx->N;
     // the converter's own index image is what projecting the current cloud would give (see pwn_hip_cloud::idximg)
+    pd.refidx0 = nullptr;
     own_index[i] = batch_shortcut && c->idx_valid && c->idx_rows == p->rows && c->idx_cols == p->cols && c->idx_minD == p->min_distance &&
                    c->idx_maxD == p->max_distance && std::memcmp(c->idx_K, p->K, sizeof(c->idx_K)) == 0;
     pd.partials = ctx->partials_ws + (size_t)slot * ctx->nblocks_max * kAccN;
@@ -969,6 +971,10 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
     std::memset(&st, 0, sizeof(st));
     Mat4 T = mat4_from(guesses ? guesses + 16 * (size_t)i : p->initial_guess);
     set_last_row(T);
+    // first reference projection with an identity pose (identity guess and reference offset): it returns the reference cloud's own index
+    // image, like the current cloud's; later iterations (and the last one, whose z-buffer the statistics pass re-reads) project as usual
+    own_ref[i] = batch_shortcut && p->outer_iterations > 1 && ident_ref && is_identity(T) && r->idx_valid && r->idx_rows == p->rows &&
+                 r->idx_cols == p->cols && r->idx_minD == p->min_distance && r->idx_maxD == p->max_distance && std::memcmp(r->idx_K, p->K, sizeof(r->idx_K)) == 0;
     st.T = T;
     st.invTcorr = iso_inverse(T);
     st.invT = st.invTcorr; set_last_row(st.invT);
@@ -982,6 +988,9 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
   for (int i = 0; i < n; ++i) if (!own_index[i]) sub_own[i / sub] = 0;
   bool any_own = false;
   for (int i = 0; i < n; ++i) if (sub_own[i / sub]) { ctx->pairs_host[i].curidx = curs[i]->idximg; any_own = true; }
+  std::vector<char> sub_ownref(sub_own.size(), 1);
+  for (int i = 0; i < n; ++i) if (!own_ref[i]) sub_ownref[i / sub] = 0;
+  for (int i = 0; i < n; ++i) if (sub_ownref[i / sub]) ctx->pairs_host[i].refidx0 = refs[i]->idximg;
   if (n > 0) {
     HIPCHK(ctx, hipMemcpyAsync(ctx->pairs_dev, ctx->pairs_host, sizeof(PairDesc) * n, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
     HIPCHK(ctx, hipMemcpyAsync(ctx->state_ws, ctx->state_host, sizeof(PairState) * n, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
@@ -1017,14 +1026,15 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
       hipLaunchKernelGGL(k_resolve_cur, dim3(std::min((N + 255) / 256, 1024), m), dim3(256), 0, st, pr, N, subTag0); }
     for (int i = 0; i < p->outer_iterations; ++i) {
       const unsigned tag = subTag0 - (unsigned)i;      // epoch of this outer iteration's reference projection
-      { StageTimer t(ctx, "project", st);
+      const int ownRef = (i == 0 && sub_ownref[kk]) ? 1 : 0;
+      if (!ownRef) { StageTimer t(ctx, "project", st);
         hipLaunchKernelGGL(k_project, dim3((maxcap_ref + 256 * kProjectPointsPerThread - 1) / (256 * kProjectPointsPerThread), m), dim3(256), 0, st, pr, ap, 0, tag); }
       for (int k = 0; k < p->inner_iterations; ++k) {
         const bool lastInner = (k == p->inner_iterations - 1);
         { StageTimer t(ctx, "corr_linearize", st);
           // first inner pass: the linearizer's transform is bitwise the finder's (aligner.cpp:79,84)
-          if (k == 0) hipLaunchKernelGGL((k_corr_linearize<true, false>), dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, tag, 0);
-          else hipLaunchKernelGGL((k_corr_linearize<false, false>), dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, tag, 0); }
+          if (k == 0) hipLaunchKernelGGL((k_corr_linearize<true, false>), dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, tag, 0, ownRef);
+          else hipLaunchKernelGGL((k_corr_linearize<false, false>), dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, tag, 0, ownRef); }
         { StageTimer t(ctx, "solve", st);
           hipLaunchKernelGGL(k_solve_update, dim3(m), dim3(256), 0, st, pr, ap, nb, lastInner ? 1 : 0); }
       }
@@ -1033,7 +1043,7 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
       // Aligner::_computeStatistics' extra Linearizer::update: the finder's correspondences of the last outer iteration
       // (tests with that iteration's transform) re-linearized at the final transform (aligner.cpp:165-170)
       StageTimer t(ctx, "statistics", st);
-      hipLaunchKernelGGL((k_corr_linearize<false, true>), dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, subLastRefTag, 1);   // full H for _computeStatistics
+      hipLaunchKernelGGL((k_corr_linearize<false, true>), dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, subLastRefTag, 1, 0);   // full H for _computeStatistics
       hipLaunchKernelGGL(k_reduce_pairs, dim3(m), dim3(256), 0, st, pr, nb, ctx->stats_dev + base);
     }
     if (scores && p->outer_iterations > 0) {
@@ -1135,8 +1145,8 @@ int pwn_hip_align_with_priors(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p,
       hs.invT = invT;
       HIPCHK(ctx, hipMemcpyAsync(ctx->state_ws, &hs, sizeof(PairState), hipMemcpyHostToDevice, st), PWN_HIP_ERR_COPY);
       if (k == 0) hipLaunchKernelGGL(k_project, dim3((ref->d.capacity + 256 * kProjectPointsPerThread - 1) / (256 * kProjectPointsPerThread), 1), dim3(256), 0, st, ctx->pairs_dev, ap, 0, tag);
-      if (k == 0) hipLaunchKernelGGL((k_corr_linearize<true, true>), dim3(nb, 1), dim3(kAlignBlock), 0, st, ctx->pairs_dev, ap, tag, 0);
-      else hipLaunchKernelGGL((k_corr_linearize<false, true>), dim3(nb, 1), dim3(kAlignBlock), 0, st, ctx->pairs_dev, ap, tag, 0);
+      if (k == 0) hipLaunchKernelGGL((k_corr_linearize<true, true>), dim3(nb, 1), dim3(kAlignBlock), 0, st, ctx->pairs_dev, ap, tag, 0, 0);
+      else hipLaunchKernelGGL((k_corr_linearize<false, true>), dim3(nb, 1), dim3(kAlignBlock), 0, st, ctx->pairs_dev, ap, tag, 0, 0);
       hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, st, ctx->pairs_dev, nb, ctx->stats_dev);
       HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
       HIPCHK(ctx, hipMemcpyAsync(ctx->stats_host, ctx->stats_dev, sizeof(SolveOut), hipMemcpyDeviceToHost, st), PWN_HIP_ERR_COPY);

@@ -100,7 +100,9 @@ struct PairDesc {
   CloudDev ref, cur;
   unsigned long long* zref;
   unsigned long long* zcur;
-  int* curidx;             // index image of the current cloud (resolved once from zcur)
+  int* curidx;             // index image of the current cloud (resolved once from zcur, or the converter's own image)
+  const int* refidx0;      // optional: index image of the reference cloud for the FIRST outer iteration (the converter's own image when the
+                           // initial guess is the identity: that projection returns it), else nullptr
   double* partials;        // [nblocks][kAccN]
   PairState* state;
 };
@@ -1203,7 +1205,7 @@ struct PairPtrs {
   gptr<const v4f> refP, refN, curP, curN;
   gptr<const float> curOm, curOmN;
   gptr<const unsigned long long> zref;
-  gptr<const int> curidx;
+  gptr<const int> curidx, refidx0;
   unsigned cap;      // capacity of the current cloud (plane stride)
 };
 __device__ __forceinline__ PairPtrs pair_ptrs(const PairDesc& pd) {
@@ -1212,6 +1214,7 @@ __device__ __forceinline__ PairPtrs pair_ptrs(const PairDesc& pd) {
   q.curP = as_global((const v4f*)pd.cur.P); q.curN = as_global((const v4f*)pd.cur.Nm);
   q.curOm = as_global((const float*)pd.cur.Om); q.curOmN = as_global((const float*)pd.cur.OmN);
   q.zref = as_global((const unsigned long long*)pd.zref); q.curidx = as_global((const int*)pd.curidx);
+  q.refidx0 = as_global(pd.refidx0);
   q.cap = (unsigned)pd.cur.capacity;
   return q;
 }
@@ -1271,7 +1274,7 @@ template <bool SAME_T, bool FULL_H, int PPT = kPixPerThread>
 #else
 #define PWN_CL_EU_ATTR
 #endif
-__global__ void PWN_CL_EU_ATTR __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_corr_linearize(const PairDesc* __restrict__ pairs, AlignParams ap, unsigned tag, int usePrevTc) {
+__global__ void PWN_CL_EU_ATTR __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_corr_linearize(const PairDesc* __restrict__ pairs, AlignParams ap, unsigned tag, int usePrevTc, int ownRefIndex) {
   const PairDesc& pd = pairs[blockIdx.y];
   const int N = ap.rows * ap.cols;
   const PairState* stp = pd.state;
@@ -1299,7 +1302,10 @@ __global__ void PWN_CL_EU_ATTR __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_co
   auto load_indices = [&](int j, int& ri, int& ci) {
     const int pix = pix0 + j * kAlignBlock;
     ri = -1; ci = -1;
-    if (j < PPT && pix < N) { ri = zkey_index(q.zref[(unsigned)pix], tag); ci = q.curidx[(unsigned)pix]; }
+    if (j < PPT && pix < N) {
+      ri = ownRefIndex ? q.refidx0[(unsigned)pix] : zkey_index(q.zref[(unsigned)pix], tag);      // wave-uniform choice
+      ci = q.curidx[(unsigned)pix];
+    }
   };
   int ri1, ci1, ri2, ci2;
   load_indices(0, ri1, ci1);
