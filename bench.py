@@ -153,7 +153,7 @@ def main():
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
 
-    slots = 2 * max(args.sub_frames, args.sub_pairs, 1)      # room for two sub-batches in flight (two-stream mode)
+    slots = max(2, args.streams) * max(args.sub_frames, args.sub_pairs, 1)      # room for one sub-batch in flight per stream
     ctx = api.Context(device=local, max_rows=rows, max_cols=cols, max_batch=slots)
     ctx.set_subbatch(args.sub_frames, args.sub_pairs)
     converter, aligner = build_objects(ctx, rows, cols, K, conv, alig)

@@ -51,8 +51,9 @@ struct pwn_hip_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t own_stream = nullptr;
-  hipStream_t stream2 = nullptr;           // batch calls alternate sub-batches between `stream` and `stream2` (own streams only)
-  hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+  hipStream_t stream2 = nullptr;           // batch calls deal sub-batches round-robin over `stream`, `stream2` and `extra` (own streams only)
+  hipStream_t extra[2] = { nullptr, nullptr };
+  hipEvent_t fork_ev = nullptr, join_ev = nullptr, join_extra[2] = { nullptr, nullptr };
   int max_rows = 0, max_cols = 0, max_batch = 0;
   size_t N = 0;
   int sub_frames = 64, sub_pairs = 64;
@@ -130,27 +131,36 @@ struct StageTimer {
 };
 // Two-stream mode: only with the context's own streams and when the workspaces hold two sub-batches.
 struct StreamPlan {
-  int sub; bool dual; hipStream_t s[2];
-  hipStream_t stream(int k) const { return s[dual ? (k & 1) : 0]; }
-  int slot0(int k) const { return dual ? (k & 1) * sub : 0; }
+  int sub; int ns; hipStream_t s[4];
+  bool dual() const { return ns > 1; }
+  hipStream_t stream(int k) const { return s[k % ns]; }
+  int slot0(int k) const { return (k % ns) * sub; }
 };
 StreamPlan make_plan(pwn_hip_ctx* ctx, int want_sub, int n) {
   StreamPlan p;
   p.sub = std::max(1, std::min(want_sub, ctx->max_batch));
-  p.dual = ctx->concurrency >= 2 && ctx->stream == ctx->own_stream && ctx->stream2 && n > p.sub && 2 * p.sub <= ctx->max_batch;
-  p.s[0] = ctx->stream; p.s[1] = p.dual ? ctx->stream2 : ctx->stream;
+  const int nsub = (n + p.sub - 1) / p.sub;
+  int ns = 1;
+  if (ctx->stream == ctx->own_stream && ctx->stream2)
+    ns = std::max(1, std::min(std::min(ctx->concurrency, 4), std::min(nsub, ctx->max_batch / p.sub)));
+  if (ns > 2 && (!ctx->extra[0] || (ns > 3 && !ctx->extra[1]))) ns = 2;
+  p.ns = ns;
+  p.s[0] = ctx->stream; p.s[1] = ctx->stream2; p.s[2] = ctx->extra[0]; p.s[3] = ctx->extra[1];
   return p;
 }
-int plan_fork(pwn_hip_ctx* ctx, const StreamPlan& p) {      // stream2 starts after everything enqueued so far on stream
-  if (!p.dual) return PWN_HIP_OK;
+int plan_fork(pwn_hip_ctx* ctx, const StreamPlan& p) {      // the other streams start after everything enqueued so far on `stream`
+  if (!p.dual()) return PWN_HIP_OK;
   HIPCHK(ctx, hipEventRecord(ctx->fork_ev, p.s[0]), PWN_HIP_ERR_LAUNCH);
-  HIPCHK(ctx, hipStreamWaitEvent(p.s[1], ctx->fork_ev, 0), PWN_HIP_ERR_LAUNCH);
+  for (int k = 1; k < p.ns; ++k) HIPCHK(ctx, hipStreamWaitEvent(p.s[k], ctx->fork_ev, 0), PWN_HIP_ERR_LAUNCH);
   return PWN_HIP_OK;
 }
-int plan_join(pwn_hip_ctx* ctx, const StreamPlan& p) {      // stream continues after stream2's work
-  if (!p.dual) return PWN_HIP_OK;
-  HIPCHK(ctx, hipEventRecord(ctx->join_ev, p.s[1]), PWN_HIP_ERR_LAUNCH);
-  HIPCHK(ctx, hipStreamWaitEvent(p.s[0], ctx->join_ev, 0), PWN_HIP_ERR_LAUNCH);
+int plan_join(pwn_hip_ctx* ctx, const StreamPlan& p) {      // `stream` continues after the other streams' work
+  if (!p.dual()) return PWN_HIP_OK;
+  for (int k = 1; k < p.ns; ++k) {
+    hipEvent_t ev = k == 1 ? ctx->join_ev : ctx->join_extra[k - 2];
+    HIPCHK(ctx, hipEventRecord(ev, p.s[k]), PWN_HIP_ERR_LAUNCH);
+    HIPCHK(ctx, hipStreamWaitEvent(p.s[0], ev, 0), PWN_HIP_ERR_LAUNCH);
+  }
   return PWN_HIP_OK;
 }
 void collect_stage_times(pwn_hip_ctx* ctx) {
@@ -468,6 +478,7 @@ int pwn_hip_ctx_create(pwn_hip_ctx** out, int device, int max_rows, int max_cols
   if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return fail(nullptr, PWN_HIP_ERR_ALLOCATION, "hipStreamCreate failed"); }
   ctx->stream = ctx->own_stream;
   (void)hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+  for (int k = 0; k < 2; ++k) { (void)hipStreamCreateWithFlags(&ctx->extra[k], hipStreamNonBlocking); (void)hipEventCreateWithFlags(&ctx->join_extra[k], hipEventDisableTiming); }
   (void)hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming); (void)hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming);
   ALLOC(ctx->depth_ws, B * N * sizeof(float));
   ALLOC(ctx->raw_ws, B * N * sizeof(uint16_t));
@@ -522,6 +533,7 @@ int pwn_hip_ctx_destroy(pwn_hip_ctx* ctx) {
   if (ctx->scene_total) (void)hipFree(ctx->scene_total);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
+  for (int k = 0; k < 2; ++k) { if (ctx->extra[k]) (void)hipStreamDestroy(ctx->extra[k]); if (ctx->join_extra[k]) (void)hipEventDestroy(ctx->join_extra[k]); }
   if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
   if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
   delete ctx;
@@ -544,7 +556,7 @@ int pwn_hip_ctx_set_subbatch(pwn_hip_ctx* ctx, int frames, int pairs) {
   return PWN_HIP_OK;
 }
 int pwn_hip_ctx_set_concurrency(pwn_hip_ctx* ctx, int streams) {
-  if (!ctx || streams < 1 || streams > 2) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "streams must be 1 or 2");
+  if (!ctx || streams < 1 || streams > 4) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "streams must be 1..4");
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
   ctx->concurrency = streams;
   return PWN_HIP_OK;

@@ -142,9 +142,10 @@ int pwn_hip_ctx_synchronize(pwn_hip_ctx* ctx);
  * max_batch), which bounds the workspace the temporaries (integral images, z-buffers) need.  Measured on
  * MI355X: larger sub-batches are faster (fewer, fuller launches).  Results do not depend on it. */
 int pwn_hip_ctx_set_subbatch(pwn_hip_ctx* ctx, int frames, int pairs);
-/* streams = 2 (default): batch calls alternate their sub-batches between two HIP streams of the context when the
- * workspaces hold two sub-batches (max_batch >= 2*sub-batch), so one sub-batch's small kernels overlap the other's
- * large ones; streams = 1: strictly serial launches (use it when profiling per-kernel durations). Results are identical. */
+/* streams = 2 (default): batch calls deal their sub-batches round-robin over up to `streams` (1..4) HIP streams of the context when the
+ * workspaces hold one sub-batch per stream: the short dependent kernels of one sub-batch (projection, 6x6 solve) fill the gaps of the
+ * other's large ones.  Measured on MI355X: 2 streams +12 % over 1, 3 and 4 no better than 2.  streams = 1: strictly serial launches (use
+ * it when profiling per-kernel durations).  Results are identical. */
 int pwn_hip_ctx_set_concurrency(pwn_hip_ctx* ctx, int streams);
 /* ctx may be NULL (errors of ctx_create). Never returns NULL. cf. AlignerStatus::toString (cudaaligner.h:54) */
 const char* pwn_hip_last_error_string(const pwn_hip_ctx* ctx);

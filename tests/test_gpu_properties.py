@@ -49,7 +49,7 @@ def test_results_do_not_depend_on_batching_streams_or_repetition(world):
     ctx, aligner = world["ctx"], world["aligner"]
     base = _digest(aligner.alignBatch(world["refs"], world["curs"]))
     assert _digest(aligner.alignBatch(world["refs"], world["curs"])) == base              # run to run
-    for sub, streams in ((1, 1), (3, 2), (5, 1), (8, 2), (16, 1)):
+    for sub, streams in ((1, 1), (3, 2), (5, 1), (8, 2), (16, 1), (4, 3), (2, 4), (3, 4)):
         ctx.set_subbatch(sub, sub); ctx.set_concurrency(streams)
         assert _digest(aligner.alignBatch(world["refs"], world["curs"])) == base, (sub, streams)
     ctx.set_subbatch(64, 64); ctx.set_concurrency(2)
