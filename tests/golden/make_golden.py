@@ -79,7 +79,7 @@ def record(name, seed, rows, cols, K, conv, alig, ref_mm, cur_mm, true_T):
         out["align_fp64" if mode else "align_fp32_serial"] = dict(
             T=hexf(r["T"]), error=hexf([r["error"]])[0], inliers=r["inliers"],
             iterations=[dict(K=it["K"], C=it["C"], inliers=it["inliers"], chi2=hexf([it["chi2"]])[0], chi2_fp64=it["chi2_fp64"],
-                             T_before=hexf(it["T_before"])) for it in r["iterations"]],
+                             T_before=hexf(it["T_before"]), H=hexf(it["H"]), b=hexf(it["b"])) for it in r["iterations"]],
             cur_index_sha256=sha(r["cur_index"]), cur_depth_sha256=sha(r["cur_depth"]), ref_index_sha256=sha(r["ref_index"]))
     print(name, seed, "M", out["reference"]["M"], out["current"]["M"], "chi2", [it["chi2_fp64"] for it in r["iterations"]][::3])
     return out
