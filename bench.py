@@ -160,7 +160,7 @@ def main():
     # CPU baseline first (rank 0 only), in a child process started before anything touches the GPU: the process that
     # drives the GPU never loads the oracle library
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # at N = 1 only: the other ranks of a multi-GPU run would wait for it
         import subprocess
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--rows", str(rows), "--cols", str(cols),
                               "--cpu-seconds", str(args.cpu_seconds)], capture_output=True, text=True, timeout=600)
