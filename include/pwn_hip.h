@@ -172,7 +172,8 @@ int pwn_hip_cloud_download(pwn_hip_ctx* ctx, const pwn_hip_cloud* cloud, float* 
 /* Stats of the last convert of this cloud (only if the convert ran with keep_stats != 0): per point
  * eigenvectors+mean as a column-major 4x4 (Stats, stats.h:13), eigenvalues[3], n (stats.h:30). */
 int pwn_hip_cloud_download_stats(pwn_hip_ctx* ctx, const pwn_hip_cloud* cloud, float* stats, float* eigenvalues, int* npoints);
-/* Cloud::transformInPlace (cloud.cpp:173-186) */
+/* Cloud::transformInPlace (cloud.cpp:173-186): points, normals, both information matrices (T Omega T^t, informationmatrix.h:111-121), the
+ * Stats when the cloud carries them (m * S, stats.h:125-131) and the Gaussians (gaussian3.h:65-73); skipped when T is the identity (:176) */
 int pwn_hip_cloud_transform_in_place(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud, const float T[16]);
 
 /* ------------------------------------------------------------------ input conditioning ------- */
