@@ -30,11 +30,12 @@ def main():
     from g2o_frontend_amd import api, synth
     from oracle import oracle as O
     from test_gpu_parity import gpu_objects
-    ctx = api.Context(0, 480, 640, 4)
+    ctx = api.Context(0, 480, 640, 16)
     rng = np.random.default_rng(2024)
     stats = dict(cases=0, worst_chi2_rel=0.0, worst_pose=0.0, points=0, merged=0)
     for name, count in (("small", args.small), ("vga", args.vga)):
         rows, cols, K, conv0, alig = case_params(name)
+        kept = []          # (aligner params key, gref, gcur, single result) of the default-configuration cases: re-run as one batch below
         for seed in range(1000, 1000 + count):
             conv = dict(conv0)
             offset = None
@@ -70,6 +71,8 @@ def main():
             g = aligner.align()
             it0 = o["iterations"][0]
             assert (int(g["K"][0]), int(g["C"][0]), int(g["iter_inliers"][0])) == (it0["K"], it0["C"], it0["inliers"]), (name, seed, "counters")
+            if offset is None and conv == conv0 and len(kept) < 16:
+                kept.append((gref, gcur, g))
             rel = abs(float(g["chi2"][0]) - it0["chi2_fp64"]) / max(it0["chi2_fp64"], 1e-30)
             assert rel <= 1e-5, (name, seed, "chi2", rel)
             pose = float(np.abs(g["T"] - o["T"]).max())
@@ -87,6 +90,19 @@ def main():
             stats["cases"] += 1; stats["worst_chi2_rel"] = max(stats["worst_chi2_rel"], rel); stats["worst_pose"] = max(stats["worst_pose"], pose)
             stats["points"] += len(oref) + len(ocur); stats["merged"] += int(((ocol >= 0) & (ocol != np.arange(len(ocol)))).sum())
             print(f"{name} seed {seed}: M {len(oref)}/{len(ocur)} offset {offset is not None} chi2 rel {rel:.1e} pose {pose:.1e} merged {ok}", flush=True)
+        # the batch path (own index images instead of two of the eleven projections, two streams) against the single alignments: bitwise
+        if len(kept) > 1:
+            _, _, aligner = gpu_objects(ctx, name)
+            for sub in (64, 3):
+                ctx.set_subbatch(sub, sub)
+                res = aligner.alignBatch([k[0] for k in kept], [k[1] for k in kept])
+                for r, (_, _, g) in zip(res, kept):
+                    assert np.array_equal(r["T"].view(np.uint32), g["T"].view(np.uint32)) and np.array_equal(r["chi2"].view(np.uint32), g["chi2"].view(np.uint32)), (name, "batch", sub)
+                    assert np.array_equal(r["C"], g["C"]) and np.array_equal(r["K"], g["K"])
+            ctx.set_subbatch(64, 64)
+            stats["batch_checked"] = stats.get("batch_checked", 0) + len(kept)
+            print(f"{name}: batch of {len(kept)} pairs bitwise equal to the single alignments", flush=True)
+        del kept
     print(json.dumps(stats))
     ctx.close()
 
