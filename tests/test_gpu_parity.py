@@ -415,6 +415,13 @@ def test_full_pipeline_1280x960(oracle):
     _check_alignment(o, g)
     _check_teacher_forced(aligner, o)
     assert np.abs(g["T"][:3, 3] - Ttrue[:3, 3]).max() < 5e-3
+    # the batch path at this size (it takes the converter's own index images instead of projecting the current cloud and, for the identity
+    # guess, the reference cloud in the first iteration): bitwise the single alignment, in both pair orders
+    res = aligner.alignBatch([gref, gcur], [gcur, gref])
+    assert np.array_equal(res[0]["T"].view(np.uint32), g["T"].view(np.uint32)) and np.array_equal(res[0]["chi2"].view(np.uint32), g["chi2"].view(np.uint32))
+    aligner.setReferenceCloud(gcur); aligner.setCurrentCloud(gref)
+    h = aligner.align()
+    assert np.array_equal(res[1]["T"].view(np.uint32), h["T"].view(np.uint32)) and np.array_equal(res[1]["chi2"].view(np.uint32), h["chi2"].view(np.uint32))
     big.close()
 
 
