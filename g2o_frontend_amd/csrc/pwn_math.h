@@ -168,6 +168,74 @@ PWN_HD void t2v(const Mat4& T, float v[6]) {
   v[3] = q.x; v[4] = q.y; v[5] = q.z;
 }
 
+#define PWN_TRIG_HD PWN_HD
+#define PWN_TRIG_SIGNBIT(x) __builtin_signbit(x)
+// ---- trig of the 3x3 eigensolver, double precision, + - * / only -----------------------------------------------------
+// The eigensolver needs atan2(sqrt(q), half_b) / 3 and cos / sin of that angle as FLOATS (the reference calls the float libm).
+// Canonical evaluation: in double by the fixed algorithms below (no libm, no FMA: every operation is an IEEE + - * /, so host
+// and device produce the same bits), rounded once to float.  Their error is < 1e-15, so the rounded float is the correctly
+// rounded value -- what a current glibc's atan2f / cosf / sinf return -- except when the true value lies within 1e-15 of a
+// rounding boundary (about one call in 1e8).
+//   atan2(y, x), y >= 0:  t = min/max in [0, 1]; centre c_k = tan(k pi/16), k = 0..4, nearest in angle;
+//                         u = (min - c max) / (max + c min), |u| <= tan(pi/32); atan(u) by its series to u^19; unfold.
+//   sin / cos on [0, pi/3]: Taylor series to x^21 / x^22.
+PWN_TRIG_HD double pwn_atan2_pos(double y, double x) {
+  const double kPi = 3.141592653589793, kPi2 = 1.5707963267948966;
+  if (y == 0.0) return (x < 0.0 || (x == 0.0 && PWN_TRIG_SIGNBIT(x))) ? kPi : 0.0;
+  const double ax = x < 0.0 ? -x : x;
+  const bool swap = ax < y;
+  const double num = swap ? ax : y, den = swap ? y : ax;
+  double c, ac;
+  if (num > 0.8206787908286602 * den)       { c = 1.0;                 ac = 0.7853981633974483; }
+  else if (num > 0.5345111359507916 * den)  { c = 0.6681786379192989;  ac = 0.5890486225480862; }
+  else if (num > 0.3033466836073424 * den)  { c = 0.41421356237309503; ac = 0.39269908169872414; }
+  else if (num > 0.09849140335716425 * den) { c = 0.198912367379658;   ac = 0.19634954084936207; }
+  else                                      { c = 0.0;                 ac = 0.0; }
+  const double u = (num - c * den) / (den + c * num);
+  const double w = u * u;
+  double p = -0.05263157894736842;
+  p = p * w + 0.058823529411764705;
+  p = p * w + -0.06666666666666667;
+  p = p * w + 0.07692307692307693;
+  p = p * w + -0.09090909090909091;
+  p = p * w + 0.1111111111111111;
+  p = p * w + -0.14285714285714285;
+  p = p * w + 0.2;
+  p = p * w + -0.3333333333333333;
+  p = p * w + 1.0;
+  double r = ac + u * p;
+  if (swap) r = kPi2 - r;
+  if (x < 0.0) r = kPi - r;
+  return r;
+}
+PWN_TRIG_HD void pwn_sincos_small(double x, double& s, double& c) {      // 0 <= x <= pi/3 (a little beyond is fine)
+  const double z = x * x;
+  double pc = -8.896791392450574e-22;
+  pc = pc * z + 4.110317623312165e-19;
+  pc = pc * z + -1.5619206968586225e-16;
+  pc = pc * z + 4.779477332387385e-14;
+  pc = pc * z + -1.1470745597729725e-11;
+  pc = pc * z + 2.08767569878681e-09;
+  pc = pc * z + -2.755731922398589e-07;
+  pc = pc * z + 2.48015873015873e-05;
+  pc = pc * z + -0.001388888888888889;
+  pc = pc * z + 0.041666666666666664;
+  pc = pc * z + -0.5;
+  pc = pc * z + 1.0;
+  double ps = 1.9572941063391263e-20;
+  ps = ps * z + -8.22063524662433e-18;
+  ps = ps * z + 2.8114572543455206e-15;
+  ps = ps * z + -7.647163731819816e-13;
+  ps = ps * z + 1.6059043836821613e-10;
+  ps = ps * z + -2.505210838544172e-08;
+  ps = ps * z + 2.7557319223985893e-06;
+  ps = ps * z + -0.0001984126984126984;
+  ps = ps * z + 0.008333333333333333;
+  ps = ps * z + -0.16666666666666666;
+  ps = ps * z + 1.0;
+  s = x * ps; c = pc;
+}
+
 // ---- SelfAdjointEigenSolver<Matrix3f>::computeDirect(A, ComputeEigenvectors) -------------------------
 // (closed-form roots of the characteristic polynomial on the shifted+scaled matrix, eigenvectors by
 // kernel extraction with cross products).  Reads the lower triangle.  evals ascending.
@@ -219,16 +287,18 @@ PWN_HD void eig3_direct(float a00, float a10, float a20, float a11, float a21, f
     float q = a_over_3 * a_over_3 * a_over_3 - half_b * half_b;
     q = fmaxf(q, 0.0f);
     const float rho = sqrtf(a_over_3);
-    // The three trig calls are evaluated correctly rounded (double precision rounded once to float) so
-    // that host libm and device ocml give the same bits; fp64 is cheap on gfx950 and this is 3 calls/pixel.
-#ifdef PWN_TIMING_FLOAT_TRIG      /* timing experiment only: wrong last bits */
-    const float theta = atan2f(sqrtf(q), half_b) * s_inv3;
-    const float cos_theta = cosf(theta);
-    const float sin_theta = sinf(theta);
-#else
+    // The three trig calls: fixed double-precision algorithms rounded once to float (see pwn_atan2_pos): the same bits on the host and on
+    // the device, a third of the instructions of the ocml double routines (this kernel is VALU-bound).
+#ifdef PWN_TRIG_LIBM_DOUBLE       /* the previous canonical form: libm / ocml double routines rounded to float */
     const float theta = (float)atan2((double)sqrtf(q), (double)half_b) * s_inv3;
     const float cos_theta = (float)cos((double)theta);
     const float sin_theta = (float)sin((double)theta);
+#else
+    const float theta = (float)pwn_atan2_pos((double)sqrtf(q), (double)half_b) * s_inv3;
+    double sd, cd;
+    pwn_sincos_small((double)theta, sd, cd);
+    const float cos_theta = (float)cd;
+    const float sin_theta = (float)sd;
 #endif
     e[0] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
     e[1] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);

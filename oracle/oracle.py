@@ -86,6 +86,7 @@ def lib():
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
         L.orc_set_trig_mode.argtypes = [C.c_int]
+        L.orc_trig_eval.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5
         L.orc_add_prior.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         L.orc_compute_statistics.argtypes = [C.c_void_p] * 6
         L.orc_align_statistics.argtypes = [C.c_void_p] * 9
@@ -452,8 +453,17 @@ def num_threads():
     return lib().orc_num_threads()
 
 
-def set_trig_mode(literal_float_libm: bool):
-    lib().orc_set_trig_mode(1 if literal_float_libm else 0)
+def set_trig_mode(mode):
+    """0 / False: canonical fixed double algorithms; 1 / True: literal float libm; 2: double libm rounded to float"""
+    lib().orc_set_trig_mode(int(mode))
+
+
+def trig_eval(mode, y, x):
+    """(theta, cos, sin) floats of the eigensolver for y = sqrt(q), x = half_b in trig mode `mode`"""
+    y = _f32(y); x = _f32(x); n = y.size
+    th = np.empty(n, np.float32); c = np.empty(n, np.float32); s = np.empty(n, np.float32)
+    lib().orc_trig_eval(int(mode), n, _p(y), _p(x), _p(th), _p(c), _p(s))
+    return th, c, s
 
 
 def set_num_threads(n):

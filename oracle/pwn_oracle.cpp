@@ -202,13 +202,98 @@ inline M4 skew4(const V4& v) {
 
 /* --------------------------------------- Eigen SelfAdjointEigenSolver<Matrix3f>::computeDirect */
 /* The reference calls std::atan2/cos/sin on floats, i.e. the host libm's atan2f/cosf/sinf, whose last
- * bit depends on the libm version.  Canonical mode 0 (default) evaluates them CORRECTLY ROUNDED
- * (double-precision libm rounded once to float), which any platform can reproduce bit for bit;
- * mode 1 calls the float libm literally.  tests/ quantify the difference between the two modes. */
+ * bit depends on the libm version.  Canonical mode 0 (default) evaluates them in double precision by the
+ * fixed + - * / algorithms below and rounds once to float, which any platform reproduces bit for bit
+ * (and which is the correctly rounded value except about once in 1e8 calls); mode 1 calls the float libm
+ * literally, mode 2 the double libm.  tests/ quantify the differences between the modes. */
+#define PWN_TRIG_HD static inline
+#define PWN_TRIG_SIGNBIT(x) std::signbit(x)
+
+// ---- trig of the 3x3 eigensolver, double precision, + - * / only -----------------------------------------------------
+// The eigensolver needs atan2(sqrt(q), half_b) / 3 and cos / sin of that angle as FLOATS (the reference calls the float libm).
+// Canonical evaluation: in double by the fixed algorithms below (no libm, no FMA: every operation is an IEEE + - * /, so host
+// and device produce the same bits), rounded once to float.  Their error is < 1e-15, so the rounded float is the correctly
+// rounded value -- what a current glibc's atan2f / cosf / sinf return -- except when the true value lies within 1e-15 of a
+// rounding boundary (about one call in 1e8).
+//   atan2(y, x), y >= 0:  t = min/max in [0, 1]; centre c_k = tan(k pi/16), k = 0..4, nearest in angle;
+//                         u = (min - c max) / (max + c min), |u| <= tan(pi/32); atan(u) by its series to u^19; unfold.
+//   sin / cos on [0, pi/3]: Taylor series to x^21 / x^22.
+PWN_TRIG_HD double orc_atan2_pos(double y, double x) {
+  const double kPi = 3.141592653589793, kPi2 = 1.5707963267948966;
+  if (y == 0.0) return (x < 0.0 || (x == 0.0 && PWN_TRIG_SIGNBIT(x))) ? kPi : 0.0;
+  const double ax = x < 0.0 ? -x : x;
+  const bool swap = ax < y;
+  const double num = swap ? ax : y, den = swap ? y : ax;
+  double c, ac;
+  if (num > 0.8206787908286602 * den)       { c = 1.0;                 ac = 0.7853981633974483; }
+  else if (num > 0.5345111359507916 * den)  { c = 0.6681786379192989;  ac = 0.5890486225480862; }
+  else if (num > 0.3033466836073424 * den)  { c = 0.41421356237309503; ac = 0.39269908169872414; }
+  else if (num > 0.09849140335716425 * den) { c = 0.198912367379658;   ac = 0.19634954084936207; }
+  else                                      { c = 0.0;                 ac = 0.0; }
+  const double u = (num - c * den) / (den + c * num);
+  const double w = u * u;
+  double p = -0.05263157894736842;
+  p = p * w + 0.058823529411764705;
+  p = p * w + -0.06666666666666667;
+  p = p * w + 0.07692307692307693;
+  p = p * w + -0.09090909090909091;
+  p = p * w + 0.1111111111111111;
+  p = p * w + -0.14285714285714285;
+  p = p * w + 0.2;
+  p = p * w + -0.3333333333333333;
+  p = p * w + 1.0;
+  double r = ac + u * p;
+  if (swap) r = kPi2 - r;
+  if (x < 0.0) r = kPi - r;
+  return r;
+}
+PWN_TRIG_HD void orc_sincos_small(double x, double& s, double& c) {      // 0 <= x <= pi/3 (a little beyond is fine)
+  const double z = x * x;
+  double pc = -8.896791392450574e-22;
+  pc = pc * z + 4.110317623312165e-19;
+  pc = pc * z + -1.5619206968586225e-16;
+  pc = pc * z + 4.779477332387385e-14;
+  pc = pc * z + -1.1470745597729725e-11;
+  pc = pc * z + 2.08767569878681e-09;
+  pc = pc * z + -2.755731922398589e-07;
+  pc = pc * z + 2.48015873015873e-05;
+  pc = pc * z + -0.001388888888888889;
+  pc = pc * z + 0.041666666666666664;
+  pc = pc * z + -0.5;
+  pc = pc * z + 1.0;
+  double ps = 1.9572941063391263e-20;
+  ps = ps * z + -8.22063524662433e-18;
+  ps = ps * z + 2.8114572543455206e-15;
+  ps = ps * z + -7.647163731819816e-13;
+  ps = ps * z + 1.6059043836821613e-10;
+  ps = ps * z + -2.505210838544172e-08;
+  ps = ps * z + 2.7557319223985893e-06;
+  ps = ps * z + -0.0001984126984126984;
+  ps = ps * z + 0.008333333333333333;
+  ps = ps * z + -0.16666666666666666;
+  ps = ps * z + 1.0;
+  s = x * ps; c = pc;
+}
+
+/* mode 0 (canonical): the fixed double-precision algorithms above, rounded once to float (what the kernels evaluate, operation for
+ * operation); mode 1: the float libm literally, as the reference; mode 2: the double libm rounded to float (the correctly rounded value
+ * up to libm's own error; tests/ check that mode 0 agrees with it). */
 int g_trig_mode = 0;
-inline float trig_atan2(float y, float x) { return g_trig_mode ? std::atan2(y, x) : (float)std::atan2((double)y, (double)x); }
-inline float trig_cos(float x) { return g_trig_mode ? std::cos(x) : (float)std::cos((double)x); }
-inline float trig_sin(float x) { return g_trig_mode ? std::sin(x) : (float)std::sin((double)x); }
+inline float trig_atan2(float y, float x) {
+  if (g_trig_mode == 1) return std::atan2(y, x);
+  if (g_trig_mode == 2) return (float)std::atan2((double)y, (double)x);
+  return (float)orc_atan2_pos((double)y, (double)x);
+}
+inline float trig_cos(float x) {
+  if (g_trig_mode == 1) return std::cos(x);
+  if (g_trig_mode == 2) return (float)std::cos((double)x);
+  double s, c; orc_sincos_small((double)x, s, c); return (float)c;
+}
+inline float trig_sin(float x) {
+  if (g_trig_mode == 1) return std::sin(x);
+  if (g_trig_mode == 2) return (float)std::sin((double)x);
+  double s, c; orc_sincos_small((double)x, s, c); return (float)s;
+}
 inline void cross3(const float a[3], const float b[3], float r[3]) {
   r[0] = a[1]*b[2] - a[2]*b[1];
   r[1] = a[2]*b[0] - a[0]*b[2];
@@ -1116,7 +1201,14 @@ void orc_eigen3(const float A[9], float evals[3], float evecs[9]) {
   M3 a; std::memcpy(a.m, A, sizeof(a.m)); M3 U; eig3_direct(a, evals, U); std::memcpy(evecs, U.m, sizeof(U.m));
 }
 void orc_ldlt_solve6(const float H[36], const float b[6], float x[6]) { ldlt_solve6(H, b, x); }
-void orc_set_trig_mode(int literal_float_libm) { g_trig_mode = literal_float_libm ? 1 : 0; }
+void orc_set_trig_mode(int mode) { g_trig_mode = (mode == 1 || mode == 2) ? mode : 0; }
+/* the eigensolver's three trig values for (y = sqrt(q), x = half_b) in the given mode: theta = atan2(y, x) / 3 (float), cos, sin */
+void orc_trig_eval(int mode, int n, const float* y, const float* x, float* theta, float* c, float* s) {
+  const int saved = g_trig_mode; g_trig_mode = (mode == 1 || mode == 2) ? mode : 0;
+  const float s_inv3 = 1.0f / 3.0f;
+  for (int i = 0; i < n; ++i) { theta[i] = trig_atan2(y[i], x[i]) * s_inv3; c[i] = trig_cos(theta[i]); s[i] = trig_sin(theta[i]); }
+  g_trig_mode = saved;
+}
 void orc_set_num_threads(int n) {
 #ifdef _OPENMP
   omp_set_num_threads(n > 0 ? n : 1);

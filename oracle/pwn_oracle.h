@@ -186,9 +186,11 @@ int  orc_cloud_load(orc_cloud* c, const char* filename, float T_out[16]);
 /* number of OpenMP threads the parallel (results-identical) loops will use */
 int  orc_num_threads(void);
 void orc_set_num_threads(int n);
-/* eigensolver trig: 0 (default) = correctly rounded via double libm (platform-independent bits);
- * 1 = literal float libm calls as the reference makes them (last bit depends on the libm version) */
-void orc_set_trig_mode(int literal_float_libm);
+/* eigensolver trig: 0 (default, canonical) = fixed double-precision algorithms (+ - * / only, the same operations as the kernels) rounded
+ * once to float; 1 = literal float libm calls as the reference makes them (last bit depends on the libm version); 2 = double libm rounded
+ * to float */
+void orc_set_trig_mode(int mode);
+void orc_trig_eval(int mode, int n, const float* y, const float* x, float* theta, float* c, float* s);
 
 #ifdef __cplusplus
 }

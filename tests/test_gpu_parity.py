@@ -4,7 +4,7 @@ Bars (BASELINE.json north_star):
   * integer / index outputs (index images, interval images, correspondence lists, counts): bit-exact;
   * unprojected points, integral image, projected depth images: bit-exact (same fp32 op order, no FMA);
   * normals / curvature / eigenvalues / Stats / both information matrices: bit-exact as well (the eigensolver's
-    three trig calls are evaluated correctly rounded on both sides, see oracle/pwn_oracle.cpp g_trig_mode);
+    three trig calls are evaluated by the same fixed double-precision algorithms on both sides, see oracle/pwn_oracle.cpp g_trig_mode);
   * per-iteration chi2 at the SAME iterate (teacher-forced with the oracle's T_i): |d|/chi2 <= 1e-5 against the
     oracle's fp64-accumulated value, counters K_i / C_i / inliers_i exact;
   * free-running chi2 trace: the iterates differ in the last bits (summation order of H, b), which can move a

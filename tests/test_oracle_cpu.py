@@ -313,7 +313,7 @@ def test_sensor_offset_consistency(oracle):
 
 
 def test_trig_mode_sensitivity(oracle):
-    """Canonical mode (correctly rounded trig) vs literal float-libm calls as the reference makes them:
+    """Canonical mode (trig rounded once from double precision) vs literal float-libm calls as the reference makes them:
     quantifies how much of the converter output depends on the host libm's last bit."""
     rows, cols, K, conv, _ = case_params("small")
     depth, _, _, _, _ = make_depth_pair("small", 1)
@@ -332,6 +332,26 @@ def test_trig_mode_sensitivity(oracle):
     same = float((dn == 0).mean())
     print(f"trig modes: {same * 100:.1f}% of normals bit-identical, median |dn| {np.median(dn):.2e}, max {dn.max():.2e}")
     assert np.quantile(dn, 0.99) < 1e-4
+
+
+def test_canonical_trig_is_the_correctly_rounded_value(oracle):
+    """The eigensolver's trig in canonical mode (fixed double-precision + - * / algorithms, the very operations the kernels execute) against
+    the double libm rounded to float, over 2 M random arguments of all magnitudes and the special points (zeros of both signs, the axes, the
+    diagonal): equal everywhere -- an error below 1e-15 changes the rounded float about once in 1e8 calls, so a couple of differing values
+    are tolerated, and none may differ by more than one ulp."""
+    rng = np.random.default_rng(7)
+    n = 2_000_000
+    y = np.abs(rng.standard_normal(n)).astype(np.float32) * np.float32(10.0) ** rng.integers(-7, 3, n).astype(np.float32)
+    x = rng.standard_normal(n).astype(np.float32) * np.float32(10.0) ** rng.integers(-7, 3, n).astype(np.float32)
+    y[:1000] = 0; x[:500] = np.float32(-0.0); x[500:1000] = 0.0; y[1000:2000] = 1.0; x[1000:1500] = 1.0; x[1500:2000] = -1.0
+    x[2000:2500] = 0.0; x[2500:3000] = np.float32(-0.0)
+    a, b = oracle.trig_eval(0, y, x), oracle.trig_eval(2, y, x)
+    for got, want, name in zip(a, b, ("theta", "cos", "sin")):
+        diff = got.view(np.int32).astype(np.int64) - want.view(np.int32).astype(np.int64)
+        assert int((diff != 0).sum()) <= 3 and int(np.abs(diff).max()) <= 1, (name, int((diff != 0).sum()))
+    th = a[0]
+    assert th.min() >= 0 and th.max() <= np.float32(np.pi / 3) * (1 + 1e-6)
+    assert np.all(a[0][:500] == np.float32(np.pi) * np.float32(1.0 / 3.0)) and np.all(a[0][500:1000] == 0)      # atan2(+0, -0) = pi, atan2(+0, +0) = 0
 
 
 # ---------------------------------------------------------------------------------------- generator
