@@ -773,7 +773,7 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
   if (idx < 0 || idx >= cap) return;
   const int itv = stream_load(ginterval + upix);
   float4 P;
-  { const gptr<const float> pp = gP + 4u * (unsigned)idx; P.x = stream_load(pp); P.y = stream_load(pp + 1); P.z = stream_load(pp + 2); P.w = 0.f; }
+  { const v4f pv = stream_load((gptr<const v4f>)(gP + 4u * (unsigned)idx)); P.x = pv.x; P.y = pv.y; P.z = pv.z; P.w = 0.f; }      // one 16-byte load
   float nx = 0.f, ny = 0.f, nz = 0.f;
   float curvature = 0.f;          // Stats() default: eigenvalues 0 -> curvature() = 0/(0+1e-9) = 0  (stats.h:21-27,98-103)
   int cls = 0;
@@ -889,9 +889,11 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
   }
   P.w = curvature;
   {
-    const gptr<float> pp = gP + 4u * (unsigned)idx, np_ = gN + 4u * (unsigned)idx;
-    stream_store(pp, P.x); stream_store(pp + 1, P.y); stream_store(pp + 2, P.z); stream_store(pp + 3, P.w);
-    stream_store(np_, nx); stream_store(np_ + 1, ny); stream_store(np_ + 2, nz); stream_store(np_ + 3, __int_as_float(cls));
+    // one 16-byte store each (four dword stores per lane would write every 1 KiB segment of the wave four times at quarter density)
+    v4f pv; pv.x = P.x; pv.y = P.y; pv.z = P.z; pv.w = P.w;
+    v4f nv; nv.x = nx; nv.y = ny; nv.z = nz; nv.w = __int_as_float(cls);
+    stream_store((gptr<v4f>)(gP + 4u * (unsigned)idx), pv);
+    stream_store((gptr<v4f>)(gN + 4u * (unsigned)idx), nv);
   }
 #pragma unroll
   for (int k = 0; k < 9; ++k) stream_store((gptr<float>)((gptr<char>)(gOm + (size_t)k * (size_t)cap) + 4u * (unsigned)idx), om[k]);
