@@ -174,7 +174,6 @@ int pwn_hip_cloud_add(pwn_hip_ctx* ctx, pwn_hip_cloud* dst, const pwn_hip_cloud*
   // _gaussians.resize(k + cloud.gaussians().size()) (cloud.cpp:153): entries the source does not provide are default Gaussians
   if (dst->sb.G) {
     const int newg = k + (srcGauss ? src->n_gauss : 0);
-    if (newg > dst->n_gauss && !srcGauss) { /* nothing appended */ }
     if (k > dst->n_gauss) HIPCHK(ctx, hipMemset(dst->sb.Gf + dst->n_gauss, 0, sizeof(int) * (size_t)(k - dst->n_gauss)), PWN_HIP_ERR_COPY);
     dst->n_gauss = std::min(newg, dst->d.capacity);
   }
