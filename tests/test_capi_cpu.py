@@ -97,6 +97,33 @@ def test_no_device_fails_loudly():
     assert e.value.code == 2 and "no CPU fallback" in str(e.value)
 
 
+def test_null_arguments_are_status_codes_not_crashes():
+    """every entry point that takes a context rejects a null one (and null handles) with PWN_HIP_ERR_INVALID_ARGUMENT -- no device needed"""
+    from g2o_frontend_amd import _lib
+    L = _lib.lib()
+    T = (C.c_float * 16)(*np.eye(4, dtype=np.float32).ravel()); K = (C.c_float * 9)(525, 0, 0, 0, 525, 0, 319.5, 239.5, 1)
+    n = C.c_int(0); out = (C.c_float * 16)()
+    cases = {
+        "pwn_hip_cloud_add": (None, None, None, T),
+        "pwn_hip_merge": (None, None, K, T, 0.5, 4.5, 120, 160, 0.1, 0.98, 10.0, C.byref(n), None),
+        "pwn_hip_voxelize": (None, None, 0.01, C.byref(n), None),
+        "pwn_hip_cloud_save": (None, None, b"/tmp/x.pwn", T, 1, 0),
+        "pwn_hip_cloud_load": (None, None, b"/tmp/x.pwn", out),
+        "pwn_hip_cloud_gaussians": (None, None, None, 120, 160, None, 0.075, 0.1),
+        "pwn_hip_cloud_download_gaussians": (None, None, None, None, None, None, None),
+        "pwn_hip_cloud_num_gaussians": (None, None, C.byref(n)),
+        "pwn_hip_cloud_transform_in_place": (None, None, T),
+        "pwn_hip_ctx_set_concurrency": (None, 2),
+        "pwn_hip_ctx_set_subbatch": (None, 64, 64),
+        "pwn_hip_align": (None, None, None, None, None),
+        "pwn_hip_convert": (None, None, None, 120, 160, None, None, None, 0),
+    }
+    for name, args in cases.items():
+        rc = getattr(L, name)(*args)
+        assert rc == 1, (name, rc)
+        assert L.pwn_hip_last_error_string(None)
+
+
 def test_product_does_not_import_the_oracle():
     """The oracle is test infrastructure: nothing under g2o_frontend_amd/ or include/ may reference it."""
     pat = re.compile(r"(from\s+oracle|import\s+oracle|oracle\.|pwn_oracle|libpwn_oracle|orc_[a-z_]+\()")
