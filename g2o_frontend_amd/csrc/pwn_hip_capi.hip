@@ -90,9 +90,22 @@ struct pwn_hip_ctx {
   int* scene_i[8] = { nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr }; size_t scene_icap = 0;
   unsigned long long* scene_k[3] = { nullptr, nullptr, nullptr }; size_t scene_kcap = 0;
   int* scene_total = nullptr;
+  // Retired clouds kept for reuse: pwn_hip_cloud_create / _destroy are called once per frame by makeCloud-style callers (the reference
+  // returns a `new Cloud` per depth image, pwn_matcher_base.cpp:77-85), and hipMalloc / hipFree of the point arrays cost more than the
+  // conversion of a frame.  Bounded by kCloudPoolBytes.
+  std::vector<pwn_hip_cloud*> cloud_pool; size_t cloud_pool_bytes = 0;
 };
 
 namespace {
+
+constexpr size_t kCloudPoolBytes = 1ull << 30;
+size_t cloud_core_bytes(const pwn_hip_cloud* c) { return (size_t)c->d.capacity * (2 * sizeof(float4) + 9 * sizeof(float)) + c->idx_cap * sizeof(int); }
+void cloud_free(pwn_hip_cloud* c) {
+  void* p[] = { c->d.P, c->d.Nm, c->d.Om, c->d.OmN, c->d.St, c->d.count, c->sb.G, c->sb.Gf,
+                c->back.P, c->back.Nm, c->back.Om, c->back.OmN, c->back.St, c->sback.G, c->sback.Gf, c->idximg };
+  for (void* q : p) if (q) (void)hipFree(q);
+  delete c;
+}
 
 int fail(pwn_hip_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg;
@@ -528,6 +541,8 @@ int pwn_hip_ctx_destroy(pwn_hip_ctx* ctx) {
   for (hipEvent_t e : ctx->event_pool) (void)hipEventDestroy(e);
   if (ctx->t0) (void)hipEventDestroy(ctx->t0);
   if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+  for (pwn_hip_cloud* r : ctx->cloud_pool) cloud_free(r);
+  ctx->cloud_pool.clear();
   for (int k = 0; k < 8; ++k) if (ctx->scene_i[k]) (void)hipFree(ctx->scene_i[k]);
   for (int k = 0; k < 3; ++k) if (ctx->scene_k[k]) (void)hipFree(ctx->scene_k[k]);
   if (ctx->scene_total) (void)hipFree(ctx->scene_total);
@@ -579,6 +594,15 @@ int pwn_hip_cloud_create(pwn_hip_ctx* ctx, int capacity, pwn_hip_cloud** out) {
   if (!ctx || !out || capacity <= 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "bad cloud_create argument");
   if (capacity > kMaxCloudPoints) return fail(ctx, PWN_HIP_ERR_CAPACITY, "a cloud holds at most 2^21 points (z-buffer word layout)");
   HIPCHK(ctx, hipSetDevice(ctx->device), PWN_HIP_ERR_NO_DEVICE);
+  for (size_t k = 0; k < ctx->cloud_pool.size(); ++k) {
+    pwn_hip_cloud* r = ctx->cloud_pool[k];
+    if (r->d.capacity != capacity) continue;
+    ctx->cloud_pool.erase(ctx->cloud_pool.begin() + (long)k);
+    ctx->cloud_pool_bytes -= cloud_core_bytes(r);
+    HIPCHK(ctx, hipMemsetAsync(r->d.count, 0, sizeof(int), ctx->stream), PWN_HIP_ERR_COPY);      // stream order: after whatever used the retired cloud
+    *out = r;
+    return PWN_HIP_OK;
+  }
   pwn_hip_cloud* c = new pwn_hip_cloud();
   std::memset(&c->d, 0, sizeof(c->d));
   c->d.capacity = capacity;
@@ -594,11 +618,18 @@ int pwn_hip_cloud_create(pwn_hip_ctx* ctx, int capacity, pwn_hip_cloud** out) {
 }
 int pwn_hip_cloud_destroy(pwn_hip_ctx* ctx, pwn_hip_cloud* c) {
   if (!c) return PWN_HIP_OK;
+  // plain clouds (no scene-stage or uploaded extras) retire into the context's pool: every call that used them has joined its streams
+  // back into ctx->stream before returning, and a reuse is enqueued on that stream
+  const bool plain = !c->d.OmN && !c->d.St && !c->sb.G && !c->sb.Gf && !c->back.P && !c->back.Nm && !c->back.Om && !c->back.OmN && !c->back.St &&
+                     !c->sback.G && !c->sback.Gf;
+  if (ctx && plain && c->d.P && c->d.Nm && c->d.Om && c->d.count && ctx->cloud_pool_bytes + cloud_core_bytes(c) <= kCloudPoolBytes) {
+    c->n_host = 0; c->has_stats = false; c->n_gauss = 0; c->idx_valid = false;
+    ctx->cloud_pool.push_back(c);
+    ctx->cloud_pool_bytes += cloud_core_bytes(c);
+    return PWN_HIP_OK;
+  }
   if (ctx) (void)hipStreamSynchronize(ctx->stream);
-  void* p[] = { c->d.P, c->d.Nm, c->d.Om, c->d.OmN, c->d.St, c->d.count, c->sb.G, c->sb.Gf,
-                c->back.P, c->back.Nm, c->back.Om, c->back.OmN, c->back.St, c->sback.G, c->sback.Gf, c->idximg };
-  for (void* q : p) if (q) (void)hipFree(q);
-  delete c;
+  cloud_free(c);
   return PWN_HIP_OK;
 }
 int pwn_hip_cloud_size(pwn_hip_ctx* ctx, const pwn_hip_cloud* c, int* n) {
