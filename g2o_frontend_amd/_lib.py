@@ -109,6 +109,7 @@ PROTOTYPES = {
     "pwn_hip_iso_mul": (None, [_VP, _VP, _VP]),
     "pwn_hip_v2t": (None, [_VP, _VP]),
     "pwn_hip_t2v": (None, [_VP, _VP]),
+    "pwn_hip_ldlt_solve6": (None, [_VP, _VP, _VP]),
     "pwn_hip_cloud_gaussians": (_I, [_VP, _VP, _VP, _I, _I, _VP, _F, _F]),
     "pwn_hip_cloud_num_gaussians": (_I, [_VP, _VP, C.POINTER(_I)]),
     "pwn_hip_cloud_download_gaussians": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),

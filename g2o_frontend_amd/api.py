@@ -905,3 +905,12 @@ def t2v(T):
     v = np.empty(6, np.float32)
     _lib.lib().pwn_hip_t2v(_ptr(_colmajor(T, 4)), _ptr(v))
     return v
+
+
+def ldlt_solve6(H, b):
+    """Matrix6f::ldlt().solve(b) (pwn_core/aligner.cpp:110): host compilation of the device function"""
+    Hc = np.ascontiguousarray(np.asarray(H, np.float32).T).reshape(-1)      # column-major
+    bc = np.ascontiguousarray(b, np.float32)
+    x = np.empty(6, np.float32)
+    _lib.lib().pwn_hip_ldlt_solve6(_ptr(Hc), _ptr(bc), _ptr(x))
+    return x

@@ -1280,6 +1280,7 @@ void pwn_hip_iso_inverse(const float T[16], float out[16]) { const Mat4 r = iso_
 void pwn_hip_iso_mul(const float A[16], const float B[16], float out[16]) { const Mat4 r = iso_mul(mat4_from(A), mat4_from(B)); std::memcpy(out, r.m, sizeof(r.m)); }
 void pwn_hip_v2t(const float v[6], float T[16]) { const Mat4 t = v2t(v); std::memcpy(T, t.m, sizeof(t.m)); }
 void pwn_hip_t2v(const float T[16], float v[6]) { t2v(mat4_from(T), v); }
+void pwn_hip_ldlt_solve6(const float H[36], const float b[6], float x[6]) { ldlt_solve6(H, b, x); }
 
 }  // extern "C"
 

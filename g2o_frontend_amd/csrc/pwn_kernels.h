@@ -1432,23 +1432,28 @@ __device__ __forceinline__ void reduce_partials(const double* partials, int nblo
 }
 __device__ __forceinline__ void assemble_Hb(const double* s, float* H, float* b) {
   // Linearizer.cpp:109-114
+#pragma unroll
   for (int i = 0; i < 3; ++i)
+#pragma unroll
     for (int j = 0; j < 3; ++j) {
       H[i + 6 * j] = (float)s[0 + i + 3 * j];
       H[i + 6 * (j + 3)] = (float)s[9 + i + 3 * j];
       H[(i + 3) + 6 * (j + 3)] = (float)s[18 + i + 3 * j];
     }
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) H[(i + 3) + 6 * j] = H[j + 6 * (i + 3)];
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) H[(i + 3) + 6 * j] = H[j + 6 * (i + 3)];
+#pragma unroll
   for (int i = 0; i < 3; ++i) { b[i] = (float)s[27 + i]; b[i + 3] = (float)s[30 + i]; }
 }
 __global__ void __launch_bounds__(256) k_solve_update(const PairDesc* __restrict__ pairs, AlignParams ap, int nblocks, int outerEnd) {
   const PairDesc& pd = pairs[blockIdx.x];
   __shared__ double sums[kAccN];
-  __shared__ float Hs[36], bs[6], ws[54];
   reduce_partials(pd.partials, nblocks, sums);
   if (threadIdx.x != 0) return;
   PairState& st = *pd.state;
-  float* H = Hs; float* b = bs;
+  float H[36], b[6];                                                     // registers: every index below is a constant
   assemble_Hb(sums, H, b);
   const int it = st.it;
   if (it < kMaxIter) {
@@ -1458,11 +1463,14 @@ __global__ void __launch_bounds__(256) k_solve_update(const PairDesc* __restrict
     st.ncand[it] = (int)sums[36];
   }
   st.it = it + 1;
+#pragma unroll
   for (int d = 0; d < 6; ++d) H[d + 6 * d] = H[d + 6 * d] + 1.0f;        // aligner.cpp:92
+#pragma unroll
   for (int d = 0; d < 6; ++d) H[d + 6 * d] = H[d + 6 * d] + 1000.0f;     // aligner.cpp:94
   float nb[6], dx[6];
+#pragma unroll
   for (int d = 0; d < 6; ++d) nb[d] = -b[d];
-  ldlt_solve6_ws(H, nb, dx, ws);
+  ldlt_solve6(H, nb, dx);
   Mat4 invT = st.invT;
   set_last_row(invT);
   invT = iso_mul(v2t(dx), invT);

@@ -129,31 +129,39 @@ PWN_HD Mat3 quat2mat(float qx, float qy, float qz) {
 }
 // Quaternionf(Matrix3f) + normalize() + sign fix (pwn_core/bm_se3.h:25-35)
 PWN_HD Vec3 mat2quat(const Mat3& R) {
-  float q[4];  // x y z w
+  float x, y, z, w;
   float t = (R(0,0) + R(1,1)) + R(2,2);
   if (t > 0.f) {
     t = sqrtf(t + 1.0f);
-    q[3] = 0.5f * t;
+    w = 0.5f * t;
     t = 0.5f / t;
-    q[0] = (R(2,1) - R(1,2)) * t;
-    q[1] = (R(0,2) - R(2,0)) * t;
-    q[2] = (R(1,0) - R(0,1)) * t;
+    x = (R(2,1) - R(1,2)) * t;
+    y = (R(0,2) - R(2,0)) * t;
+    z = (R(1,0) - R(0,1)) * t;
   } else {
+    // Eigen: i = index of the largest diagonal entry, j = (i+1)%3, k = (j+1)%3; q[i] = t/2, w = (R(k,j)-R(j,k)) t', q[j] = (R(j,i)+R(i,j)) t',
+    // q[k] = (R(k,i)+R(i,k)) t' -- written out per i so that no index is a run-time value (registers, not scratch, on the device)
     int i = 0;
     if (R(1,1) > R(0,0)) i = 1;
-    if (R(2,2) > R(i,i)) i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    t = sqrtf(R(i,i) - R(j,j) - R(k,k) + 1.0f);
-    q[i] = 0.5f * t;
-    t = 0.5f / t;
-    q[3] = (R(k,j) - R(j,k)) * t;
-    q[j] = (R(j,i) + R(i,j)) * t;
-    q[k] = (R(k,i) + R(i,k)) * t;
+    if (R(2,2) > (i == 0 ? R(0,0) : R(1,1))) i = 2;
+    if (i == 0) {
+      t = sqrtf(R(0,0) - R(1,1) - R(2,2) + 1.0f);
+      x = 0.5f * t; t = 0.5f / t;
+      w = (R(2,1) - R(1,2)) * t; y = (R(1,0) + R(0,1)) * t; z = (R(2,0) + R(0,2)) * t;
+    } else if (i == 1) {
+      t = sqrtf(R(1,1) - R(2,2) - R(0,0) + 1.0f);
+      y = 0.5f * t; t = 0.5f / t;
+      w = (R(0,2) - R(2,0)) * t; z = (R(2,1) + R(1,2)) * t; x = (R(0,1) + R(1,0)) * t;
+    } else {
+      t = sqrtf(R(2,2) - R(0,0) - R(1,1) + 1.0f);
+      z = 0.5f * t; t = 0.5f / t;
+      w = (R(1,0) - R(0,1)) * t; x = (R(0,2) + R(2,0)) * t; y = (R(1,2) + R(2,1)) * t;
+    }
   }
-  const float n = sqrtf((q[0]*q[0] + q[1]*q[1]) + (q[2]*q[2] + q[3]*q[3]));
-  for (int a = 0; a < 4; ++a) q[a] = q[a] / n;
-  Vec3 r = { q[0], q[1], q[2] };
-  if (q[3] < 0.f) { r.x = -r.x; r.y = -r.y; r.z = -r.z; }
+  const float n = sqrtf((x*x + y*y) + (z*z + w*w));
+  x = x / n; y = y / n; z = z / n; w = w / n;
+  Vec3 r = { x, y, z };
+  if (w < 0.f) { r.x = -r.x; r.y = -r.y; r.z = -r.z; }
   return r;
 }
 // pwn_core/bm_se3.h:37-43
@@ -337,69 +345,112 @@ PWN_HD void eig3_direct(float a00, float a10, float a20, float a11, float a21, f
 }
 
 // ---- Matrix6f::ldlt().solve(b): pivoted (largest |diagonal|) LDL^T, fp32 -------------------------------
-// ws: caller-provided workspace of >= 54 floats (on the device: LDS, so that the dynamically indexed
-// factorisation does not live in scratch memory)
-PWN_HD void ldlt_solve6_ws(const float Hin[36], const float bin[6], float x[6], float* ws) {
-  const int n = 6;
-  float* A = ws;            // 36
-  float* temp = ws + 36;    // 6
-  float* d = ws + 42;       // 6
-  float* trf = ws + 48;     // 6 (transposition indices stored as floats)
-  for (int i = 0; i < 36; ++i) A[i] = Hin[i];
+// Every index is a compile-time constant (the step k is a template parameter, the pivot row p selects one of the
+// statically indexed swap bodies), so that the 6x6 factorisation lives in registers on the device: the one thread per pair
+// that runs it would otherwise walk a chain of dependent LDS (or scratch) round trips.  The arithmetic -- the operations and
+// their order -- is that of Eigen's ldlt_inplace<Lower>::unblocked followed by LDLT::_solve_impl.
 #define PWN_A(r, c) A[(r) + 6 * (c)]
-#define tr_get(k) ((int)trf[k])
-  for (int i = 0; i < 6; ++i) { trf[i] = (float)i; temp[i] = 0.f; }
-  float cutoff = 0.f;
-  for (int k = 0; k < n; ++k) {
-    int p = k; float big = fabsf(PWN_A(k,k));
-    for (int i = k + 1; i < n; ++i) if (fabsf(PWN_A(i,i)) > big) { big = fabsf(PWN_A(i,i)); p = i; }
-    if (k == 0) cutoff = fabsf(FLT_EPSILON * big);
-    if (big < cutoff) { for (int i = k; i < n; ++i) trf[i] = (float)i; break; }
-    trf[k] = (float)p;
-    if (k != p) {
-      for (int j = 0; j < k; ++j) { const float t = PWN_A(k,j); PWN_A(k,j) = PWN_A(p,j); PWN_A(p,j) = t; }
-      for (int i = p + 1; i < n; ++i) { const float t = PWN_A(i,k); PWN_A(i,k) = PWN_A(i,p); PWN_A(i,p) = t; }
-      { const float t = PWN_A(k,k); PWN_A(k,k) = PWN_A(p,p); PWN_A(p,p) = t; }
-      for (int i = k + 1; i < p; ++i) { const float t = PWN_A(i,k); PWN_A(i,k) = PWN_A(p,i); PWN_A(p,i) = t; }
-    }
-    if (k > 0) {
-      for (int j = 0; j < k; ++j) temp[j] = PWN_A(j,j) * PWN_A(k,j);
-      float d = PWN_A(k,0) * temp[0];
-      for (int j = 1; j < k; ++j) d = d + PWN_A(k,j) * temp[j];
-      PWN_A(k,k) = PWN_A(k,k) - d;
-      for (int i = k + 1; i < n; ++i) {
-        float s = PWN_A(i,0) * temp[0];
-        for (int j = 1; j < k; ++j) s = s + PWN_A(i,j) * temp[j];
-        PWN_A(i,k) = PWN_A(i,k) - s;
-      }
-    }
-    if (k + 1 < n && fabsf(PWN_A(k,k)) > cutoff)
-      for (int i = k + 1; i < n; ++i) PWN_A(i,k) = PWN_A(i,k) / PWN_A(k,k);
+// conditional swap as two selects: the addresses stay compile-time constants whatever the pivot row is (a branch per pivot row
+// gets its stores merged into one store through a selected address, which puts the matrix into scratch memory)
+PWN_HD void ldlt_cswap(bool m, float& a, float& b) { const float ta = m ? b : a, tb = m ? a : b; a = ta; b = tb; }
+template <int K, int P> PWN_HD void ldlt_pivot_swap(float (&A)[36], bool m) {    // symmetric row/column swap K <-> P, lower triangle
+#pragma unroll
+  for (int j = 0; j < K; ++j) ldlt_cswap(m, PWN_A(K, j), PWN_A(P, j));
+#pragma unroll
+  for (int i = P + 1; i < 6; ++i) ldlt_cswap(m, PWN_A(i, K), PWN_A(i, P));
+  ldlt_cswap(m, PWN_A(K, K), PWN_A(P, P));
+#pragma unroll
+  for (int i = K + 1; i < P; ++i) ldlt_cswap(m, PWN_A(i, K), PWN_A(P, i));
+}
+template <int K, int P> PWN_HD void ldlt_pivot_dispatch(float (&A)[36], int p) {
+  if constexpr (P < 6) {
+    ldlt_pivot_swap<K, P>(A, p == P);
+    ldlt_pivot_dispatch<K, P + 1>(A, p);
   }
+}
+template <int K, int P> PWN_HD void ldlt_perm_dispatch(float (&d)[6], int p) {   // swap d[K] <-> d[p]
+  if constexpr (P < 6) {
+    ldlt_cswap(p == P, d[K], d[P]);
+    ldlt_perm_dispatch<K, P + 1>(d, p);
+  }
+}
+// one step of the factorisation; false = the remaining diagonal is below the cutoff (the factorisation stops)
+template <int K> PWN_HD bool ldlt_step(float (&A)[36], int (&tr)[6], float& cutoff) {
+  int p = K; float big = fabsf(PWN_A(K, K));
+#pragma unroll
+  for (int i = K + 1; i < 6; ++i) if (fabsf(PWN_A(i, i)) > big) { big = fabsf(PWN_A(i, i)); p = i; }
+  if (K == 0) cutoff = fabsf(FLT_EPSILON * big);
+  if (big < cutoff) return false;
+  tr[K] = p;
+  ldlt_pivot_dispatch<K, K + 1>(A, p);
+  if constexpr (K > 0) {
+    float temp[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) temp[j] = PWN_A(j, j) * PWN_A(K, j);
+    float d = PWN_A(K, 0) * temp[0];
+#pragma unroll
+    for (int j = 1; j < K; ++j) d = d + PWN_A(K, j) * temp[j];
+    PWN_A(K, K) = PWN_A(K, K) - d;
+#pragma unroll
+    for (int i = K + 1; i < 6; ++i) {
+      float s = PWN_A(i, 0) * temp[0];
+#pragma unroll
+      for (int j = 1; j < K; ++j) s = s + PWN_A(i, j) * temp[j];
+      PWN_A(i, K) = PWN_A(i, K) - s;
+    }
+  }
+  if constexpr (K + 1 < 6) {
+    if (fabsf(PWN_A(K, K)) > cutoff) {
+#pragma unroll
+      for (int i = K + 1; i < 6; ++i) PWN_A(i, K) = PWN_A(i, K) / PWN_A(K, K);
+    }
+  }
+  return true;
+}
+PWN_HD void ldlt_solve6(const float Hin[36], const float bin[6], float x[6]) {
+  float A[36];
+#pragma unroll
+  for (int i = 0; i < 36; ++i) A[i] = Hin[i];
+  int tr[6] = {0, 1, 2, 3, 4, 5};
+  float cutoff = 0.f;
+  (void)(ldlt_step<0>(A, tr, cutoff) && ldlt_step<1>(A, tr, cutoff) && ldlt_step<2>(A, tr, cutoff) && ldlt_step<3>(A, tr, cutoff) &&
+         ldlt_step<4>(A, tr, cutoff) && ldlt_step<5>(A, tr, cutoff));
+  float d[6];
+#pragma unroll
   for (int i = 0; i < 6; ++i) d[i] = bin[i];
-  for (int k = 0; k < n; ++k) if (tr_get(k) != k) { const float t = d[k]; d[k] = d[tr_get(k)]; d[tr_get(k)] = t; }
-  for (int i = 1; i < n; ++i) {
-    float s = PWN_A(i,0) * d[0];
-    for (int j = 1; j < i; ++j) s = s + PWN_A(i,j) * d[j];
+  ldlt_perm_dispatch<0, 1>(d, tr[0]);
+  ldlt_perm_dispatch<1, 2>(d, tr[1]);
+  ldlt_perm_dispatch<2, 3>(d, tr[2]);
+  ldlt_perm_dispatch<3, 4>(d, tr[3]);
+  ldlt_perm_dispatch<4, 5>(d, tr[4]);
+#pragma unroll
+  for (int i = 1; i < 6; ++i) {                          // L^-1 (unit lower)
+    float s = PWN_A(i, 0) * d[0];
+#pragma unroll
+    for (int j = 1; j < i; ++j) s = s + PWN_A(i, j) * d[j];
     d[i] = d[i] - s;
   }
   float dmax = 0.f;
-  for (int i = 0; i < n; ++i) dmax = fmaxf(dmax, fabsf(PWN_A(i,i)));
+#pragma unroll
+  for (int i = 0; i < 6; ++i) dmax = fmaxf(dmax, fabsf(PWN_A(i, i)));
   const float tol = fmaxf(dmax * FLT_EPSILON, 1.0f / FLT_MAX);
-  for (int i = 0; i < n; ++i) { if (fabsf(PWN_A(i,i)) > tol) d[i] = d[i] / PWN_A(i,i); else d[i] = 0.f; }
-  for (int i = n - 2; i >= 0; --i) {
-    float s = PWN_A(i+1,i) * d[i+1];
-    for (int j = i + 2; j < n; ++j) s = s + PWN_A(j,i) * d[j];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { if (fabsf(PWN_A(i, i)) > tol) d[i] = d[i] / PWN_A(i, i); else d[i] = 0.f; }
+#pragma unroll
+  for (int i = 4; i >= 0; --i) {                         // L^-T
+    float s = PWN_A(i + 1, i) * d[i + 1];
+#pragma unroll
+    for (int j = i + 2; j < 6; ++j) s = s + PWN_A(j, i) * d[j];
     d[i] = d[i] - s;
   }
-  for (int k = n - 1; k >= 0; --k) if (tr_get(k) != k) { const float t = d[k]; d[k] = d[tr_get(k)]; d[tr_get(k)] = t; }
+  ldlt_perm_dispatch<4, 5>(d, tr[4]);
+  ldlt_perm_dispatch<3, 4>(d, tr[3]);
+  ldlt_perm_dispatch<2, 3>(d, tr[2]);
+  ldlt_perm_dispatch<1, 2>(d, tr[1]);
+  ldlt_perm_dispatch<0, 1>(d, tr[0]);
+#pragma unroll
   for (int i = 0; i < 6; ++i) x[i] = d[i];
+}
 #undef PWN_A
-#undef tr_get
-}
-PWN_HD void ldlt_solve6(const float Hin[36], const float bin[6], float x[6]) {
-  float ws[54];
-  ldlt_solve6_ws(Hin, bin, x, ws);
-}
 
 }  // namespace pwnhip

@@ -309,6 +309,9 @@ void pwn_hip_iso_mul(const float A[16], const float B[16], float out[16]);
 /* bm_se3.h:37-52 */
 void pwn_hip_v2t(const float v[6], float T[16]);
 void pwn_hip_t2v(const float T[16], float v[6]);
+/* Matrix6f::ldlt().solve(b) as aligner.cpp:110 calls it (column-major H, lower triangle read): the host compilation of the
+ * function k_solve_update runs on the device */
+void pwn_hip_ldlt_solve6(const float H[36], const float b[6], float x[6]);
 /* per-kernel device time (ms) of the stages of the last batch/single call, for bench.py:
  * names: "unproject","integral_rows","integral_cols","stats","project","corr_linearize","solve" */
 int pwn_hip_last_stage_ms(pwn_hip_ctx* ctx, const char* stage, float* ms, int* launches);

@@ -71,6 +71,41 @@ def test_helpers_run_on_the_host_and_match_the_oracle(oracle):
         p = api.PinholePointProjector(); p.setCameraMatrix([[525, 0, 319.5], [0, 525, 239.5], [0, 0, 1]]); p.setTransform(T)
         for a, b in zip(p.matrices(), oracle.projector_matrices((525, 525, 319.5, 239.5), T)):
             assert np.array_equal(a, b)
+    for n in range(300):                                                    # rotations beyond 120 degrees: the trace <= 0 branches of t2v
+        q = rng.normal(size=3); q *= rng.uniform(0.87, 0.9999) / np.linalg.norm(q)
+        if n % 3 == 0: q[n // 3 % 3] *= 8; q *= rng.uniform(0.87, 0.9999) / np.linalg.norm(q)     # one dominant axis each
+        T = api.v2t(np.concatenate([rng.normal(size=3), q]).astype(np.float32))
+        assert np.array_equal(T, oracle.v2t(api.t2v(T) * 0 + np.concatenate([T[:3, 3], q]).astype(np.float32)))
+        assert np.array_equal(api.t2v(T).view(np.uint32), oracle.t2v(T).view(np.uint32))
+
+
+def test_ldlt_host_compilation_matches_the_oracle(oracle):
+    """The 6x6 pivoted LDLT the device runs in registers (every index a compile-time constant, pivot swaps dispatched on the pivot
+    row): its host compilation against the oracle's loop form, bit for bit -- well conditioned systems, the aligner's
+    H + 1001 I shape, every pivot order, rank-deficient and all-zero matrices."""
+    from g2o_frontend_amd import api
+    rng = np.random.default_rng(7)
+    cases = []
+    for _ in range(300):
+        J = rng.normal(size=(12, 6)); H = (J.T @ J) * 10.0 ** rng.uniform(-3, 6)
+        cases.append((H, rng.normal(size=6)))
+    for _ in range(100):                                                    # the Gauss-Newton shape: large, badly scaled blocks + damping
+        J = rng.normal(size=(40, 6)) * np.array([30, 30, 30, 900, 900, 900]); H = J.T @ J + 1001.0 * np.eye(6)
+        cases.append((H, rng.normal(size=6) * 1e4))
+    import itertools
+    for perm in itertools.permutations(range(6)):                           # every order of the diagonal: every pivot sequence
+        d = np.array([1.0, 2.0, 4.0, 8.0, 16.0, 32.0])[list(perm)]
+        L = np.tril(rng.normal(size=(6, 6)) * 0.1, -1) + np.eye(6)
+        cases.append((L @ np.diag(d) @ L.T, rng.normal(size=6)))
+    for r in range(6):                                                      # rank r: the factorisation stops early
+        J = rng.normal(size=(r, 6)); cases.append((J.T @ J, rng.normal(size=6)))
+    cases.append((np.zeros((6, 6)), np.ones(6)))
+    cases.append((np.diag([0, 0, 5.0, 0, 0, 0]), np.arange(6.0)))
+    cases.append((-np.eye(6) * 3 + 0.1, np.arange(6.0)))                    # negative definite: LDLT still factors it
+    for H, b in cases:
+        H = H.astype(np.float32); b = b.astype(np.float32)
+        x, xo = api.ldlt_solve6(H, b), oracle.ldlt_solve6(H, b)
+        assert np.array_equal(x.view(np.uint32), xo.view(np.uint32)), (H, b, x, xo)
 
 
 def test_host_mirror_parameter_plumbing():
