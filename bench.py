@@ -308,6 +308,13 @@ def main():
             lat.append((time.perf_counter() - a) * 1e3)
         extra["single_pair_latency_ms"] = float(np.median(lat))
 
+    hbm_read = hbm_copy = None
+    if rank == 0:
+        # the bandwidth this box actually delivers, next to the 8 TB/s spec figure (float4 streaming read / copy of 2 GiB)
+        try:
+            hbm_read, hbm_copy = ctx.measure_hbm(1 << 31)
+        except Exception:
+            hbm_read = hbm_copy = None
     if rank == 0:
         value = world * P * args.steps / dt
         launches = max(stage_n["corr_linearize"], 1)
@@ -340,6 +347,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_launch_algorithmic": k_bytes, "avg_launch_ms": k_ms, "launches": stage_n["corr_linearize"],
                          "dominant_by_time": dom,
+                         "measured_hbm_GBps": {"read": hbm_read, "copy": hbm_copy},    # this box, float4 streaming kernels over 2 GiB; not frac's denominator
+                         "traffic_GBps": (traffic / (k_ms * 1e-3) / 1e9) if (traffic and k_ms > 0) else None,
                          "measured_in": "serial profiled pass of the same K steps (one stream, hipEvent pair per kernel stage); "
                                         "the timed region runs two streams without instrumentation",
                          "serial_pass_alignments_per_s": (world * P * args.steps / dt_serial) if dt_serial else None},

@@ -100,6 +100,12 @@ class Context:
     def set_profiling(self, on: bool):
         self.check(self._L.pwn_hip_set_profiling(self.h, 1 if on else 0))
 
+    def measure_hbm(self, nbytes: int = 1 << 30):
+        """(read GB/s, copy GB/s) of float4 streaming kernels over `nbytes` on this GPU (the copy counts read + written bytes)"""
+        r, c = C.c_float(0), C.c_float(0)
+        self.check(self._L.pwn_hip_measure_hbm(self.h, nbytes, C.byref(r), C.byref(c)))
+        return float(r.value), float(c.value)
+
     def stage_ms(self, stage: str):
         ms, n = C.c_float(0), C.c_int(0)
         self.check(self._L.pwn_hip_last_stage_ms(self.h, stage.encode(), C.byref(ms), C.byref(n)))

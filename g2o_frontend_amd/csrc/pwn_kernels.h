@@ -1192,6 +1192,11 @@ __device__ __forceinline__ void block_reduce_store(float* acc, double* out_gener
 #ifndef PWN_CL_WAVES
 #define PWN_CL_WAVES 1
 #endif
+// PWN_CL_X (timing experiments only, results are wrong): 1 = no information-matrix loads, 2 = no reference-normal gather,
+// 4 = the reference index comes from the converter's index image in every iteration (no z-buffer word, coherent reference gathers)
+#ifndef PWN_CL_X
+#define PWN_CL_X 0
+#endif
 struct Candidate {
   float4 rP, rN, cP, cN;
 #if PWN_OMEGA_PREFETCH
@@ -1224,7 +1229,12 @@ __device__ __forceinline__ void candidate_load(const PairPtrs& q, int ri, int ci
   c.valid = !(ri < 0 || ci < 0 || ri >= nref || ci >= ncur);
   c.ci = ci;
   if (c.valid) {
-    c.rP = load4(q.refP + (unsigned)ri); c.rN = load4(q.refN + (unsigned)ri); c.cP = load4(q.curP + (unsigned)ci); c.cN = load4(q.curN + (unsigned)ci);
+    c.rP = load4(q.refP + (unsigned)ri); c.cP = load4(q.curP + (unsigned)ci); c.cN = load4(q.curN + (unsigned)ci);
+#if PWN_CL_X & 2
+    c.rN = c.cN;
+#else
+    c.rN = load4(q.refN + (unsigned)ri);
+#endif
 #if PWN_OMEGA_PREFETCH
 #pragma unroll
     for (int k = 0; k < 9; ++k) c.oP[k] = q.curOm[(size_t)k * q.cap + (unsigned)ci];
@@ -1261,8 +1271,14 @@ __device__ __forceinline__ void candidate_consume(const PairDesc& pd, const Pair
   {
     const size_t cap = (size_t)q.cap;
     const unsigned ci = (unsigned)c.ci;
+#if PWN_CL_X & 1
+    (void)cap; (void)ci;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) oP[k] = oN[k] * 10.f;
+#else
 #pragma unroll
     for (int k = 0; k < 9; ++k) oP[k] = q.curOm[k * cap + ci];
+#endif
   }
 #endif
   if (linearize_term(rp, rn, make_float3(c.cP.x, c.cP.y, c.cP.z), make_float3(c.cN.x, c.cN.y, c.cN.z), oP, oN, ap.maxChi2, ap.robust, acc))
@@ -1305,7 +1321,11 @@ __global__ void PWN_CL_EU_ATTR __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_co
     const int pix = pix0 + j * kAlignBlock;
     ri = -1; ci = -1;
     if (j < PPT && pix < N) {
+#if PWN_CL_X & 4
+      ri = q.refidx0 ? q.refidx0[(unsigned)pix] : zkey_index(q.zref[(unsigned)pix], tag);
+#else
       ri = ownRefIndex ? q.refidx0[(unsigned)pix] : zkey_index(q.zref[(unsigned)pix], tag);      // wave-uniform choice
+#endif
       ci = q.curidx[(unsigned)pix];
     }
   };

@@ -315,6 +315,10 @@ void pwn_hip_ldlt_solve6(const float H[36], const float b[6], float x[6]);
 /* per-kernel device time (ms) of the stages of the last batch/single call, for bench.py:
  * names: "unproject","integral_rows","integral_cols","stats","project","corr_linearize","solve" */
 int pwn_hip_last_stage_ms(pwn_hip_ctx* ctx, const char* stage, float* ms, int* launches);
+/* what this GPU's HBM delivers, for the roofline report (SURVEY 8(d) asks for the measured figure next to the 8 TB/s spec):
+ * float4 streaming read and device-to-device copy of `bytes` (use >= 1 GiB: the Infinity Cache holds 256 MiB), best of 5,
+ * GB/s; the copy counts bytes read + written.  Allocates and frees 2 x bytes. */
+int pwn_hip_measure_hbm(pwn_hip_ctx* ctx, size_t bytes, float* read_gbps, float* copy_gbps);
 /* enable/disable hipEvent timing around every kernel launch (adds host overhead; default off) */
 int pwn_hip_set_profiling(pwn_hip_ctx* ctx, int enabled);
 

@@ -137,3 +137,11 @@ def test_zbuffer_epoch_tags_wrap_without_changing_results():
             assert r["iterations"] == 10 and r["inliers"] > 1000
         assert _digest(aligner.alignBatch(refs, curs)) == base, i
     ctx.close()
+
+
+def test_measured_hbm_bandwidth_is_sane(world):
+    """The bandwidth probe bench.py reports next to the spec peak: a streaming read and a copy of 1 GiB land between 2 and 8 TB/s on an
+    MI355X (anything else means the probe, not the memory, is broken)."""
+    rd, cp = world["ctx"].measure_hbm(1 << 30)
+    assert 2000.0 < rd < 8000.0 and 2000.0 < cp < 8000.0, (rd, cp)
+
