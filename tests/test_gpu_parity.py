@@ -510,3 +510,55 @@ def test_error_paths(ctx):
     small_cloud = api.Cloud(ctx, 10)
     with pytest.raises(PwnHipError):
         converter.compute(small_cloud, np.full((120, 160), 1.0, np.float32))
+
+
+@pytest.mark.parametrize("rows,cols", [(113, 150), (97, 131), (33, 70), (17, 65), (16, 64), (121, 63), (5, 300)])
+def test_odd_image_sizes(oracle, rows, cols):
+    """Image sizes that are no multiple of anything the kernels tile by (64-column strips, 16-row bands, 256-pixel blocks, 2048-pixel
+    tiles of the fused kernel): converter arrays and images bit for bit -- alone (three-kernel integral image) and in a 26-frame batch
+    (single-pass strip kernel) --, first-iteration counters exactly, chi2 from the same iterate to 1e-5, batch == single bitwise."""
+    from g2o_frontend_amd import api, synth
+    scale = 4
+    K = synth.scaled_K(synth.K_VGA, scale)
+    K = (K[0], K[1], (cols - 1) / 2.0, (rows - 1) / 2.0)
+    conv, alig = dict(oracle.QVGA4_CONF_CONVERTER), dict(oracle.QVGA4_CONF_ALIGNER)
+    ctx = api.Context(0, rows, cols, 32)
+    try:
+        proj, converter, aligner = gpu_objects(ctx, "small")
+        for p in (proj, aligner.projector()):
+            p.setCameraMatrix([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]]); p.setImageSize(rows, cols)
+        aligner.correspondenceFinder().setImageSize(rows, cols)
+        ref_mm, cur_mm, _ = synth.make_pair(11, rows, cols, K)
+        ref, cur = oracle.convert_16u_to_32f(ref_mm), oracle.convert_16u_to_32f(cur_mm)
+        cp = oracle.converter_params(K=K, **conv)
+        oref, oidx, oitv = oracle.convert(cp, ref); ocur, _, _ = oracle.convert(cp, cur)
+        gref, gcur = api.Cloud(ctx, rows * cols), api.Cloud(ctx, rows * cols)
+        converter.compute(gref, ref)
+        assert np.array_equal(converter.indexImage(), oidx) and np.array_equal(converter.intervalImage(), oitv)
+        converter.compute(gcur, cur)
+        def same(o, g):
+            assert len(o["points"]) == len(g["points"])
+            for k in ("points", "normals", "curvature", "omega_p", "omega_n"):
+                a, b = o[k].reshape(len(o[k]), -1), g[k].reshape(len(g[k]), -1)
+                assert (((a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0)))).all(), k
+        same(oref.arrays(), gref.arrays()); same(ocur.arrays(), gcur.arrays())
+        # the batch path (>= 24 frames: single-pass strip kernel)
+        many = [api.Cloud(ctx, rows * cols) for _ in range(26)]
+        converter.computeBatch(many, [ref_mm, cur_mm] * 13, raw_scale=0.001)
+        for k in (0, 1, 24, 25):
+            same((oref if k % 2 == 0 else ocur).arrays(), many[k].arrays())
+        if len(oref) == 0 or len(ocur) == 0:
+            return
+        ap = oracle.aligner_params(rows, cols, K=K, accumulate_fp64=1, **alig)
+        o = oracle.align(ap, oref, ocur)
+        aligner.setReferenceCloud(gref); aligner.setCurrentCloud(gcur)
+        g = aligner.align()
+        it0 = o["iterations"][0]
+        assert (int(g["K"][0]), int(g["C"][0]), int(g["iter_inliers"][0])) == (it0["K"], it0["C"], it0["inliers"])
+        if it0["chi2_fp64"] > 0:
+            assert abs(float(g["chi2"][0]) - it0["chi2_fp64"]) <= 1e-5 * it0["chi2_fp64"]
+        res = aligner.alignBatch([many[0], many[2], gref], [many[1], many[3], gcur])
+        for r in res:
+            assert np.array_equal(r["T"].view(np.uint32), g["T"].view(np.uint32)) and np.array_equal(r["chi2"].view(np.uint32), g["chi2"].view(np.uint32))
+    finally:
+        ctx.close()
