@@ -44,6 +44,13 @@ def build_tools(force: bool = False) -> str:
     if force or (not os.path.exists(out2)) or any(os.path.getmtime(d) > os.path.getmtime(out2) for d in deps2):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", root, src2, "-o", out2, "-L", _HERE, "-lpwn_hip",
                                "-Wl,-rpath,$ORIGIN/../g2o_frontend_amd"])
+    # the tracker + closer flow (PwnTracker::processFrame, CloudCache, batched matchClouds, statistics, priors) over the same mirror
+    src3 = os.path.join(root, "tools", "pwn_hip_tracker_app.cpp")
+    out3 = os.path.join(root, "tools", "pwn_hip_tracker_app")
+    deps3 = [src3] + deps[1:]
+    if force or (not os.path.exists(out3)) or any(os.path.getmtime(d) > os.path.getmtime(out3) for d in deps3):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", root, src3, "-o", out3, "-L", _HERE, "-lpwn_hip",
+                               "-Wl,-rpath,$ORIGIN/../g2o_frontend_amd"])
     return out
 
 

@@ -12,8 +12,11 @@
 
 #include <cmath>
 #include <cstring>
+#include <list>
+#include <map>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/pwn_hip.h"
@@ -65,6 +68,18 @@ struct IntImage { int rows = 0, cols = 0; std::vector<int> data; void create(int
 
 inline Isometry3f v2t(const float v[6]) { Isometry3f T; pwn_hip_v2t(v, T.data()); return T; }      // bm_se3.h:37-43
 inline void t2v(const Isometry3f& T, float v[6]) { pwn_hip_t2v(T.data(), v); }                     // bm_se3.h:45-52
+// Isometry3f * Isometry3f with the evaluation order of the CPU path (the library's host helper; what the device-side pose chaining uses)
+inline Isometry3f iso_mul(const Isometry3f& a, const Isometry3f& b) { Isometry3f r; pwn_hip_iso_mul(a.data(), b.data(), r.data()); return r; }
+struct Matrix6f {                          // bm_defs.h:11, column-major
+  float m[36];
+  Matrix6f() { std::memset(m, 0, sizeof(m)); }
+  static Matrix6f Identity() { Matrix6f r; for (int i = 0; i < 6; ++i) r.m[7 * i] = 1.f; return r; }
+  float& operator()(int r, int c) { return m[r + 6 * c]; }
+  float operator()(int r, int c) const { return m[r + 6 * c]; }
+  const float* data() const { return m; }
+  float* data() { return m; }
+};
+struct Vector6f { float v[6] = { 0, 0, 0, 0, 0, 0 }; float& operator[](int i) { return v[i]; } float operator[](int i) const { return v[i]; } };
 
 // One per (GPU, host thread); every object below borrows it (non-owning raw pointer, like the reference's
 // collaborator pointers: aligner.h:381-386).
@@ -297,9 +312,11 @@ class Linearizer {
   float inlierMaxChi2() const { return _inlierMaxChi2; }  void setInlierMaxChi2(float v) { _inlierMaxChi2 = v; }
   bool robustKernel() const { return _robustKernel; }      void setRobustKernel(bool v) { _robustKernel = v; }
   float error() const { return _error; }  int inliers() const { return _inliers; }
+  const Matrix6f& H() const { return _H; }  const Vector6f& b() const { return _b; }       // filled by Aligner::align when statistics are computed
  private:
   friend class Aligner;
   Aligner* _aligner = nullptr; float _inlierMaxChi2 = 9e3f; bool _robustKernel = true; float _error = 0.f; int _inliers = 0;
+  Matrix6f _H; Vector6f _b;
 };
 
 // aligner.{h,cpp}
@@ -310,7 +327,26 @@ class Aligner {
   void setProjector(PinholePointProjector* p) { _projector = p; }            PinholePointProjector* projector() { return _projector; }
   void setLinearizer(Linearizer* l) { _linearizer = l; if (l) l->setAligner(this); }  Linearizer* linearizer() { return _linearizer; }
   void setCorrespondenceFinder(CorrespondenceFinder* f) { _correspondenceFinder = f; } CorrespondenceFinder* correspondenceFinder() { return _correspondenceFinder; }
-  void setReferenceCloud(Cloud* c) { _referenceCloud = c; }  void setCurrentCloud(Cloud* c) { _currentCloud = c; }     // aligner.h:60-80
+  void setReferenceCloud(Cloud* c) { _referenceCloud = c; clearPriors(); }                                           // aligner.h:60-63: setting a cloud clears the priors
+  void setCurrentCloud(Cloud* c) { _currentCloud = c; clearPriors(); }                                               // aligner.h:77-80
+  // aligner.cpp:34-47, se3_prior.h
+  void addRelativePrior(const Isometry3f& mean, const Matrix6f& informationMatrix) { _priors.push_back(makePrior(0, mean, Isometry3f::Identity(), informationMatrix)); }
+  void addAbsolutePrior(const Isometry3f& referenceTransform, const Isometry3f& mean, const Matrix6f& informationMatrix) {
+    _priors.push_back(makePrior(1, mean, referenceTransform, informationMatrix));
+  }
+  void clearPriors() { _priors.clear(); }
+  size_t numPriors() const { return _priors.size(); }
+  // Aligner::_computeStatistics (aligner.cpp:127,152-199) costs one more linearizer pass and 6x6 host math; the reference always runs it,
+  // here it is run when asked for (the tracker and the closer never read its outputs)
+  bool computeStatistics() const { return _computeStatistics; }  void setComputeStatistics(bool v) { _computeStatistics = v; }
+  const Matrix6f& omega() const { return _omega; }                                                                    // aligner.h:314
+  const Vector6f& mean() const { return _mean; }
+  float translationalEigenRatio() const { return _translationalEigenRatio; }  float rotationalEigenRatio() const { return _rotationalEigenRatio; }
+  float translationalMinEigenRatio() const { return _translationalMinEigenRatio; }  void setTranslationalMinEigenRatio(float v) { _translationalMinEigenRatio = v; }
+  float rotationalMinEigenRatio() const { return _rotationalMinEigenRatio; }        void setRotationalMinEigenRatio(float v) { _rotationalMinEigenRatio = v; }
+  bool solutionValid() const {                                                                                         // aligner.cpp:128-129
+    return !(_rotationalEigenRatio > _rotationalMinEigenRatio || _translationalEigenRatio > _translationalMinEigenRatio);
+  }
   int outerIterations() const { return _outerIterations; }  void setOuterIterations(int n) { _outerIterations = n; }
   int innerIterations() const { return _innerIterations; }  void setInnerIterations(int n) { _innerIterations = n; }
   const Isometry3f& T() const { return _T; }
@@ -341,7 +377,18 @@ class Aligner {
   virtual void align(bool fetchImages = false) {
     if (!_referenceCloud || !_currentCloud) throw Error(PWN_HIP_ERR_INVALID_ARGUMENT, "Aligner: missing cloud");
     const pwn_hip_aligner_params p = params();
-    _ctx->check(pwn_hip_align(_ctx->handle(), &p, _referenceCloud->handle(), _currentCloud->handle(), &_result));
+    if (!_priors.empty()) {                                                       // aligner.cpp:96-108: host-driven loop with the prior terms
+      _ctx->check(pwn_hip_align_with_priors(_ctx->handle(), &p, _referenceCloud->handle(), _currentCloud->handle(), (int)_priors.size(), _priors.data(), &_result));
+    } else if (_computeStatistics) {
+      pwn_hip_cloud* r = _referenceCloud->handle(); pwn_hip_cloud* c = _currentCloud->handle();
+      pwn_hip_align_statistics q;
+      _ctx->check(pwn_hip_align_batch_ex(_ctx->handle(), &p, 1, &r, &c, nullptr, &_result, 0.f, nullptr, &q));
+      std::memcpy(_omega.m, q.omega, sizeof(q.omega)); std::memcpy(_mean.v, q.mean, sizeof(q.mean));
+      _translationalEigenRatio = q.translational_eigen_ratio; _rotationalEigenRatio = q.rotational_eigen_ratio;
+      std::memcpy(_linearizer->_H.m, q.H, sizeof(q.H)); std::memcpy(_linearizer->_b.v, q.b, sizeof(q.b));
+    } else {
+      _ctx->check(pwn_hip_align(_ctx->handle(), &p, _referenceCloud->handle(), _currentCloud->handle(), &_result));
+    }
     _T = Isometry3f(_result.T); _error = _result.error; _inliers = _result.inliers; _totalTime = _result.total_time_ms;
     _linearizer->_error = _error; _linearizer->_inliers = _inliers;
     _correspondenceFinder->_numCorrespondences = _result.iterations > 0 ? _result.iter_correspondences[_result.iterations - 1] : 0;
@@ -353,10 +400,44 @@ class Aligner {
                                        f._currentIndexImage.data.data(), f._currentDepthImage.data.data()));
     }
   }
+  // n independent alignments with this aligner's parameters (the candidate loop of PwnCloser::processPartition, pwn_closer.cpp:92-111);
+  // initialGuesses: n isometries or empty (= this aligner's initial guess for all); scores: optional depth-agreement scores of matchClouds
+  std::vector<pwn_hip_align_result> alignBatch(const std::vector<Cloud*>& references, const std::vector<Cloud*>& currents,
+                                               const std::vector<Isometry3f>& initialGuesses = std::vector<Isometry3f>(),
+                                               std::vector<pwn_hip_match_result>* scores = nullptr, float frameInlierDepthThreshold = 50.f) {
+    const size_t n = references.size();
+    if (currents.size() != n || (!initialGuesses.empty() && initialGuesses.size() != n)) throw Error(PWN_HIP_ERR_INVALID_ARGUMENT, "Aligner::alignBatch: list sizes differ");
+    std::vector<pwn_hip_align_result> results(n);
+    if (n == 0) return results;
+    const pwn_hip_aligner_params p = params();
+    std::vector<pwn_hip_cloud*> r(n), c(n);
+    for (size_t i = 0; i < n; ++i) {
+      if (!references[i] || !currents[i]) throw Error(PWN_HIP_ERR_INVALID_ARGUMENT, "Aligner::alignBatch: null cloud");
+      r[i] = references[i]->handle(); c[i] = currents[i]->handle();
+    }
+    std::vector<float> g;
+    for (const Isometry3f& T : initialGuesses) { Isometry3f t = T; t.forceLastRow(); g.insert(g.end(), t.m, t.m + 16); }
+    if (scores) scores->resize(n);
+    _ctx->check(pwn_hip_align_batch_ex(_ctx->handle(), &p, (int)n, r.data(), c.data(), g.empty() ? nullptr : g.data(), results.data(),
+                                       frameInlierDepthThreshold, scores ? scores->data() : nullptr, nullptr));
+    return results;
+  }
+  Context* context() const { return _ctx; }
  protected:
+  static pwn_hip_prior makePrior(int kind, const Isometry3f& mean, const Isometry3f& referenceTransform, const Matrix6f& info) {
+    pwn_hip_prior q; q.kind = kind;
+    std::memcpy(q.mean, mean.data(), sizeof(q.mean)); std::memcpy(q.reference_transform, referenceTransform.data(), sizeof(q.reference_transform));
+    std::memcpy(q.information, info.data(), sizeof(q.information));
+    return q;
+  }
   Context* _ctx;
   PinholePointProjector* _projector = nullptr; Linearizer* _linearizer = nullptr; CorrespondenceFinder* _correspondenceFinder = nullptr;
   Cloud* _referenceCloud = nullptr; Cloud* _currentCloud = nullptr;
+  std::vector<pwn_hip_prior> _priors;
+  bool _computeStatistics = false;
+  Matrix6f _omega; Vector6f _mean;
+  float _translationalEigenRatio = 3.402823466e+38f, _rotationalEigenRatio = 3.402823466e+38f;
+  float _translationalMinEigenRatio = 50.f, _rotationalMinEigenRatio = 50.f;                                          // aligner.cpp:29-30
   int _outerIterations = 10, _innerIterations = 1;                                                                    // aligner.cpp:19-20
   Isometry3f _T, _initialGuess, _referenceSensorOffset, _currentSensorOffset;
   float _error = 0.f; int _inliers = 0; double _totalTime = 0.0;
@@ -373,10 +454,13 @@ struct PwnMatcherBase {
     float image_reprojectionDistance;
   };
   PwnMatcherBase(Context* ctx, Aligner* aligner, DepthImageConverter* converter) : _ctx(ctx), _aligner(aligner), _converter(converter) {}
+  virtual ~PwnMatcherBase() {}
   int scale() const { return _scale; }  void setScale(int s) { _scale = s; }
+  float frameInlierDepthThreshold() const { return _frameInlierDepthThreshold; }  void setFrameInlierDepthThreshold(float v) { _frameInlierDepthThreshold = v; }
   Aligner* aligner() { return _aligner; }  DepthImageConverter* converter() { return _converter; }
 
-  // .cpp:57-86: returns a new Cloud owned by the caller; r, c, cameraMatrix receive the scaled values
+  // .cpp:57-86: returns a new Cloud owned by the caller; r, c, cameraMatrix receive the scaled values.  DepthImage_scale (:72) and
+  // converter->compute (:79) run as one device-side call (no scaled image on the host); same side effects on the converter's projector.
   Cloud* makeCloud(int& r, int& c, Matrix3f& cameraMatrix, const Isometry3f& sensorOffset, const DepthImage& depthImage) {
     PinholePointProjector* projector = _converter->projector();
     const float invScale = 1.0f / _scale;
@@ -385,43 +469,172 @@ struct PwnMatcherBase {
     scaled(2,2) = 1.0f;
     projector->setCameraMatrix(scaled);
     projector->setImageSize(depthImage.rows / _scale, depthImage.cols / _scale);
-    DepthImage scaledImage;
-    DepthImage_scale(*_ctx, scaledImage, depthImage, _scale);
+    projector->setTransform(Isometry3f::Identity());
     cameraMatrix = projector->cameraMatrix(); r = projector->imageRows(); c = projector->imageCols();
-    Cloud* cloud = new Cloud(*_ctx, scaledImage.rows * scaledImage.cols > 0 ? scaledImage.rows * scaledImage.cols : 1);
-    _converter->compute(*cloud, scaledImage, sensorOffset);
+    Cloud* cloud = new Cloud(*_ctx, r * c > 0 ? r * c : 1);
+    const pwn_hip_converter_params p = _converter->params(sensorOffset);
+    const int rc = pwn_hip_convert_scaled(_ctx->handle(), &p, depthImage.data.data(), depthImage.rows, depthImage.cols, _scale, 0.01f, cloud->handle());
+    if (rc) { delete cloud; _ctx->check(rc); }
     ++numCalls;
     return cloud;
   }
   // .cpp:88-183
   void matchClouds(MatcherResult& result, Cloud* fromCloud, Cloud* toCloud, const Isometry3f& fromOffset, const Isometry3f& toOffset,
                    const Matrix3f& toCameraMatrix, int toRows, int toCols, const Isometry3f& initialGuess = Isometry3f::Identity()) {
+    configure(fromOffset, toOffset, toCameraMatrix, toRows, toCols, initialGuess);
+    _aligner->setReferenceCloud(fromCloud);
+    _aligner->setCurrentCloud(toCloud);
+    _aligner->align();
+    pwn_hip_match_result m;
+    _ctx->check(pwn_hip_match_score(_ctx->handle(), _frameInlierDepthThreshold, &m));
+    fill(result, _aligner->result(), m);
+  }
+  // the candidate loop of PwnCloser::processPartition (pwn_closer.cpp:92-111) as one batched call: results[i] = matchClouds(from[i], to[i])
+  void matchCloudsBatch(std::vector<MatcherResult>& results, const std::vector<Cloud*>& fromClouds, const std::vector<Cloud*>& toClouds,
+                        const Isometry3f& fromOffset, const Isometry3f& toOffset, const Matrix3f& toCameraMatrix, int toRows, int toCols,
+                        const std::vector<Isometry3f>& initialGuesses = std::vector<Isometry3f>()) {
+    configure(fromOffset, toOffset, toCameraMatrix, toRows, toCols, Isometry3f::Identity());
+    std::vector<Isometry3f> g(fromClouds.size());
+    for (size_t i = 0; i < g.size(); ++i) { if (!initialGuesses.empty()) g[i] = initialGuesses[i]; g[i](2,3) = 0.f; g[i].forceLastRow(); }
+    std::vector<pwn_hip_match_result> scores;
+    const std::vector<pwn_hip_align_result> r = _aligner->alignBatch(fromClouds, toClouds, g, &scores, _frameInlierDepthThreshold);
+    results.resize(r.size());
+    for (size_t i = 0; i < r.size(); ++i) fill(results[i], r[i], scores[i]);
+  }
+  int numCalls = 0;
+ protected:
+  void configure(const Isometry3f& fromOffset, const Isometry3f& toOffset, const Matrix3f& toCameraMatrix, int toRows, int toCols, const Isometry3f& initialGuess) {
     PinholePointProjector* projector = _aligner->projector();
     _aligner->setReferenceSensorOffset(fromOffset);
     _aligner->setCurrentSensorOffset(toOffset);
     Isometry3f ig = initialGuess;
-    ig(2,3) = 0.f;
+    ig(2,3) = 0.f;                                                               // :114
     _aligner->setInitialGuess(ig);
     projector->setCameraMatrix(toCameraMatrix);
     projector->setImageSize(toRows, toCols);
-    projector->scale((float)(1. / _scale));
+    projector->scale((float)(1. / _scale));                                      // :117-119
     _aligner->correspondenceFinder()->setImageSize(projector->imageRows(), projector->imageCols());
-    _aligner->setReferenceCloud(fromCloud);
-    _aligner->setCurrentCloud(toCloud);
-    _aligner->align();
-    for (int i = 0; i < 16; ++i) result.transform[i] = _aligner->T().m[i];
-    for (int i = 0; i < 36; ++i) result.informationMatrix[i] = (i % 7 == 0) ? 100.0 : 0.0;
-    result.cloud_inliers = _aligner->inliers();
-    pwn_hip_match_result m;
-    _ctx->check(pwn_hip_match_score(_ctx->handle(), _frameInlierDepthThreshold, &m));
+  }
+  static void fill(MatcherResult& result, const pwn_hip_align_result& a, const pwn_hip_match_result& m) {
+    for (int i = 0; i < 16; ++i) result.transform[i] = a.T[i];
+    for (int i = 0; i < 36; ++i) result.informationMatrix[i] = (i % 7 == 0) ? 100.0 : 0.0;     // :147-148 HACK kept
+    result.cloud_inliers = a.inliers;
     result.image_reprojectionDistance = m.image_reprojection_distance;
     result.image_nonZeros = m.image_non_zeros; result.image_outliers = m.image_outliers; result.image_inliers = m.image_inliers;
   }
-  int numCalls = 0;
- protected:
   Context* _ctx; Aligner* _aligner; DepthImageConverter* _converter;
   float _frameInlierDepthThreshold = 50.f;   // .cpp:13
   int _scale = 2;                            // .cpp:12
+};
+
+// acceptance rule of PwnCloser::matchFrames (pwn_tracker/pwn_closer.cpp:56-58,138-141)
+struct PwnCloserAcceptance {
+  int frameMinNonZeroThreshold = 3000, frameMaxOutliersThreshold = 100, frameMinInliersThreshold = 1000;
+  bool accept(const PwnMatcherBase::MatcherResult& r) const {
+    return !(r.image_nonZeros < frameMinNonZeroThreshold || r.image_outliers > frameMaxOutliersThreshold || r.image_inliers < frameMinInliersThreshold);
+  }
+};
+
+// pwn_tracker/pwn_tracker_cache.cpp:24-51 (+ boss_map_building cache.hpp): device-resident LRU of clouds keyed by frame; a miss re-runs the
+// converter on the frame's stored depth image (PwnCache::loadFrame), so closure batches do not re-convert frames still resident in HBM.
+class CloudCache {
+ public:
+  CloudCache(PwnMatcherBase* matcher, size_t capacity = 64) : _matcher(matcher), _capacity(capacity) {}
+  ~CloudCache() { for (auto& e : _lru) delete e.second; }
+  // the cache takes ownership of `cloud` (may be nullptr: the cloud is then made on the first get)
+  void addFrame(int key, const DepthImage& depthImage, const Matrix3f& cameraMatrix, const Isometry3f& sensorOffset, Cloud* cloud = nullptr) {
+    _frames[key] = Frame{ depthImage, cameraMatrix, sensorOffset };
+    if (cloud) insert(key, cloud);
+  }
+  Cloud* get(int key) {
+    for (auto it = _lru.begin(); it != _lru.end(); ++it)
+      if (it->first == key) { ++hits; _lru.splice(_lru.end(), _lru, it); return _lru.back().second; }
+    ++misses;
+    auto f = _frames.find(key);
+    if (f == _frames.end()) throw Error(PWN_HIP_ERR_INVALID_ARGUMENT, "CloudCache: unknown frame");
+    int r, c; Matrix3f K = f->second.cameraMatrix;
+    Cloud* cloud = _matcher->makeCloud(r, c, K, f->second.sensorOffset, f->second.depth);      // pwn_tracker_cache.cpp:38-44
+    insert(key, cloud);
+    return cloud;
+  }
+  size_t resident() const { return _lru.size(); }
+  int hits = 0, misses = 0;
+ private:
+  struct Frame { DepthImage depth; Matrix3f cameraMatrix; Isometry3f sensorOffset; };
+  void insert(int key, Cloud* cloud) {
+    for (auto it = _lru.begin(); it != _lru.end(); ++it) if (it->first == key) { delete it->second; _lru.erase(it); break; }
+    _lru.emplace_back(key, cloud);
+    while (_lru.size() > _capacity) { delete _lru.front().second; _lru.pop_front(); }          // least recently used
+  }
+  PwnMatcherBase* _matcher; size_t _capacity;
+  std::list<std::pair<int, Cloud*> > _lru;       // front = least recently used
+  std::map<int, Frame> _frames;
+};
+
+// pwn_tracker/pwn_tracker.{h,cpp}: sequential odometry with key-cloud switching (processFrame, .cpp:106-215).  The BOSS map bookkeeping of
+// the reference (frames / relations handed to the map manager, :217-281) is reported through FrameResult instead.
+class PwnTracker : public PwnMatcherBase {
+ public:
+  struct FrameResult { bool newFrame = false, aligned = false; int inliers = 0; float error = 0.f, inliersFraction = 0.f; Isometry3f T, globalT; };
+  using PwnMatcherBase::PwnMatcherBase;
+  ~PwnTracker() { delete _previousCloud; if (_currentCloud != _previousCloud) delete _currentCloud; }
+  const Isometry3f& globalT() const { return _globalT; }
+  int numKeyframes() const { return _numKeyframes; }
+  float newFrameInliersFraction() const { return _newFrameInliersFraction; }  void setNewFrameInliersFraction(float v) { _newFrameInliersFraction = v; }
+  void init() {                                                                  // pwn_tracker.cpp:38-49
+    delete _previousCloud; if (_currentCloud != _previousCloud) delete _currentCloud;
+    _previousCloud = _currentCloud = nullptr;
+    _globalT.setIdentity(); _previousCloudTransform.setIdentity(); _counter = 0; _numKeyframes = 0;
+  }
+  // pwn_tracker.cpp:106-215
+  FrameResult processFrame(const DepthImage& depthImage, const Isometry3f& sensorOffset, const Matrix3f& cameraMatrix, const Isometry3f& initialGuess = Isometry3f::Identity()) {
+    FrameResult out;
+    int r, c; Matrix3f scaledCameraMatrix = cameraMatrix;
+    Cloud* currentCloud = makeCloud(r, c, scaledCameraMatrix, sensorOffset, depthImage);                         // :115
+    if (_currentCloud != _previousCloud) delete _currentCloud;                                                   // the last non-key cloud
+    _currentCloud = currentCloud;
+    if (_previousCloud) {
+      _aligner->setCurrentSensorOffset(sensorOffset); _aligner->setCurrentCloud(currentCloud);
+      _aligner->setReferenceSensorOffset(_previousCloudOffset); _aligner->setReferenceCloud(_previousCloud);
+      _aligner->correspondenceFinder()->setImageSize(r, c);
+      _aligner->projector()->setCameraMatrix(scaledCameraMatrix); _aligner->projector()->setImageSize(r, c);
+      const Isometry3f guess = iso_mul(iso_mul(_previousCloudTransform.inverse(), _globalT), initialGuess);     // :132
+      _aligner->setInitialGuess(guess);
+      _aligner->align();                                                                                         // :136
+      if (_aligner->inliers() > 0) _globalT = iso_mul(_previousCloudTransform, _aligner->T());                   // :147
+      else _globalT = iso_mul(_globalT, guess);                                                                  // :150
+      if (!(_counter % 50)) {                                                                                    // :154-159: R <- R - 0.5 R (R^T R - I)
+        float R[9], Rt[9], E[9], hR[9], D[9];
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { R[i + 3 * j] = _globalT(i,j); Rt[j + 3 * i] = _globalT(i,j); hR[i + 3 * j] = 0.5f * _globalT(i,j); }
+        mul3(Rt, R, E); E[0] -= 1.f; E[4] -= 1.f; E[8] -= 1.f;
+        mul3(hR, E, D);
+        for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) _globalT(i,j) = R[i + 3 * j] - D[i + 3 * j];
+      }
+      _globalT.forceLastRow();
+      out.aligned = true; out.inliers = _aligner->inliers(); out.error = _aligner->error(); out.T = _aligner->T();
+      out.inliersFraction = (float)_aligner->inliers() / (float)(r * c);
+      if (out.inliersFraction < _newFrameInliersFraction) {                                                      // :164-185
+        out.newFrame = true; ++_numKeyframes;
+        delete _previousCloud;
+        _previousCloud = currentCloud; _previousCloudTransform = _globalT;
+      }
+    } else {                                                                                                     // :194-200
+      out.newFrame = true; ++_numKeyframes;
+      _previousCloud = currentCloud; _previousCloudTransform = _globalT; _previousCloudOffset = sensorOffset;
+    }
+    ++_counter;
+    out.globalT = _globalT;
+    return out;
+  }
+  Cloud* previousCloud() const { return _previousCloud; }  Cloud* currentCloud() const { return _currentCloud; }
+ private:
+  static void mul3(const float* A, const float* B, float* C) {      // 3x3 float product, left-to-right inner products (no FMA: build without -ffast-math)
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { float s = A[i] * B[3 * j]; s = s + A[i + 3] * B[1 + 3 * j]; s = s + A[i + 6] * B[2 + 3 * j]; C[i + 3 * j] = s; }
+  }
+  Cloud* _previousCloud = nullptr; Cloud* _currentCloud = nullptr;
+  Isometry3f _globalT, _previousCloudTransform, _previousCloudOffset;
+  float _newFrameInliersFraction = 0.4f;     // pwn_tracker.cpp:36
+  int _counter = 0, _numKeyframes = 0;
 };
 
 }  // namespace pwn_hip

@@ -150,3 +150,113 @@ def test_scene_mapping_harness_matches_oracle(tmp_path, oracle):
         assert np.isfinite(a["points"]).all() and np.abs(np.linalg.norm(a["normals"][:, :3], axis=1)[np.abs(a["normals"][:, :3]).sum(1) > 0] - 1).max() < 1e-3
     true = np.linalg.inv(poses[0]) @ poses[n - 1]
     assert np.abs(G[:3, 3] - true[:3, 3]).max() < 0.02
+
+
+@pytest.mark.gpu
+def test_tracker_closer_harness_matches_python_mirror(tmp_path):
+    """tools/pwn_hip_tracker_app.cpp -- PwnTracker::processFrame with key-cloud switching, the closure pass through CloudCache + batched
+    matchClouds + PwnCloser's acceptance rule, Aligner statistics (omega, eigen ratios) and SE(3) priors, all over the C++ mirror --
+    against the same flow written with the Python mirror.  Both are thin layers over the same C-ABI calls with the same arguments, so
+    every number must agree to the last digit printed (%.9g round-trips a float)."""
+    from g2o_frontend_amd import api, build, synth
+    from oracle import oracle as O          # parameter tables only
+    build.build_tools()
+    exe = os.path.join(ROOT, "tools", "pwn_hip_tracker_app")
+    n = 5
+    poses = synth.trajectory(13, n)
+    frames = [synth.render_depth_mm(13, poses[k], 480, 640, synth.K_VGA, hole_stream=k) for k in range(n)]
+    lst = []
+    for k, f in enumerate(frames):
+        p = tmp_path / f"d{k}.pgm"
+        write_pgm16(str(p), f)
+        lst.append(f"{k * 0.033:.3f} {p}")
+    # every frame becomes a keyframe (inliers fraction is always < 2), a cache of two clouds forces misses and evictions
+    (tmp_path / "conf.txt").write_text(CONF + "newFrameInliersFraction 2.0\ncacheSize 2\nframeMaxOutliersThreshold 100000\n")
+    (tmp_path / "list.txt").write_text("\n".join(lst) + "\n")
+    prefix = str(tmp_path / "run")
+    subprocess.check_call([exe, str(tmp_path / "conf.txt"), str(tmp_path / "list.txt"), prefix], timeout=300)
+    track = np.loadtxt(prefix + "_track.txt")
+    clos = np.loadtxt(prefix + "_closures.txt", comments="#", ndmin=2)
+    hits_line = [l for l in open(prefix + "_closures.txt") if l.startswith("#")][0].split()
+    extras = {l.split()[0]: np.array(l.split()[1:], np.float64) for l in open(prefix + "_extras.txt")}
+    assert track.shape == (n, 22) and clos.shape == (n * (n - 1) // 2, 24)
+
+    # the same flow with the Python mirror
+    conv, alig = O.QVGA4_CONF_CONVERTER, O.QVGA4_CONF_ALIGNER
+    K = synth.K_VGA
+    Kmat = np.array([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]], np.float32)
+    ctx = api.Context(0, 480, 640, 32)
+    try:
+        cproj, aproj = api.PinholePointProjector(), api.PinholePointProjector()
+        for p in (cproj, aproj):
+            p.setMinDistance(conv["min_distance"]); p.setMaxDistance(conv["max_distance"])
+        stats = api.StatsCalculatorIntegralImage()
+        stats.setWorldRadius(conv["world_radius"]); stats.setMinImageRadius(conv["min_image_radius"]); stats.setMaxImageRadius(conv["max_image_radius"])
+        stats.setMinPoints(conv["min_points"]); stats.setCurvatureThreshold(conv["stats_curvature_threshold"])
+        pinfo, ninfo = api.PointInformationMatrixCalculator(), api.NormalInformationMatrixCalculator()
+        pinfo.setCurvatureThreshold(conv["point_info_curvature_threshold"]); ninfo.setCurvatureThreshold(conv["normal_info_curvature_threshold"])
+        converter = api.DepthImageConverterIntegralImage(cproj, stats, pinfo, ninfo)
+        finder = api.CorrespondenceFinder()
+        finder.setInlierDistanceThreshold(alig["inlier_distance_threshold"]); finder.setInlierNormalAngularThreshold(alig["inlier_normal_angular_threshold"])
+        finder.setFlatCurvatureThreshold(alig["flat_curvature_threshold"]); finder.setInlierCurvatureRatioThreshold(alig["inlier_curvature_ratio_threshold"])
+        lin = api.Linearizer(); lin.setInlierMaxChi2(alig["inlier_max_chi2"]); lin.setRobustKernel(alig["robust_kernel"])
+        aligner = api.Aligner(ctx)
+        aligner.setProjector(aproj); aligner.setLinearizer(lin); aligner.setCorrespondenceFinder(finder)
+        aligner.setOuterIterations(alig["outer_iterations"]); aligner.setInnerIterations(alig["inner_iterations"])
+        tracker = api.PwnTracker(aligner, converter); tracker.setScale(4); tracker.setNewFrameInliersFraction(2.0)
+        I = np.eye(4, dtype=np.float32)
+        depth = [np.where(f > 0, np.float32(0.001) * f.astype(np.float32), np.float32(0)).astype(np.float32) for f in frames]
+        keyPoses = []
+        for k in range(n):
+            out = tracker.processFrame(depth[k], I, Kmat)
+            g = track[k]
+            assert (int(g[0]), bool(g[1]), bool(g[2]), int(g[3])) == (k, out["newFrame"], out["aligned"], out["inliers"]), (k, g[:6], out)
+            assert np.float32(g[4]) == np.float32(out["error"]) and np.float32(g[5]) == np.float32(out.get("inliersFraction", 0.0))
+            assert np.array_equal(g[6:].astype(np.float32).reshape(4, 4).T, out["globalT"]), (k, g[6:], out["globalT"])
+            assert out["newFrame"]
+            keyPoses.append(out["globalT"])
+        # chained odometry follows the true camera motion
+        true = np.linalg.inv(poses[0]) @ poses[n - 1]
+        assert np.abs(keyPoses[-1][:3, 3] - true[:3, 3]).max() < 0.02
+        cache = api.CloudCache(tracker, capacity=2)
+        for k in range(n):
+            cache.addFrame(k, depth[k], Kmat, I)
+        acc = api.PwnCloserAcceptance(frameMaxOutliersThreshold=100000)
+        row = 0
+        for a in range(n):
+            for b in range(a):
+                cur = cache.get(a); oth = cache.get(b)
+                guess = api.iso_mul(api.iso_inverse(keyPoses[b]), keyPoses[a])
+                m = tracker.matchCloudsBatch([oth], [cur], I, I, Kmat, 480, 640, [guess])[0]
+                g = clos[row]; row += 1
+                assert (int(g[0]), int(g[1])) == (b, a)
+                assert (bool(g[2]), int(g[3]), int(g[4]), int(g[5]), int(g[6])) == (acc.accept(m), m["cloud_inliers"], m["image_nonZeros"], m["image_outliers"], m["image_inliers"]), (g[:8], m)
+                assert np.float32(g[7]) == np.float32(m["image_reprojectionDistance"])
+                assert np.array_equal(g[8:].astype(np.float32).reshape(4, 4).T, m["transform"].astype(np.float32))
+                # the closure transform agrees with the tracked relative pose (same scene, consistent estimates)
+                assert np.abs(m["transform"][:3, 3] - guess[:3, 3]).max() < 0.02
+        assert (int(hits_line[3]), int(hits_line[5])) == (cache.hits, cache.misses) and cache.misses > n
+        assert clos[:, 2].sum() >= 1                 # some closure is accepted
+        # statistics and priors
+        ca, cb = cache.get(0), cache.get(1)
+        aproj.setCameraMatrix(Kmat); aproj.setImageSize(480, 640); aproj.scale(np.float32(0.25))
+        finder.setImageSize(aproj.imageRows(), aproj.imageCols())
+        aligner.setSensorOffset(I); aligner.setInitialGuess(I)
+        aligner.setReferenceCloud(ca); aligner.setCurrentCloud(cb)
+        r = aligner.align(statistics=True)
+        e = extras["statistics"]
+        assert bool(e[0]) == aligner.solutionValid()
+        assert np.float32(e[1]) == np.float32(aligner.translationalEigenRatio()) and np.float32(e[2]) == np.float32(aligner.rotationalEigenRatio())
+        assert np.array_equal(e[3:39].astype(np.float32), aligner.omega().ravel(order="F"))
+        assert np.array_equal(e[39:75].astype(np.float32), lin._H.ravel(order="F"))
+        assert np.array_equal(e[75:91].astype(np.float32).reshape(4, 4).T, r["T"])
+        info = np.eye(6, dtype=np.float32) * 1000
+        aligner.setReferenceCloud(ca); aligner.setCurrentCloud(cb)
+        aligner.addAbsolutePrior(I, I, info); aligner.addRelativePrior(I, info)
+        rp = aligner.align()
+        e = extras["priors"]
+        assert (int(e[0]), int(e[1])) == (2, rp["inliers"]) and np.float32(e[2]) == np.float32(rp["error"])
+        assert np.array_equal(e[3:19].astype(np.float32).reshape(4, 4).T, rp["T"])
+        assert not np.array_equal(rp["T"], r["T"])       # the priors did change the estimate
+    finally:
+        ctx.close()
