@@ -154,12 +154,31 @@ class PinholePointProjector {
     for (int c = 0; c < 3; ++c) { _cameraMatrix(0,c) *= s; _cameraMatrix(1,c) *= s; }
     _imageRows = (int)(_imageRows * s); _imageCols = (int)(_imageCols * s);
   }
+  // unProject(points, indexImage, depthImage) (.cpp:68-91 / :93-133 without the Gaussians): fills the cloud's points with this projector's
+  // transform, the other fields are reset to "invalid"
+  void unProject(Context& ctx, Cloud& cloud, IntImage& indexImage, const DepthImage& depthImage) const {
+    indexImage.create(depthImage.rows, depthImage.cols);
+    const pwn_hip_converter_params p = stageParams(0.1f);
+    ctx.check(pwn_hip_unproject(ctx.handle(), &p, _transform.data(), depthImage.data.data(), depthImage.rows, depthImage.cols, cloud.handle(), indexImage.data.data()));
+  }
+  // projectIntervals(intervalImage, depthImage, worldRadius) (.cpp:135-147)
+  void projectIntervals(Context& ctx, IntImage& intervalImage, const DepthImage& depthImage, float worldRadius) const {
+    intervalImage.create(depthImage.rows, depthImage.cols);
+    const pwn_hip_converter_params p = stageParams(worldRadius);
+    ctx.check(pwn_hip_project_intervals(ctx.handle(), &p, depthImage.data.data(), depthImage.rows, depthImage.cols, intervalImage.data.data()));
+  }
   void project(Context& ctx, IntImage& indexImage, DepthImage& depthImage, const Cloud& cloud) const {  // .cpp:33-66
     indexImage.create(_imageRows, _imageCols); depthImage.create(_imageRows, _imageCols);
     ctx.check(pwn_hip_project(ctx.handle(), _cameraMatrix.data(), _transform.data(), _minDistance, _maxDistance, _imageRows, _imageCols,
                               cloud.handle(), indexImage.data.data(), depthImage.data.data()));
   }
  private:
+  pwn_hip_converter_params stageParams(float worldRadius) const {
+    pwn_hip_converter_params p; pwn_hip_default_converter_params(&p);
+    std::memcpy(p.K, _cameraMatrix.data(), sizeof(p.K));
+    p.min_distance = _minDistance; p.max_distance = _maxDistance; p.world_radius = worldRadius;
+    return p;
+  }
   Matrix3f _cameraMatrix; Isometry3f _transform;
   float _minDistance = 0.01f, _maxDistance = 6.0f;                                                        // pointprojector.cpp:9-10
   float _baseline = 0.075f, _alpha = 0.1f;                                                                // pinholepointprojector.cpp:10-11
@@ -295,13 +314,18 @@ class CorrespondenceFinder {
   void setImageSize(int r, int c) { _rows = r; _cols = c; }
   int imageRows() const { return _rows; }  int imageCols() const { return _cols; }
   int numCorrespondences() const { return _numCorrespondences; }
+  // (referenceIndex, currentIndex) pairs of the last Aligner::computeCorrespondences: the first numCorrespondences() are valid, in
+  // row-major pixel order, the rest are (-1,-1) (correspondencefinder.cpp:116-117)
+  const std::vector<int>& correspondences() const { return _correspondences; }
+  int numCandidates() const { return _numCandidates; }
   IntImage& referenceIndexImage() { return _referenceIndexImage; }  IntImage& currentIndexImage() { return _currentIndexImage; }
   DepthImage& referenceDepthImage() { return _referenceDepthImage; }  DepthImage& currentDepthImage() { return _currentDepthImage; }
  private:
   friend class Aligner;
   float _inlierDistanceThreshold = 0.5f, _inlierNormalAngularThreshold = (float)std::cos(M_PI / 6), _flatCurvatureThreshold = 0.02f,
         _inlierCurvatureRatioThreshold = 1.3f;
-  int _rows = 0, _cols = 0, _numCorrespondences = 0;
+  int _rows = 0, _cols = 0, _numCorrespondences = 0, _numCandidates = 0;
+  std::vector<int> _correspondences;
   IntImage _referenceIndexImage, _currentIndexImage; DepthImage _referenceDepthImage, _currentDepthImage;
 };
 class Aligner;
@@ -421,6 +445,23 @@ class Aligner {
     _ctx->check(pwn_hip_align_batch_ex(_ctx->handle(), &p, (int)n, r.data(), c.data(), g.empty() ? nullptr : g.data(), results.data(),
                                        frameInlierDepthThreshold, scores ? scores->data() : nullptr, nullptr));
     return results;
+  }
+  // stage-level entry points with explicit inputs: CorrespondenceFinder::compute(reference, current, T) on two index images
+  // (correspondencefinder.cpp:20-118) and Linearizer::update() with _T = T on the finder's correspondences (linearizer.cpp:17-115)
+  void computeCorrespondences(const IntImage& referenceIndexImage, const IntImage& currentIndexImage, const Isometry3f& T) {
+    if (!_referenceCloud || !_currentCloud) throw Error(PWN_HIP_ERR_INVALID_ARGUMENT, "Aligner: missing cloud");
+    const pwn_hip_aligner_params p = params();
+    CorrespondenceFinder& f = *_correspondenceFinder;
+    f._correspondences.assign((size_t)p.rows * p.cols * 2, -1);
+    _ctx->check(pwn_hip_correspondences(_ctx->handle(), &p, _referenceCloud->handle(), _currentCloud->handle(), referenceIndexImage.data.data(),
+                                        currentIndexImage.data.data(), T.data(), f._correspondences.data(), &f._numCorrespondences, &f._numCandidates));
+  }
+  void linearize(const Isometry3f& T) {
+    if (!_referenceCloud || !_currentCloud) throw Error(PWN_HIP_ERR_INVALID_ARGUMENT, "Aligner: missing cloud");
+    const pwn_hip_aligner_params p = params();
+    CorrespondenceFinder& f = *_correspondenceFinder;
+    _ctx->check(pwn_hip_linearize(_ctx->handle(), &p, _referenceCloud->handle(), _currentCloud->handle(), f._correspondences.data(), f._numCorrespondences,
+                                  T.data(), _linearizer->_H.m, _linearizer->_b.v, &_linearizer->_error, &_linearizer->_inliers));
   }
   Context* context() const { return _ctx; }
  protected:

@@ -258,5 +258,21 @@ def test_tracker_closer_harness_matches_python_mirror(tmp_path):
         assert (int(e[0]), int(e[1])) == (2, rp["inliers"]) and np.float32(e[2]) == np.float32(rp["error"])
         assert np.array_equal(e[3:19].astype(np.float32).reshape(4, 4).T, rp["T"])
         assert not np.array_equal(rp["T"], r["T"])       # the priors did change the estimate
+        aligner.clearPriors()
+        # stage-level calls
+        aproj.setTransform(I)
+        ri, _ = aproj.project(ca); ci, _ = aproj.project(cb)
+        aligner.setReferenceCloud(ca); aligner.setCurrentCloud(cb)
+        corr, ncand = aligner.computeCorrespondences(ri, ci, I)
+        l = aligner.linearize(corr, I)
+        e = extras["stages"]
+        assert (int(e[0]), int(e[1]), int(e[2])) == (len(corr), ncand, l["inliers"]) and np.float32(e[3]) == np.float32(l["chi2"]) and int(e[4]) == int(ri.astype(np.int64).sum())
+        assert np.array_equal(e[5:41].astype(np.float32), l["H"].ravel(order="F")) and np.array_equal(e[41:47].astype(np.float32), l["b"])
+        scaled = O.depth_scale(depth[0], 4)
+        pts = api.Cloud(ctx, scaled.size)
+        ui = aproj.unProject(pts, scaled)
+        itv = aproj.projectIntervals(ctx, scaled, conv["world_radius"])
+        e = extras["projector"]
+        assert (int(e[0]), int(e[1]), int(e[2])) == (pts.size(), int(ui.astype(np.int64).sum()), int(itv.astype(np.int64).sum()))
     finally:
         ctx.close()

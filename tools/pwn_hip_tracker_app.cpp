@@ -183,6 +183,26 @@ int main(int argc, char** argv) {
       std::fprintf(fe, "priors %zu %d %.9g", aligner.numPriors(), aligner.inliers(), aligner.error());
       put16(fe, aligner.T().data()); std::fprintf(fe, "\n");
       aligner.clearPriors();
+      // stage-level calls: project both clouds, CorrespondenceFinder::compute and Linearizer::update at the identity
+      IntImage ri, ci, itv; DepthImage rd, cd;
+      alignerProjector.setTransform(Isometry3f::Identity());
+      alignerProjector.project(ctx, ri, rd, *a); alignerProjector.project(ctx, ci, cd, *b);
+      aligner.setReferenceCloud(a); aligner.setCurrentCloud(b);
+      aligner.computeCorrespondences(ri, ci, Isometry3f::Identity());
+      aligner.linearize(Isometry3f::Identity());
+      long long sumIdx = 0; for (int v : ri.data) sumIdx += v;
+      std::fprintf(fe, "stages %d %d %d %.9g %lld", finder.numCorrespondences(), finder.numCandidates(), linearizer.inliers(), linearizer.error(), sumIdx);
+      for (int i = 0; i < 36; ++i) std::fprintf(fe, " %.9g", linearizer.H().m[i]);
+      for (int i = 0; i < 6; ++i) std::fprintf(fe, " %.9g", linearizer.b()[i]);
+      std::fprintf(fe, "\n");
+      // unProject + projectIntervals of the first (scaled) frame through the projector alone
+      DepthImage scaled; DepthImage_scale(ctx, scaled, frames[keyframes[0]], imageScale);
+      Cloud pts(ctx, scaled.rows * scaled.cols);
+      IntImage ui;
+      alignerProjector.unProject(ctx, pts, ui, scaled);
+      alignerProjector.projectIntervals(ctx, itv, scaled, statsCalculator.worldRadius());
+      long long sumU = 0, sumI = 0; for (int v : ui.data) sumU += v; for (int v : itv.data) sumI += v;
+      std::fprintf(fe, "projector %zu %lld %lld\n", pts.size(), sumU, sumI);
     }
     std::fclose(fe);
   } catch (const Error& e) {
