@@ -94,6 +94,10 @@ class Context {
   Context& operator=(const Context&) = delete;
   pwn_hip_ctx* handle() const { return _ctx; }
   void check(int rc) const { if (rc) throw Error(rc, pwn_hip_last_error_string(_ctx)); }
+  // batch calls: frames / pairs per kernel launch and the number of HIP streams the sub-batches are dealt over (include/pwn_hip.h)
+  void setSubbatch(int frames, int pairs) { check(pwn_hip_ctx_set_subbatch(_ctx, frames, pairs)); }
+  void setConcurrency(int streams) { check(pwn_hip_ctx_set_concurrency(_ctx, streams)); }
+  void synchronize() { check(pwn_hip_ctx_synchronize(_ctx)); }
  private:
   pwn_hip_ctx* _ctx = nullptr;
 };
@@ -251,6 +255,27 @@ class DepthImageConverter {
 class DepthImageConverterIntegralImage : public DepthImageConverter {
  public:
   using DepthImageConverter::DepthImageConverter;
+  // n independent frames of equal size in one call (what a closure batch or a cache refill converts at once): depthFrames[i] -> *clouds[i].
+  // The frame pointers may be host or device memory; the raw variant takes uint16 millimetre frames and fuses
+  // DepthImage_convert_16UC1_to_32FC1(depthScale) in front.  Side effects on the projector as in compute().
+  void computeBatch(const std::vector<Cloud*>& clouds, const std::vector<const float*>& depthFrames, int rows, int cols,
+                    const Isometry3f& sensorOffset = Isometry3f::Identity()) {
+    if (clouds.size() != depthFrames.size()) throw Error(PWN_HIP_ERR_INVALID_ARGUMENT, "computeBatch: list sizes differ");
+    const pwn_hip_converter_params p = params(sensorOffset);
+    _projector->setImageSize(rows, cols); _projector->setTransform(Isometry3f::Identity());
+    std::vector<pwn_hip_cloud*> h(clouds.size());
+    for (size_t i = 0; i < h.size(); ++i) h[i] = clouds[i]->handle();
+    _ctx->check(pwn_hip_convert_batch(_ctx->handle(), &p, depthFrames.data(), (int)h.size(), rows, cols, h.data()));
+  }
+  void computeBatchRaw(const std::vector<Cloud*>& clouds, const std::vector<const uint16_t*>& rawFrames, float depthScale, int rows, int cols,
+                       const Isometry3f& sensorOffset = Isometry3f::Identity()) {
+    if (clouds.size() != rawFrames.size()) throw Error(PWN_HIP_ERR_INVALID_ARGUMENT, "computeBatchRaw: list sizes differ");
+    const pwn_hip_converter_params p = params(sensorOffset);
+    _projector->setImageSize(rows, cols); _projector->setTransform(Isometry3f::Identity());
+    std::vector<pwn_hip_cloud*> h(clouds.size());
+    for (size_t i = 0; i < h.size(); ++i) h[i] = clouds[i]->handle();
+    _ctx->check(pwn_hip_convert_batch_u16(_ctx->handle(), &p, rawFrames.data(), depthScale, (int)h.size(), rows, cols, h.data()));
+  }
   void compute(Cloud& cloud, const DepthImage& depthImage, const Isometry3f& sensorOffset = Isometry3f::Identity()) override {
     if (depthImage.rows <= 0 || depthImage.cols <= 0) throw Error(PWN_HIP_ERR_INVALID_ARGUMENT, "DepthImageConverterIntegralImage: depthImage has zero size");
     const pwn_hip_converter_params p = params(sensorOffset);

@@ -276,3 +276,38 @@ def test_tracker_closer_harness_matches_python_mirror(tmp_path):
         assert (int(e[0]), int(e[1]), int(e[2])) == (pts.size(), int(ui.astype(np.int64).sum()), int(itv.astype(np.int64).sum()))
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_cpp_bench_matches_python_mirror(tmp_path):
+    """tools/pwn_hip_bench.cpp (bench.py's step -- batched convert of the raw frames resident in HBM + batched align -- driven from C++)
+    returns, pair for pair, the bits the Python mirror returns for the same frames and parameters."""
+    from g2o_frontend_amd import api, build, synth
+    from test_gpu_parity import gpu_objects
+    build.build_tools()
+    exe = os.path.join(ROOT, "tools", "pwn_hip_bench")
+    npairs = 3
+    pairs = [synth.make_pair(500 + i, 480, 640, synth.K_VGA) for i in range(npairs)]
+    names = []
+    for i, (r, c, _) in enumerate(pairs):
+        for tag, img in (("r", r), ("c", c)):
+            p = tmp_path / f"{tag}{i}.pgm"
+            write_pgm16(str(p), img); names.append(str(p))
+    (tmp_path / "list.txt").write_text("\n".join(names) + "\n")
+    out = subprocess.check_output([exe, str(tmp_path / "list.txt"), "32", "2", "1"], timeout=300).decode().splitlines()
+    head = out[0].split()
+    assert head[0] == "pairs" and int(head[1]) == 32 and float(head[7]) > 100.0, out[0]
+    rows = [np.array(l.split()[1:], np.float64) for l in out[1:] if l.startswith("pair")]
+    assert len(rows) == npairs
+    ctx = api.Context(0, 480, 640, 8)
+    try:
+        _, converter, aligner = gpu_objects(ctx, "vga")
+        refs = [api.Cloud(ctx, 480 * 640) for _ in pairs]; curs = [api.Cloud(ctx, 480 * 640) for _ in pairs]
+        converter.computeBatch(refs + curs, [p[0] for p in pairs] + [p[1] for p in pairs], raw_scale=0.001)
+        res = aligner.alignBatch(refs, curs)
+        for g, r in zip(rows, res):
+            assert int(g[1]) == r["inliers"] and np.float32(g[2]) == np.float32(r["error"])
+            assert np.array_equal(g[3:19].astype(np.float32).reshape(4, 4).T, r["T"])
+            assert np.array_equal(g[19:].astype(np.float32), r["chi2"])
+    finally:
+        ctx.close()
