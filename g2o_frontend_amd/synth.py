@@ -122,11 +122,12 @@ def render_depth_mm(seed: int, pose: np.ndarray | None = None, rows: int = 480, 
     return mm
 
 
-def make_pair(seed: int, rows: int = 480, cols: int = 640, K=K_VGA, holes: float = 0.03):
-    """(reference depth mm, current depth mm, true T[4x4 float64]) of the seeded pair."""
+def make_pair(seed: int, rows: int = 480, cols: int = 640, K=K_VGA, holes: float = 0.03, noise: bool = False):
+    """(reference depth mm, current depth mm, true T[4x4 float64]) of the seeded pair; noise: the Kinect-like z-noise of
+    render_depth_mm (sigma = 1.2 mm + 1.9 mm/m^2 (z - 0.4 m)^2), off for the parity fixtures."""
     T = pair_pose(seed)
-    ref = render_depth_mm(seed, np.eye(4), rows, cols, K, holes, hole_stream=0)
-    cur = render_depth_mm(seed, T, rows, cols, K, holes, hole_stream=1)
+    ref = render_depth_mm(seed, np.eye(4), rows, cols, K, holes, hole_stream=0, noise=noise)
+    cur = render_depth_mm(seed, T, rows, cols, K, holes, hole_stream=1, noise=noise)
     return ref, cur, T
 
 

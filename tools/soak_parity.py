@@ -45,7 +45,8 @@ def main():
             if seed % 4 == 2:      # other window / threshold settings
                 conv["min_image_radius"] = int(rng.integers(2, 12)); conv["max_image_radius"] = conv["min_image_radius"] + int(rng.integers(1, 20))
                 conv["min_points"] = int(rng.integers(5, 80)); conv["stats_curvature_threshold"] = float(rng.uniform(0.01, 0.3))
-            ref_mm, cur_mm, Ttrue = synth.make_pair(seed, rows, cols, K, holes=float(rng.uniform(0.0, 0.2)))
+            noisy = seed % 5 == 3      # sensor-like z-noise: many non-flat / rejected neighbourhoods, every branch of the eigensolver
+            ref_mm, cur_mm, Ttrue = synth.make_pair(seed, rows, cols, K, holes=float(rng.uniform(0.0, 0.2)), noise=noisy)
             ref, cur = O.convert_16u_to_32f(ref_mm), O.convert_16u_to_32f(cur_mm)
             O.set_gaussians(True)
             cp = O.converter_params(K=K, sensor_offset=offset, **conv)
@@ -76,7 +77,7 @@ def main():
             rel = abs(float(g["chi2"][0]) - it0["chi2_fp64"]) / max(it0["chi2_fp64"], 1e-30)
             assert rel <= 1e-5, (name, seed, "chi2", rel)
             pose = float(np.abs(g["T"] - o["T"]).max())
-            assert pose <= (2e-5 if name == "vga" else 5e-4), (name, seed, "pose", pose)
+            assert pose <= ((2e-5 if name == "vga" else 5e-4) if not noisy else 2e-3), (name, seed, "pose", pose)
             # scene: add both views, merge in the first view
             oscene = O.Cloud(); gscene = api.Cloud(ctx, 2 * rows * cols)
             oscene.add(oref, np.eye(4)); gscene.add(gref, np.eye(4)); oscene.add(ocur, o["T"]); gscene.add(gcur, o["T"])
@@ -89,7 +90,7 @@ def main():
                 assert np.array_equal(bits(oa[k]), bits(ga[k])), (name, seed, "scene", k)
             stats["cases"] += 1; stats["worst_chi2_rel"] = max(stats["worst_chi2_rel"], rel); stats["worst_pose"] = max(stats["worst_pose"], pose)
             stats["points"] += len(oref) + len(ocur); stats["merged"] += int(((ocol >= 0) & (ocol != np.arange(len(ocol)))).sum())
-            print(f"{name} seed {seed}: M {len(oref)}/{len(ocur)} offset {offset is not None} chi2 rel {rel:.1e} pose {pose:.1e} merged {ok}", flush=True)
+            print(f"{name} seed {seed}: M {len(oref)}/{len(ocur)} offset {offset is not None} noise {noisy} chi2 rel {rel:.1e} pose {pose:.1e} merged {ok}", flush=True)
         # the batch path (own index images instead of two of the eleven projections, two streams) against the single alignments: bitwise
         if len(kept) > 1:
             _, _, aligner = gpu_objects(ctx, name)
