@@ -107,6 +107,15 @@ void cloud_free(pwn_hip_cloud* c) {
   delete c;
 }
 
+// the fused correspondence + linearize pass: the throughput shape, or the latency shape when the launch covers at most kLatPairs pairs
+// (same sums bit for bit, see k_corr_linearize_lat)
+constexpr int kLatPairs = 2;
+template <bool SAME_T, bool FULL_H>
+void launch_corr_linearize(int nb, int m, hipStream_t st, const PairDesc* pr, const AlignParams& ap, unsigned tag, int usePrevTc, int ownRef) {
+  if (m <= kLatPairs) hipLaunchKernelGGL((k_corr_linearize_lat<SAME_T, FULL_H>), dim3(nb, m), dim3(kLatBlock), 0, st, pr, ap, tag, usePrevTc, ownRef);
+  else hipLaunchKernelGGL((k_corr_linearize<SAME_T, FULL_H>), dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, tag, usePrevTc, ownRef);
+}
+
 int fail(pwn_hip_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg;
   g_err = msg;
@@ -1130,8 +1139,8 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
         const bool lastInner = (k == p->inner_iterations - 1);
         { StageTimer t(ctx, "corr_linearize", st);
           // first inner pass: the linearizer's transform is bitwise the finder's (aligner.cpp:79,84)
-          if (k == 0) hipLaunchKernelGGL((k_corr_linearize<true, false>), dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, tag, 0, ownRef);
-          else hipLaunchKernelGGL((k_corr_linearize<false, false>), dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, tag, 0, ownRef); }
+          if (k == 0) launch_corr_linearize<true, false>(nb, m, st, pr, ap, tag, 0, ownRef);
+          else launch_corr_linearize<false, false>(nb, m, st, pr, ap, tag, 0, ownRef); }
         { StageTimer t(ctx, "solve", st);
           hipLaunchKernelGGL(k_solve_update, dim3(m), dim3(256), 0, st, pr, ap, nb, lastInner ? 1 : 0); }
       }
@@ -1140,7 +1149,7 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
       // Aligner::_computeStatistics' extra Linearizer::update: the finder's correspondences of the last outer iteration
       // (tests with that iteration's transform) re-linearized at the final transform (aligner.cpp:165-170)
       StageTimer t(ctx, "statistics", st);
-      hipLaunchKernelGGL((k_corr_linearize<false, true>), dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, subLastRefTag, 1, 0);   // full H for _computeStatistics
+      launch_corr_linearize<false, true>(nb, m, st, pr, ap, subLastRefTag, 1, 0);   // full H for _computeStatistics
       hipLaunchKernelGGL(k_reduce_pairs, dim3(m), dim3(256), 0, st, pr, nb, ctx->stats_dev + base);
     }
     if (scores && p->outer_iterations > 0) {
@@ -1242,8 +1251,8 @@ int pwn_hip_align_with_priors(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p,
       hs.invT = invT;
       HIPCHK(ctx, hipMemcpyAsync(ctx->state_ws, &hs, sizeof(PairState), hipMemcpyHostToDevice, st), PWN_HIP_ERR_COPY);
       if (k == 0) hipLaunchKernelGGL(k_project, dim3((ref->d.capacity + 256 * kProjectPointsPerThread - 1) / (256 * kProjectPointsPerThread), 1), dim3(256), 0, st, ctx->pairs_dev, ap, 0, tag);
-      if (k == 0) hipLaunchKernelGGL((k_corr_linearize<true, true>), dim3(nb, 1), dim3(kAlignBlock), 0, st, ctx->pairs_dev, ap, tag, 0, 0);
-      else hipLaunchKernelGGL((k_corr_linearize<false, true>), dim3(nb, 1), dim3(kAlignBlock), 0, st, ctx->pairs_dev, ap, tag, 0, 0);
+      if (k == 0) launch_corr_linearize<true, true>(nb, 1, st, ctx->pairs_dev, ap, tag, 0, 0);
+      else launch_corr_linearize<false, true>(nb, 1, st, ctx->pairs_dev, ap, tag, 0, 0);
       hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, st, ctx->pairs_dev, nb, ctx->stats_dev);
       HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
       HIPCHK(ctx, hipMemcpyAsync(ctx->stats_host, ctx->stats_dev, sizeof(SolveOut), hipMemcpyDeviceToHost, st), PWN_HIP_ERR_COPY);

@@ -1351,6 +1351,98 @@ __global__ void PWN_CL_EU_ATTR __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_co
   block_reduce_store<FULL_H>(acc, pd.partials + (size_t)blockIdx.x * kAccN);
 }
 
+// Latency shape of the fused pass for one or two pairs (sequential odometry: PwnTracker::processFrame aligns one pair at a time).  A pair is
+// only 150 workgroups of k_corr_linearize, one wave per SIMD, so the launch lasts as long as one thread's chain of 8 dependent pixels.  Here
+// a workgroup has 1024 threads for the same 2048-pixel tile: thread (q, col) = (tid / 256, tid % 256) takes pixels q and q + 4 of column col, so
+// the gathers and the arithmetic of all eight pixels of a column run side by side.  The sums stay bit-identical to k_corr_linearize: the
+// per-pixel terms are added to the column's LDS accumulator in the same order, pixel 0, 1, ... 7 -- eight ordered turns, a workgroup barrier
+// between turns -- and the block reduction is the same tree on the same 256 columns.  (Putting the four threads of a column into one wave
+// needs no barriers but makes every wave walk all eight turns and quarters the gathers' coalescing: measured 19 vs 16 us per launch.)
+// grid = (ceil(N / 2048), pairs), block = 1024.
+constexpr int kLatBlock = 4 * kAlignBlock;
+template <bool SAME_T, bool FULL_H>
+__global__ void __launch_bounds__(kLatBlock) k_corr_linearize_lat(const PairDesc* __restrict__ pairs, AlignParams ap, unsigned tag, int usePrevTc, int ownRefIndex) {
+  static_assert(kPixPerThread == 8, "two rounds of four turns");
+  const PairDesc& pd = pairs[blockIdx.y];
+  const int N = ap.rows * ap.cols;
+  const PairState* stp = pd.state;
+  const Mat4 Tc = uniform_iso_global(as_global((const float*)(usePrevTc ? stp->invTcorrPrev.m : stp->invTcorr.m)));
+  const Mat4 Tl = uniform_iso_global(as_global((const float*)stp->invT.m));
+  constexpr int kSlots = LdsAcc<FULL_H>::kSlots;
+  __shared__ float lacc[kSlots * kAlignBlock];
+  __shared__ float lcnt[3 * kAlignBlock];
+  __shared__ float omNtab[27];
+  const int tid = threadIdx.x, col = tid & (kAlignBlock - 1), q = tid >> 8;
+  for (int i = tid; i < kSlots * kAlignBlock; i += kLatBlock) lacc[i] = 0.f;
+  if (tid < 3 * kAlignBlock) lcnt[tid] = 0.f;
+  if (tid < 27) omNtab[tid] = tid < 9 ? 0.f : pd.cur.omN[(tid - 9) / 9][(tid - 9) % 9];
+  const int nref = min(*as_global((const int*)pd.ref.count), pd.ref.capacity), ncur = min(*as_global((const int*)pd.cur.count), pd.cur.capacity);
+  const int pix0 = blockIdx.x * kPixPerThread * kAlignBlock + col;
+  const PairPtrs pp = pair_ptrs(pd);
+  // both pixels' indices, then both pixels' gathers, then both pixels' terms: every load is in flight before the first ordered turn
+  int ri[2], ci[2];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const int pix = pix0 + (q + 4 * r) * kAlignBlock;
+    ri[r] = -1; ci[r] = -1;
+    if (pix < N) {
+      ri[r] = ownRefIndex ? pp.refidx0[(unsigned)pix] : zkey_index(pp.zref[(unsigned)pix], tag);
+      ci[r] = pp.curidx[(unsigned)pix];
+    }
+  }
+  Candidate cand[2];
+  candidate_load(pp, ri[0], ci[0], nref, ncur, cand[0]);
+  candidate_load(pp, ri[1], ci[1], nref, ncur, cand[1]);
+  __syncthreads();                                   // accumulators zeroed, class table written
+  float t[2][kAccN], c3[2][3];
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+#pragma unroll
+    for (int k = 0; k < kAccN; ++k) t[r][k] = 0.f;
+    c3[r][0] = c3[r][1] = c3[r][2] = 0.f;
+    candidate_consume<SAME_T>(pd, pp, ap, Tc, Tl, cand[r], RegAcc{ t[r] }, c3[r], omNtab);
+  }
+#pragma unroll
+  for (int r = 0; r < 2; ++r) {
+    const bool has = c3[r][2] > 0.f;              // linearize_term added this pixel's terms
+#pragma unroll 1
+    for (int turn = 0; turn < 4; ++turn) {
+      if (q == turn) {
+        if (has) {
+#pragma unroll
+          for (int k = 0; k < 34; ++k)
+            if (FULL_H || !acc_is_upper(k)) lacc[(FULL_H ? k : acc_slot_lower(k)) * kAlignBlock + col] += t[r][k];
+        }
+        lcnt[col] += c3[r][0]; lcnt[kAlignBlock + col] += c3[r][1]; lcnt[2 * kAlignBlock + col] += c3[r][2];     // counts: integers, exact in any order
+      }
+      __syncthreads();
+    }
+  }
+  // block reduction: the tree of block_reduce_store on the 256 columns (waves 0..3), the other waves only meet the barrier
+  __shared__ float red[kAlignBlock / 64][kAccN];
+  if (tid < kAlignBlock) {
+    float acc[kAccN];
+#pragma unroll
+    for (int k = 0; k < 34; ++k)
+      acc[k] = (FULL_H || !acc_is_upper(k)) ? lacc[(FULL_H ? k : acc_slot_lower(k)) * kAlignBlock + tid] : 0.f;
+    acc[36] = lcnt[tid]; acc[35] = lcnt[kAlignBlock + tid]; acc[34] = lcnt[2 * kAlignBlock + tid];
+#pragma unroll
+    for (int k = 0; k < kAccN; ++k) {
+      if (!FULL_H && k < 34 && acc_is_upper(k)) { if (lane_id() == 63) red[tid >> 6][k] = 0.f; continue; }
+      const float v = wave_sum_dpp_lane63(acc[k]);
+      if (lane_id() == 63) red[tid >> 6][k] = v;
+    }
+  }
+  __syncthreads();
+  if (tid < kAccN) {
+    const gptr<double> out = as_global(pd.partials + (size_t)blockIdx.x * kAccN);
+    double sum = 0.0;
+#pragma unroll
+    for (int w = 0; w < kAlignBlock / 64; ++w) sum += (double)red[w][tid];
+    out[tid] = sum;
+  }
+}
+
 // CorrespondenceFinder::compute as a per-pixel pair image (compacted on the host in row-major order).
 __global__ void __launch_bounds__(256) k_correspondence_image(CloudDev ref, CloudDev cur, const int* __restrict__ refIndex,
                                                               const int* __restrict__ curIndex, AlignParams ap, Mat4 Tc,
