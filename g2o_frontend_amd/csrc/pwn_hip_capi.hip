@@ -107,9 +107,10 @@ void cloud_free(pwn_hip_cloud* c) {
   delete c;
 }
 
-// the fused correspondence + linearize pass: the throughput shape, or the latency shape when the launch covers at most kLatPairs pairs
-// (same sums bit for bit, see k_corr_linearize_lat)
-constexpr int kLatPairs = 2;
+// the fused correspondence + linearize pass: the throughput shape, or the latency shape when the launch covers a single pair (same sums bit
+// for bit, see k_corr_linearize_lat; its 1024-thread workgroups fit one per CU, so the 300 workgroups of two VGA pairs would already need
+// two rounds on 256 CUs)
+constexpr int kLatPairs = 1;
 template <bool SAME_T, bool FULL_H>
 void launch_corr_linearize(int nb, int m, hipStream_t st, const PairDesc* pr, const AlignParams& ap, unsigned tag, int usePrevTc, int ownRef) {
   if (m <= kLatPairs) hipLaunchKernelGGL((k_corr_linearize_lat<SAME_T, FULL_H>), dim3(nb, m), dim3(kLatBlock), 0, st, pr, ap, tag, usePrevTc, ownRef);
