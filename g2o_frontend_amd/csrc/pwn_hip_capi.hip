@@ -55,6 +55,7 @@ struct pwn_hip_ctx {
   hipStream_t extra[2] = { nullptr, nullptr };
   hipEvent_t fork_ev = nullptr, join_ev = nullptr, join_extra[2] = { nullptr, nullptr };
   int max_rows = 0, max_cols = 0, max_batch = 0;
+  int num_cus = 256;                       // compute units of the device (hipDeviceAttributeMultiprocessorCount)
   size_t N = 0;
   int sub_frames = 64, sub_pairs = 64;
   int concurrency = 2;
@@ -107,13 +108,12 @@ void cloud_free(pwn_hip_cloud* c) {
   delete c;
 }
 
-// the fused correspondence + linearize pass: the throughput shape, or the latency shape when the launch covers a single pair (same sums bit
-// for bit, see k_corr_linearize_lat; its 1024-thread workgroups fit one per CU, so the 300 workgroups of two VGA pairs would already need
-// two rounds on 256 CUs)
-constexpr int kLatPairs = 1;
+// the fused correspondence + linearize pass: the throughput shape, or the latency shape (same sums bit for bit, see k_corr_linearize_lat)
+// when all workgroups of the launch find a CU of their own -- its 1024-thread workgroups fit one per CU, a second round costs more than
+// the shape saves: one VGA pair is 150 workgroups, two pairs or one 1280x960 pair are not worth it on 256 CUs
 template <bool SAME_T, bool FULL_H>
-void launch_corr_linearize(int nb, int m, hipStream_t st, const PairDesc* pr, const AlignParams& ap, unsigned tag, int usePrevTc, int ownRef) {
-  if (m <= kLatPairs) hipLaunchKernelGGL((k_corr_linearize_lat<SAME_T, FULL_H>), dim3(nb, m), dim3(kLatBlock), 0, st, pr, ap, tag, usePrevTc, ownRef);
+void launch_corr_linearize(const pwn_hip_ctx* ctx, int nb, int m, hipStream_t st, const PairDesc* pr, const AlignParams& ap, unsigned tag, int usePrevTc, int ownRef) {
+  if ((long long)nb * m <= ctx->num_cus) hipLaunchKernelGGL((k_corr_linearize_lat<SAME_T, FULL_H>), dim3(nb, m), dim3(kLatBlock), 0, st, pr, ap, tag, usePrevTc, ownRef);
   else hipLaunchKernelGGL((k_corr_linearize<SAME_T, FULL_H>), dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, tag, usePrevTc, ownRef);
 }
 
@@ -494,6 +494,7 @@ int pwn_hip_ctx_create(pwn_hip_ctx** out, int device, int max_rows, int max_cols
   pwn_hip_ctx* ctx = new pwn_hip_ctx();
   ctx->device = device; ctx->max_rows = max_rows; ctx->max_cols = max_cols; ctx->max_batch = max_batch;
   ctx->N = (size_t)max_rows * max_cols;
+  { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->num_cus = cus; }
   const size_t N = ctx->N, B = (size_t)max_batch;
   ctx->nblocks_max = align_nblocks((int)N);
 #define ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc((void**)&(ptr), (bytes)); if (e_ != hipSuccess) { std::string m = std::string("hipMalloc ") + #ptr + ": " + hipGetErrorString(e_); pwn_hip_ctx_destroy(ctx); return fail(nullptr, PWN_HIP_ERR_ALLOCATION, m); } } while (0)
@@ -1140,8 +1141,8 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
         const bool lastInner = (k == p->inner_iterations - 1);
         { StageTimer t(ctx, "corr_linearize", st);
           // first inner pass: the linearizer's transform is bitwise the finder's (aligner.cpp:79,84)
-          if (k == 0) launch_corr_linearize<true, false>(nb, m, st, pr, ap, tag, 0, ownRef);
-          else launch_corr_linearize<false, false>(nb, m, st, pr, ap, tag, 0, ownRef); }
+          if (k == 0) launch_corr_linearize<true, false>(ctx, nb, m, st, pr, ap, tag, 0, ownRef);
+          else launch_corr_linearize<false, false>(ctx, nb, m, st, pr, ap, tag, 0, ownRef); }
         { StageTimer t(ctx, "solve", st);
           hipLaunchKernelGGL(k_solve_update, dim3(m), dim3(256), 0, st, pr, ap, nb, lastInner ? 1 : 0); }
       }
@@ -1150,7 +1151,7 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
       // Aligner::_computeStatistics' extra Linearizer::update: the finder's correspondences of the last outer iteration
       // (tests with that iteration's transform) re-linearized at the final transform (aligner.cpp:165-170)
       StageTimer t(ctx, "statistics", st);
-      launch_corr_linearize<false, true>(nb, m, st, pr, ap, subLastRefTag, 1, 0);   // full H for _computeStatistics
+      launch_corr_linearize<false, true>(ctx, nb, m, st, pr, ap, subLastRefTag, 1, 0);   // full H for _computeStatistics
       hipLaunchKernelGGL(k_reduce_pairs, dim3(m), dim3(256), 0, st, pr, nb, ctx->stats_dev + base);
     }
     if (scores && p->outer_iterations > 0) {
@@ -1252,8 +1253,8 @@ int pwn_hip_align_with_priors(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p,
       hs.invT = invT;
       HIPCHK(ctx, hipMemcpyAsync(ctx->state_ws, &hs, sizeof(PairState), hipMemcpyHostToDevice, st), PWN_HIP_ERR_COPY);
       if (k == 0) hipLaunchKernelGGL(k_project, dim3((ref->d.capacity + 256 * kProjectPointsPerThread - 1) / (256 * kProjectPointsPerThread), 1), dim3(256), 0, st, ctx->pairs_dev, ap, 0, tag);
-      if (k == 0) launch_corr_linearize<true, true>(nb, 1, st, ctx->pairs_dev, ap, tag, 0, 0);
-      else launch_corr_linearize<false, true>(nb, 1, st, ctx->pairs_dev, ap, tag, 0, 0);
+      if (k == 0) launch_corr_linearize<true, true>(ctx, nb, 1, st, ctx->pairs_dev, ap, tag, 0, 0);
+      else launch_corr_linearize<false, true>(ctx, nb, 1, st, ctx->pairs_dev, ap, tag, 0, 0);
       hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, st, ctx->pairs_dev, nb, ctx->stats_dev);
       HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
       HIPCHK(ctx, hipMemcpyAsync(ctx->stats_host, ctx->stats_dev, sizeof(SolveOut), hipMemcpyDeviceToHost, st), PWN_HIP_ERR_COPY);

@@ -1351,7 +1351,7 @@ __global__ void PWN_CL_EU_ATTR __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_co
   block_reduce_store<FULL_H>(acc, pd.partials + (size_t)blockIdx.x * kAccN);
 }
 
-// Latency shape of the fused pass for a launch of one pair (sequential odometry: PwnTracker::processFrame aligns one pair at a time).  A pair is
+// Latency shape of the fused pass for small launches (sequential odometry: PwnTracker::processFrame aligns one pair at a time).  A pair is
 // only 150 workgroups of k_corr_linearize, one wave per SIMD, so the launch lasts as long as one thread's chain of 8 dependent pixels.  Here
 // a workgroup has 1024 threads for the same 2048-pixel tile: thread (q, col) = (tid / 256, tid % 256) takes pixels q and q + 4 of column col, so
 // the gathers and the arithmetic of all eight pixels of a column run side by side.  The sums stay bit-identical to k_corr_linearize: the
