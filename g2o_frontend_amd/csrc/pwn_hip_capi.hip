@@ -333,7 +333,8 @@ int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, h
       hipLaunchKernelGGL(k_integral_cols, dim3((cp.cols + 255) / 256, kIntegralChannels, n), dim3(256), 0, st, fr, cp.rows, cp.cols); }
   }
   { StageTimer t(ctx, "stats", st);
-    const unsigned nblk = 8u * (unsigned)((n + 7) / 8) * (unsigned)cp.rows * (unsigned)((cp.cols + 255) / 256);
+    const unsigned perFrame = (unsigned)cp.rows * (unsigned)((cp.cols + 255) / 256);
+    const unsigned nblk = (n >= 8 ? 8u * (unsigned)((n + 7) / 8) : (unsigned)n) * perFrame;      // see k_stats: XCD-aware placement from 8 frames on
 #ifndef PWN_STATS_LDS
 #define PWN_STATS_LDS 0
 #endif

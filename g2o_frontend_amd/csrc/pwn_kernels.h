@@ -727,7 +727,8 @@ __global__ void __launch_bounds__(256) k_integral_cols(const FrameDesc* __restri
 // XCD-aware 1-D grid: workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share an XCD and its 4 MiB L2), so
 // block b works on frame 8*(k / blocksPerFrame) + (b % 8), k = b / 8, walking that frame's rows in order: every frame lives on
 // one XCD and the four corner reads of neighbouring rows (2*radius rows apart, ~1.6 MB of planes) are L2 hits instead of one
-// L2 fill per XCD.  Placement only affects speed.  grid = 8 * ceil(frames/8) * rows * ceil(cols/256), block = 256.
+// L2 fill per XCD.  Placement only affects speed.  grid = 8 * ceil(frames/8) * rows * ceil(cols/256) (frames >= 8; else frames * rows *
+// ceil(cols/256), frame-major), block = 256.
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { v = (v < lo) ? lo : v; v = (v > hi) ? hi : v; return v; }
 #ifndef PWN_STATS_NT
 #define PWN_STATS_NT 1
@@ -752,10 +753,16 @@ template <typename PTR, typename T> __device__ __forceinline__ void stream_store
 __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ frames, ConvertParams cp, int nframes) {
   const int nxb = (cp.cols + 255) / 256;
   const int perFrame = nxb * cp.rows;
-  const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-  const int frame = (k / perFrame) * 8 + xcd;
+  int frame, rem;
+  if (nframes >= 8) {
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+    frame = (k / perFrame) * 8 + xcd;
+    rem = k % perFrame;
+  } else {                                   // fewer frames than XCDs (tracker, makeCloud): a frame per XCD would idle the others; grid = nframes * perFrame
+    frame = blockIdx.x / perFrame;
+    rem = blockIdx.x % perFrame;
+  }
   if (frame >= nframes) return;
-  const int rem = k % perFrame;
   const FrameDesc& f = frames[frame];
   const int r = rem / nxb;
   const int c = (rem % nxb) * 256 + threadIdx.x;
