@@ -330,7 +330,7 @@ int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, h
     { StageTimer t(ctx, "integral_rows", st);      // unProject + intervals + accumulate + row prefix, one pass over the depth
       hipLaunchKernelGGL(k_unproject_integral_rows, dim3((cp.rows + kIR_Rows - 1) / kIR_Rows, n), dim3(256), 0, st, fr, cp); }
     { StageTimer t(ctx, "integral_cols", st);
-      hipLaunchKernelGGL(k_integral_cols, dim3((cp.cols + 255) / 256, kIntegralChannels, n), dim3(256), 0, st, fr, cp.rows, cp.cols); }
+      hipLaunchKernelGGL(k_integral_cols, dim3((cp.cols + kIC_Block - 1) / kIC_Block, kIntegralChannels, n), dim3(kIC_Block), 0, st, fr, cp.rows, cp.cols); }
   }
   { StageTimer t(ctx, "stats", st);
     const unsigned perFrame = (unsigned)cp.rows * (unsigned)((cp.cols + 255) / 256);
@@ -919,7 +919,7 @@ int pwn_hip_integral_image(pwn_hip_ctx* ctx, const int* index_image, const pwn_h
   HIPCHK(ctx, copy_any(ctx->frames_host[0].index, index_image, N * 4, ctx->stream), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipMemcpyAsync(ctx->frames_dev, ctx->frames_host, sizeof(FrameDesc), hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
   hipLaunchKernelGGL(k_integral_rows, dim3((rows + kIR_Rows - 1) / kIR_Rows, 1), dim3(256), 0, ctx->stream, ctx->frames_dev, rows, cols);
-  hipLaunchKernelGGL(k_integral_cols, dim3((cols + 255) / 256, kIntegralChannels, 1), dim3(256), 0, ctx->stream, ctx->frames_dev, rows, cols);
+  hipLaunchKernelGGL(k_integral_cols, dim3((cols + kIC_Block - 1) / kIC_Block, kIntegralChannels, 1), dim3(kIC_Block), 0, ctx->stream, ctx->frames_dev, rows, cols);
   HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
   HIPCHK(ctx, copy_any(out, ctx->frames_host[0].integral, N * kIntegralChannels * 4, ctx->stream), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);

@@ -699,10 +699,12 @@ __global__ void __launch_bounds__(kII_Threads) k_unproject_integral(const FrameD
   }
 }
 // pass 3 (pwn_core/pointintegralimage.cpp:38-43): prefix-sum along image y inside each image column, sequential.
-// one thread per (column, channel) chain, lanes along x.  grid = (ceil(cols/256), 10, frames), block = 256.
-__global__ void __launch_bounds__(256) k_integral_cols(const FrameDesc* __restrict__ frames, int rows, int cols) {
+// one thread per (column, channel) chain, lanes along x.  grid = (ceil(cols/64), 10, frames), block = 64: this kernel only runs on the
+// latency path (a few frames), where one-wave workgroups spread a frame's 6400 chains over 100 CUs instead of 30.
+constexpr int kIC_Block = 64;
+__global__ void __launch_bounds__(kIC_Block) k_integral_cols(const FrameDesc* __restrict__ frames, int rows, int cols) {
   const FrameDesc& f = frames[blockIdx.z];
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int c = blockIdx.x * kIC_Block + threadIdx.x;
   if (c >= cols) return;
   float* p = f.integral + (size_t)blockIdx.y * rows * cols + c;
   float carry = 0.f;
