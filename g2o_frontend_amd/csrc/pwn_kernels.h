@@ -1543,8 +1543,17 @@ __device__ __forceinline__ void reduce_partials(const double* partials, int nblo
   const int c = threadIdx.x & 63, s = threadIdx.x >> 6;
   if (c < kAccN) {
     double acc = 0.0;
+    int b = s;
+    // 32 independent loads in flight, then the 32 adds in block order (one pair at VGA: 150 records, 38 per wave: two round trips instead of ten)
+    for (; b + 4 * 31 < nblocks; b += 4 * 32) {
+      double v[32];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) v[i] = partials[(size_t)(b + 4 * i) * kAccN + c];
+#pragma unroll
+      for (int i = 0; i < 32; ++i) acc += v[i];
+    }
 #pragma unroll 4
-    for (int b = s; b < nblocks; b += 4) acc += partials[(size_t)b * kAccN + c];
+    for (; b < nblocks; b += 4) acc += partials[(size_t)b * kAccN + c];
     part[s][c] = acc;
   }
   __syncthreads();
