@@ -328,7 +328,10 @@ int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, h
       hipLaunchKernelGGL(k_row_count, dim3(cp.rows, n), dim3(256), 0, st, fr, cp);
       hipLaunchKernelGGL(k_row_offsets, dim3(n), dim3(1024), 0, st, fr, cp.rows); }
     { StageTimer t(ctx, "integral_rows", st);      // unProject + intervals + accumulate + row prefix, one pass over the depth
-      hipLaunchKernelGGL(k_unproject_integral_rows, dim3((cp.rows + kIR_Rows - 1) / kIR_Rows, n), dim3(256), 0, st, fr, cp); }
+      const unsigned epoch = ++ctx->convert_epoch;
+      if (epoch == 0) return fail(ctx, PWN_HIP_ERR_LAUNCH, "convert epoch wrapped: recreate the context");
+      hipLaunchKernelGGL(k_unproject_integral_rows, dim3(8u * (unsigned)((bands_of(cp.rows) + 7) / 8) * (unsigned)strips_of(cp.cols), n), dim3(256), 0, st, fr, cp,
+                         epoch, ctx->fault_dev); }
     { StageTimer t(ctx, "integral_cols", st);
       hipLaunchKernelGGL(k_integral_cols, dim3((cp.cols + kIC_Block - 1) / kIC_Block, kIntegralChannels, n), dim3(kIC_Block), 0, st, fr, cp.rows, cp.cols); }
   }

@@ -383,88 +383,116 @@ __global__ void __launch_bounds__(256) k_integral_rows(const FrameDesc* __restri
     __syncthreads();
   }
 }
-// Converter fast path: unProject + projectIntervals (k_unproject) fused into the row scan.  Depth is read once; the
-// kernel writes the points, the index and interval images AND the row-prefixed integral planes.  Wave w of the block owns
-// rows r0 + w + 4j (j = 0..3) of the 16-row band: one wave instruction covers 64 consecutive columns of one row, so the
-// point index of a valid pixel = row offset + running count of the row + popcount(ballot below the lane).
-// grid = (ceil(rows/16), frames), block = 256.
-__global__ void __launch_bounds__(256) k_unproject_integral_rows(const FrameDesc* __restrict__ frames, ConvertParams cp) {
+// Converter latency path (a few frames: tracker, makeCloud): unProject + projectIntervals fused into the row scan.  Depth is read once;
+// the kernel writes the points, the index and interval images AND the row-prefixed integral planes (k_integral_cols finishes them).
+// One workgroup per 16-row x 64-column tile, so a VGA frame is 300 workgroups instead of 30 walking ten tiles each: unprojecting and
+// storing a tile does not depend on its left neighbour, only the 160 (channel, row) chains do -- they continue from the neighbour's
+// carry, handed over as in k_unproject_integral (one 64-bit word per chain = launch epoch << 32 | float bits, written once per launch;
+// a tile waits only for a lower-numbered workgroup; bounded poll that raises *fault instead of hanging).  All tiles of a band sit on
+// one XCD (workgroup ids are dealt round-robin over the 8 XCDs), so the hand-over words stay in that XCD's L2.  Wave w owns rows
+// r0 + w + 4j (j = 0..3): one wave instruction covers the 64 columns of one row, the point index of a valid pixel = row offset +
+// valid pixels of the row left of the tile (counted here) + popcount(ballot below the lane).
+// grid = (8 * ceil(bands/8) * strips, frames), block = 256.
+constexpr int kII_ChainsRows = kIntegralChannels * kIR_Rows;     // 160
+__global__ void __launch_bounds__(256) k_unproject_integral_rows(const FrameDesc* __restrict__ frames, ConvertParams cp, unsigned epoch, int* __restrict__ fault) {
   const FrameDesc& f = frames[blockIdx.y];
   const int rows = cp.rows, cols = cp.cols;
-  const int r0 = blockIdx.x * kIR_Rows;
+  const int S = (cols + kIR_Cols - 1) / kIR_Cols, NB = (rows + kIR_Rows - 1) / kIR_Rows;
+  const unsigned kk = blockIdx.x >> 3;
+  const int band = 8 * (int)(kk / (unsigned)S) + (int)(blockIdx.x & 7u), s = (int)(kk % (unsigned)S);
+  if (band >= NB) return;
+  const int r0 = band * kIR_Rows, x0 = s * kIR_Cols;
   __shared__ float tile[kIntegralChannels * kIR_Rows * kIR_Stride];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const size_t N = (size_t)rows * cols;
-  const int srow = tid % kIR_Rows, sch = tid / kIR_Rows;
-  float carry = 0.f;
-  int base[kIR_Rows / 4];
+  // 1. unproject the tile
 #pragma unroll
-  for (int j = 0; j < kIR_Rows / 4; ++j) { const int r = r0 + wave + 4 * j; base[j] = (r < rows) ? f.rowoff[r] : 0; }
-  for (int x0 = 0; x0 < cols; x0 += kIR_Cols) {
+  for (int j = 0; j < kIR_Rows / 4; ++j) {
+    const int lr = wave + 4 * j, lc = lane;
+    const int r = r0 + lr, c = x0 + lc;
+    const bool in = r < rows && c < cols;
+    int base = 0;
+    if (r < rows) {                                           // wave-uniform
+      base = f.rowoff[r];
+      for (int t = 0; t < s; ++t) {                           // full strips left of this one
+        const float dl = frame_depth(f, (size_t)r * cols + t * kIR_Cols + lane);
+        base += __popcll(__ballot(!(dl < cp.minD || dl > cp.maxD)));
+      }
+    }
+    const float d = in ? frame_depth(f, (size_t)r * cols + c) : 0.f;
+    const bool valid = in && !(d < cp.minD || d > cp.maxD);
+    const unsigned long long bal = __ballot(valid);
+    float v[kIntegralChannels];
 #pragma unroll
-    for (int j = 0; j < kIR_Rows / 4; ++j) {
-      const int lr = wave + 4 * j, lc = lane;
-      const int r = r0 + lr, c = x0 + lc;
-      const bool in = r < rows && c < cols;
-      const float d = in ? frame_depth(f, (size_t)r * cols + c) : 0.f;
-      const bool valid = in && !(d < cp.minD || d > cp.maxD);
-      const unsigned long long bal = __ballot(valid);
-      float v[kIntegralChannels];
-#pragma unroll
-      for (int k = 0; k < kIntegralChannels; ++k) v[k] = 0.f;
-      if (in) {
-        int idx = -1, itv = -1;
-        if (valid) {
-          idx = base[j] + __popcll(bal & ((1ull << lane) - 1ull));
-          const float a = (float)c * d, b = (float)r * d;
-          float4 p;
-          p.x = dot4seq(cp.iKRt(0,0), a, cp.iKRt(0,1), b, cp.iKRt(0,2), d, cp.iKRt(0,3), 1.0f);
-          p.y = dot4seq(cp.iKRt(1,0), a, cp.iKRt(1,1), b, cp.iKRt(1,2), d, cp.iKRt(1,3), 1.0f);
-          p.z = dot4seq(cp.iKRt(2,0), a, cp.iKRt(2,1), b, cp.iKRt(2,2), d, cp.iKRt(2,3), 1.0f);
-          p.w = 0.f;
-          if (idx < f.cloud.capacity) {
-            f.cloud.P[idx] = p;
-            v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = 1.0f;
-            v[4] = p.x * p.x; v[5] = p.x * p.y; v[6] = p.x * p.z;
-            v[7] = p.y * p.y; v[8] = p.y * p.z; v[9] = p.z * p.z;
-          }
-          const float inv = 1.0f / d;
-          const float px = cp.ivx * inv, py = cp.ivy * inv;
-          itv = (px > py) ? (int)px : (int)py;
+    for (int k = 0; k < kIntegralChannels; ++k) v[k] = 0.f;
+    if (in) {
+      int idx = -1, itv = -1;
+      if (valid) {
+        idx = base + __popcll(bal & ((1ull << lane) - 1ull));
+        const float a = (float)c * d, b = (float)r * d;
+        float4 p;
+        p.x = dot4seq(cp.iKRt(0,0), a, cp.iKRt(0,1), b, cp.iKRt(0,2), d, cp.iKRt(0,3), 1.0f);
+        p.y = dot4seq(cp.iKRt(1,0), a, cp.iKRt(1,1), b, cp.iKRt(1,2), d, cp.iKRt(1,3), 1.0f);
+        p.z = dot4seq(cp.iKRt(2,0), a, cp.iKRt(2,1), b, cp.iKRt(2,2), d, cp.iKRt(2,3), 1.0f);
+        p.w = 0.f;
+        if (idx < f.cloud.capacity) {
+          f.cloud.P[idx] = p;
+          v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = 1.0f;
+          v[4] = p.x * p.x; v[5] = p.x * p.y; v[6] = p.x * p.z;
+          v[7] = p.y * p.y; v[8] = p.y * p.z; v[9] = p.z * p.z;
         }
-        f.index[(size_t)r * cols + c] = idx;
-        f.interval[(size_t)r * cols + c] = itv;
+        const float inv = 1.0f / d;
+        const float px = cp.ivx * inv, py = cp.ivy * inv;
+        itv = (px > py) ? (int)px : (int)py;
       }
-      base[j] += __popcll(bal);
-#pragma unroll
-      for (int k = 0; k < kIntegralChannels; ++k) tile[(k * kIR_Rows + lr) * kIR_Stride + lc] = v[k];
+      f.index[(size_t)r * cols + c] = idx;
+      f.interval[(size_t)r * cols + c] = itv;
     }
-    __syncthreads();
-    if (tid < kIntegralChannels * kIR_Rows) {
-      float* t = &tile[(sch * kIR_Rows + srow) * kIR_Stride];
+#pragma unroll
+    for (int k = 0; k < kIntegralChannels; ++k) tile[(k * kIR_Rows + lr) * kIR_Stride + lc] = v[k];
+  }
+  __syncthreads();
+  // 2. the 160 (channel, row) chains of the tile, continued from the tile to the left
+  if (tid < kII_ChainsRows) {
+    float carry = 0.f;
+    if (s > 0) {
+      const unsigned long long* src = f.carry + ((size_t)(s - 1) * NB + band) * kII_ChainsRows + tid;
+      unsigned long long w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int spins = 0;
+      while ((unsigned)(w >> 32) != epoch) {
+        if (++spins >= (1 << 20)) { atomicExch(fault, 1); break; }       // a starved chain finishes with garbage instead of hanging the device
+        __builtin_amdgcn_s_sleep(1);
+        w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      carry = __uint_as_float((unsigned)w);
+    }
+    const int srow = tid % kIR_Rows, sch = tid / kIR_Rows;
+    float* t = &tile[(sch * kIR_Rows + srow) * kIR_Stride];
 #pragma unroll 1
-      for (int c0 = 0; c0 < kIR_Cols; c0 += 16) {          // 16 LDS reads in flight, then the sequential adds
-        float vals[16];
+    for (int c0 = 0; c0 < kIR_Cols; c0 += 16) {          // 16 LDS reads in flight, then the sequential adds
+      float vals[16];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) vals[c] = t[c0 + c];
+      for (int c = 0; c < 16; ++c) vals[c] = t[c0 + c];
 #pragma unroll
-        for (int c = 0; c < 16; ++c) { carry = vals[c] + carry; vals[c] = carry; }
+      for (int c = 0; c < 16; ++c) { carry = vals[c] + carry; vals[c] = carry; }
 #pragma unroll
-        for (int c = 0; c < 16; ++c) t[c0 + c] = vals[c];
-      }
+      for (int c = 0; c < 16; ++c) t[c0 + c] = vals[c];
     }
-    __syncthreads();
+    if (s + 1 < S)
+      __hip_atomic_store(f.carry + ((size_t)s * NB + band) * kII_ChainsRows + tid,
+                         ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(carry), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  // 3. the row-prefixed planes
 #pragma unroll
-    for (int j = 0; j < kIR_Rows / 4; ++j) {
-      const int lr = wave + 4 * j, lc = lane;
-      const int r = r0 + lr, c = x0 + lc;
-      if (r < rows && c < cols) {
+  for (int j = 0; j < kIR_Rows / 4; ++j) {
+    const int lr = wave + 4 * j, lc = lane;
+    const int r = r0 + lr, c = x0 + lc;
+    if (r < rows && c < cols) {
 #pragma unroll
-        for (int k = 0; k < kIntegralChannels; ++k)
-          f.integral[k * N + (size_t)r * cols + c] = tile[(k * kIR_Rows + lr) * kIR_Stride + lc];
-      }
+      for (int k = 0; k < kIntegralChannels; ++k)
+        f.integral[k * N + (size_t)r * cols + c] = tile[(k * kIR_Rows + lr) * kIR_Stride + lc];
     }
-    __syncthreads();
   }
 }
 // ------------------------------------------------------------------------------------------------------------------
