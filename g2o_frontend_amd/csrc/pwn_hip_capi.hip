@@ -309,7 +309,7 @@ int ensure_desc(pwn_hip_ctx* ctx, int n) {
 int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, hipStream_t st) {
   const FrameDesc* fr = ctx->frames_dev + base;
 #ifndef PWN_SINGLE_PASS_MIN_FRAMES
-#define PWN_SINGLE_PASS_MIN_FRAMES 24     // measured crossover on MI355X at VGA: 16 frames 0.38 vs 0.36 ms, 32 frames 0.64 vs 0.70 ms
+#define PWN_SINGLE_PASS_MIN_FRAMES 16     // measured on MI355X at VGA (tools/ab_convert_n.py), three kernels vs single pass: 8 frames 0.20 vs 0.27 ms, 16 frames 0.38 vs 0.35, 32 frames 0.74 vs 0.58
 #endif
   if (n >= PWN_SINGLE_PASS_MIN_FRAMES) {
     // throughput path: the integral planes are written once; a frame is a chain of strips * bands hand-over steps, so it

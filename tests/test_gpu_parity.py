@@ -542,7 +542,7 @@ def test_odd_image_sizes(oracle, rows, cols):
                 a, b = o[k].reshape(len(o[k]), -1), g[k].reshape(len(g[k]), -1)
                 assert (((a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0)))).all(), k
         same(oref.arrays(), gref.arrays()); same(ocur.arrays(), gcur.arrays())
-        # the batch path (>= 24 frames: single-pass strip kernel)
+        # the batch path (>= 16 frames: single-pass strip kernel)
         many = [api.Cloud(ctx, rows * cols) for _ in range(26)]
         converter.computeBatch(many, [ref_mm, cur_mm] * 13, raw_scale=0.001)
         for k in (0, 1, 24, 25):
