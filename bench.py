@@ -5,18 +5,24 @@ Workload (BASELINE.json configs[3] sharded as SURVEY.md §8(e) prescribes; at N=
 1024-pair loop-closure batch, at N=1 it is one GPU's 128-pair shard): every rank owns `--pairs`
 independent synthetic VGA depth pairs, resident in HBM as uint16 millimetre frames when the timed region
 starts.  One step = for every pair: DepthImage_convert_16UC1_to_32FC1 + DepthImageConverterIntegralImage::compute
-on both frames, then Aligner::align (10 outer x 1 inner iterations), then (N>1) an RCCL all-gather of the
-4x4 poses.  Nothing is cached between steps.
+on both frames, then Aligner::align (10 outer x 1 inner iterations), then an all-gather of the result records
+(RCCL when N > 1).  Nothing is cached between steps.
 
-Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, live hipEvent
-timing inside the timed region) and `cpu_baseline` (the CPU oracle = a port of the reference path, timed on
-this box's host cores on a bounded sample of the same workload).
+`python bench.py --gpus N` without a torchrun environment starts the N ranks itself (one process per GPU, before
+anything touches a GPU); under `python -m torch.distributed.run ... bench.py --gpus N` it is one of the N ranks.
+
+Prints ONE JSON line (rank 0) with the contract fields plus `roofline` (dominant kernel, live hipEvent timing),
+`cpu_baseline` (the CPU oracle = a port of the reference path, timed on this box's host cores on a bounded sample
+of the same workload) and, at N = 1, the other lines of SURVEY.md §8(d) as extra keys: `chi2_match`, `align_only`,
+`closure_match_batch` (the loop-closure call proper: non-identity guesses + matchClouds scores), `config5_1280x960`,
+`tracker_config2` (BASELINE configs[2]: 200-frame VGA stream through PwnTracker::processFrame).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -26,10 +32,10 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6 TB/s is what a bare streaming read gets on these boxes
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
@@ -39,14 +45,19 @@ def parse():
     ap.add_argument("--cols", type=int, default=640)
     ap.add_argument("--sub-frames", type=int, default=int(os.environ.get("PWN_SUB_FRAMES", 64)))
     ap.add_argument("--sub-pairs", type=int, default=int(os.environ.get("PWN_SUB_PAIRS", 64)))
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the CPU baseline sample")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of each leg of the CPU baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-latency", action="store_true")
-    ap.add_argument("--align-only", action="store_true", help="also time align-only (clouds resident)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the extra bench lines (align_only, closure_match_batch, config5, tracker)")
+    ap.add_argument("--no-config5", action="store_true")
+    ap.add_argument("--no-tracker", action="store_true")
+    ap.add_argument("--tracker-frames", type=int, default=200)
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run only the CPU baseline leg and print its JSON")
     ap.add_argument("--no-profile", action="store_true", help="skip the serial profiled pass (roofline fields become 0)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the batch calls use in the timed region (1 = serial)")
-    return ap.parse_args()
+    ap.add_argument("--dry-run-cpu", action="store_true",
+                    help="launcher / sharding / gather plumbing only, on the CPU with the gloo backend (no GPU, no kernels): used by tests")
+    return ap.parse_args(argv)
 
 
 def conf(rows, cols):
@@ -83,42 +94,89 @@ def build_objects(ctx, rows, cols, K, conv, alig):
     return converter, al
 
 
-def cpu_baseline(rows, cols, K, conv, alig, seeds, budget_s):
-    """The CPU oracle (port of the reference CPU path) on a bounded sample of the same workload, one thread."""
+# ------------------------------------------------------------------------------------------------ launcher (N > 1 without torchrun)
+def _free_port():
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def launch_ranks(n: int, argv) -> int:
+    """One child process per GPU, started before this process has touched a GPU (it never does).  Rank 0's stdout is this
+    process's stdout (the one JSON line); the other ranks' stdout goes to stderr.  Returns the worst exit code."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.2)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:          # a rank failed: the others would wait in a collective for ever
+                    q.terminate()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------ input rendering (CPU, before GPU init)
+def _render_job(job):
     from g2o_frontend_amd import synth
-    from oracle import oracle as O
-    O.set_num_threads(1)
-    cp = O.converter_params(K=K, **conv)
-    apar = O.aligner_params(rows, cols, K=K, **alig)
+    kind = job[0]
+    if kind == "pair":
+        _, seed, rows, cols, K = job
+        ref_mm, cur_mm, _ = synth.make_pair(seed, rows, cols, K)
+        return ref_mm, cur_mm
+    _, seed, pose, rows, cols, K, hole_stream = job
+    return synth.render_depth_mm(seed, np.asarray(pose), rows, cols, K, hole_stream=hole_stream)
+
+
+def render_all(jobs, world):
+    """the synthetic uint16 frames of all jobs, rendered by a pool of CPU processes (spawned before the GPU is initialised)"""
+    import concurrent.futures as cf
+    import multiprocessing as mp
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    workers = max(1, min(16, ncpu // max(world, 1), len(jobs)))
+    if workers == 1:
+        return [_render_job(j) for j in jobs]
+    with cf.ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as ex:
+        return list(ex.map(_render_job, jobs, chunksize=max(1, len(jobs) // (4 * workers))))
+
+
+# ------------------------------------------------------------------------------------------------ CPU baseline (child process)
+def _cpu_pairs_loop(O, synth, rows, cols, K, cp, apar, seeds, budget_s):
     done, t_conv, t_align, t0 = 0, 0.0, 0.0, time.perf_counter()
     for s in seeds:
-        ref_mm, cur_mm, _ = synth.make_pair(s, rows, cols, K)
+        ref_mm, cur_mm, _ = synth.make_pair(s, rows, cols, K)          # rendering is not part of the measured work
         a = time.perf_counter()
-        ref = O.convert_16u_to_32f(ref_mm); cur = O.convert_16u_to_32f(cur_mm)
-        cr, _, _ = O.convert(cp, ref); cc, _, _ = O.convert(cp, cur)
+        cr, _, _ = O.convert(cp, O.convert_16u_to_32f(ref_mm)); cc, _, _ = O.convert(cp, O.convert_16u_to_32f(cur_mm))
         b = time.perf_counter()
         O.align(apar, cr, cc)
         c = time.perf_counter()
         t_conv += b - a; t_align += c - b; done += 1
         if time.perf_counter() - t0 > budget_s:
             break
-    tot = t_conv + t_align
-    out = {"value": done / tot, "unit": "alignments/s", "cores": 1, "kind": "port",
-           "sample": f"{done} of the benchmark's {rows}x{cols} pairs (convert 2 frames + align, 10 GN iterations), "
-                     f"single thread, {tot:.1f} s CPU ({t_conv / done * 1e3:.0f} ms convert + {t_align / done * 1e3:.0f} ms align per pair)",
-           "align_only_value": done / t_align}
-    return out
+    return done, t_conv, t_align
 
 
 def _cpu_worker(job):
-    """one host core: `n` pairs of the same workload through the oracle, single-threaded; returns (pairs, seconds of oracle work)"""
+    """one host core: its own pairs of the same workload through the oracle, single-threaded; (pairs, seconds of oracle work)"""
     rows, cols, K, conv, alig, seeds = job
+    os.environ["PWN_ORACLE_VARIANT"] = "fast"
     from g2o_frontend_amd import synth
     from oracle import oracle as O
-    O.set_num_threads(1)
+    O.set_num_threads(1); O.set_parallel_align(False)
     cp = O.converter_params(K=K, **conv)
     apar = O.aligner_params(rows, cols, K=K, **alig)
-    frames = [synth.make_pair(s, rows, cols, K) for s in seeds]        # rendering the synthetic frames is not part of the measured work
+    frames = [synth.make_pair(s, rows, cols, K) for s in seeds]
     t0 = time.perf_counter()
     for ref_mm, cur_mm, _ in frames:
         cr, _, _ = O.convert(cp, O.convert_16u_to_32f(ref_mm)); cc, _, _ = O.convert(cp, O.convert_16u_to_32f(cur_mm))
@@ -126,52 +184,400 @@ def _cpu_worker(job):
     return len(frames), time.perf_counter() - t0
 
 
-def cpu_baseline_all_cores(rows, cols, K, conv, alig, per_core, max_cores=32):
-    """the same oracle on every host core at once: independent pairs, one single-threaded process per core (the way the reference's own
-    loop-closure batch would be spread over a CPU)"""
-    import concurrent.futures as cf
-    import multiprocessing as mp
-    cores = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), max_cores))
-    jobs = [(rows, cols, K, conv, alig, [1000 + c * per_core + i for i in range(per_core)]) for c in range(cores)]
-    with cf.ProcessPoolExecutor(max_workers=cores, mp_context=mp.get_context("spawn")) as ex:
-        res = list(ex.map(_cpu_worker, jobs))
-    pairs = sum(r[0] for r in res); slowest = max(r[1] for r in res)
-    return {"value": pairs / slowest, "unit": "alignments/s", "cores": cores,
-            "sample": f"{pairs} pairs, {per_core} per core on {cores} cores at once (one single-threaded oracle process per core), slowest core {slowest:.1f} s"}
+def cpu_baseline_child(args):
+    """The CPU oracle (port of the reference CPU path; BASELINE.md §3: -O3 -march=native, built on this host) on bounded samples of the
+    benchmark's own pairs: (i) one thread, (ii) OpenMP over all cores inside each alignment like the reference (rows / correspondences
+    over threads, without its remainder dropping), (iii) one single-threaded process per core on independent pairs (how a CPU would
+    run the loop-closure batch).  Also returns the fp64-accumulated chi2 traces of the first pairs for the bench line's chi2_match."""
+    os.environ["PWN_ORACLE_VARIANT"] = "fast"
+    rows, cols = args.rows, args.cols
+    K, conv, alig = conf(rows, cols)
+    from g2o_frontend_amd import synth
+    from oracle import oracle as O
+    O.lib()                                                 # builds oracle/_fast/<cpu>/libpwn_oracle.so on first use (untimed)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cp = O.converter_params(K=K, **conv)
+    apar = O.aligner_params(rows, cols, K=K, **alig)
+    out = {"unit": "alignments/s", "kind": "port", "build": "g++ -O3 -march=native -ffp-contract=off -fopenmp (built on this host)"}
+    # (i) one thread
+    O.set_num_threads(1); O.set_parallel_align(False)
+    done, t_conv, t_align = _cpu_pairs_loop(O, synth, rows, cols, K, cp, apar, range(0, 64), args.cpu_seconds)
+    single = done / (t_conv + t_align)
+    out.update(single_thread_value=single, single_thread_ms_convert=t_conv / done * 1e3, single_thread_ms_align=t_align / done * 1e3,
+               align_only_single_thread_value=done / t_align)
+    # (ii) OpenMP inside each alignment
+    omp_cores = min(cores, 64)
+    O.set_num_threads(omp_cores); O.set_parallel_align(True)
+    d2, c2, a2 = _cpu_pairs_loop(O, synth, rows, cols, K, cp, apar, range(64, 192), args.cpu_seconds / 2)
+    out.update(openmp_value=d2 / (c2 + a2), openmp_cores=omp_cores)
+    # (iii) one process per core
+    O.set_num_threads(1); O.set_parallel_align(False)
+    per_core = 0
+    try:
+        import concurrent.futures as cf
+        import multiprocessing as mp
+        pc = max(1, min(cores, 64))
+        per_core = max(1, int(0.5 * args.cpu_seconds * single))
+        jobs = [(rows, cols, K, conv, alig, [1000 + c * per_core + i for i in range(per_core)]) for c in range(pc)]
+        with cf.ProcessPoolExecutor(max_workers=pc, mp_context=mp.get_context("spawn")) as ex:
+            res = list(ex.map(_cpu_worker, jobs))
+        pairs = sum(r[0] for r in res); slowest = max(r[1] for r in res)
+        out.update(all_cores_value=pairs / slowest, all_cores=pc)
+    except Exception as e:      # never let one leg break the line
+        out.update(all_cores_value=None, all_cores=0, all_cores_error=str(e)[:200])
+    # the reported baseline = the strongest CPU configuration measured
+    best = max([(single, 1, "one thread"), (out["openmp_value"], omp_cores, "OpenMP inside each alignment"),
+                (out.get("all_cores_value") or 0.0, out.get("all_cores") or 0, "one single-threaded process per core")], key=lambda t: t[0])
+    out.update(value=best[0], cores=best[1],
+               sample=f"{best[2]}; {rows}x{cols} pairs of the benchmark (convert 2 frames + align, 10 GN it.), "
+                      f"{done} pairs 1-thread / {d2} OpenMP / {out.get('all_cores', 0)}x{per_core if out.get('all_cores') else 0} per-core")
+    # chi2 traces for chi2_match: fp64-accumulated sums (what the 1e-5 bar is stated against), canonical one-thread align loops
+    O.set_num_threads(omp_cores); O.set_parallel_align(False)
+    ap64 = O.aligner_params(rows, cols, K=K, accumulate_fp64=1, **alig)
+    traces = []
+    for s in range(0, 3):
+        ref_mm, cur_mm, _ = synth.make_pair(s, rows, cols, K)
+        cr, _, _ = O.convert(cp, O.convert_16u_to_32f(ref_mm)); cc, _, _ = O.convert(cp, O.convert_16u_to_32f(cur_mm))
+        r64 = O.align(ap64, cr, cc)
+        r32 = O.align(apar, cr, cc)
+        traces.append({"seed": s, "chi2_fp64": [float(it["chi2_fp64"]) for it in r64["iterations"]],
+                       "chi2_fp32_serial": [float(it["chi2"]) for it in r32["iterations"]], "T": r64["T"].astype(float).tolist()})
+    out["chi2_traces"] = traces
+    print(json.dumps(out))
 
 
+# ------------------------------------------------------------------------------------------------ the batch workload (headline, config 5)
+STAGES = ["u16_to_f32", "unproject", "integral", "integral_rows", "integral_cols", "stats", "project_cur", "project_ref", "corr_linearize", "solve"]
+
+
+class BatchWorkload:
+    """`P` pairs of one frame size on one context: convert 2P frames + align P pairs per step."""
+
+    def __init__(self, args, device, rows, cols, P, frames_mm, seeds, use_dist, world):
+        import ctypes as C
+        import torch
+        from g2o_frontend_amd import api, shard
+        self.args, self.rows, self.cols, self.P, self.seeds, self.use_dist, self.world = args, rows, cols, P, list(seeds), use_dist, world
+        self.N = rows * cols
+        self.K, self.conv, self.alig = conf(rows, cols)
+        self.n_it = self.alig["outer_iterations"] * self.alig["inner_iterations"]
+        slots = max(2, args.streams) * max(args.sub_frames, args.sub_pairs, 1)      # room for one sub-batch in flight per stream
+        self.ctx = api.Context(device=device, max_rows=rows, max_cols=cols, max_batch=slots)
+        self.ctx.set_subbatch(args.sub_frames, args.sub_pairs)
+        self.converter, self.aligner = build_objects(self.ctx, rows, cols, self.K, self.conv, self.alig)
+        self.ref_dev = [torch.from_numpy(f[0].view(np.int16)).cuda() for f in frames_mm]
+        self.cur_dev = [torch.from_numpy(f[1].view(np.int16)).cuda() for f in frames_mm]
+        self.refs = [api.Cloud(self.ctx, self.N) for _ in range(P)]
+        self.curs = [api.Cloud(self.ctx, self.N) for _ in range(P)]
+        self.records = torch.empty((P, shard.RECORD_FLOATS), dtype=torch.float32, device="cuda")
+        self.records_host = torch.empty((P, shard.RECORD_FLOATS), dtype=torch.float32).pin_memory()
+        self.conv_prep = self.converter.batchHandles(self.refs + self.curs, self.ref_dev + self.cur_dev)
+        self.align_prep = ((C.c_void_p * P)(*[c.h for c in self.refs]), (C.c_void_p * P)(*[c.h for c in self.curs]), P)
+        self.stage_ms = {k: 0.0 for k in STAGES}; self.stage_n = {k: 0 for k in STAGES}
+        self.last = {}
+
+    def step(self, profile=False):
+        from g2o_frontend_amd import shard
+        self.converter.computeBatch(self.refs + self.curs, self.ref_dev + self.cur_dev, raw_scale=0.001, prepared=self.conv_prep)
+        if profile:
+            for k in STAGES[:6]:
+                ms, n = self.ctx.stage_ms(k); self.stage_ms[k] += ms; self.stage_n[k] += n
+        res = self.aligner.alignBatch(self.refs, self.curs, raw=True, prepared=self.align_prep)
+        if profile:
+            for k in STAGES[6:]:
+                ms, n = self.ctx.stage_ms(k); self.stage_ms[k] += ms; self.stage_n[k] += n
+        self.records_host.numpy()[:] = shard.pack_results_raw(res, self.seeds)
+        self.records.copy_(self.records_host, non_blocking=False)
+        self.last["gathered"] = shard.gather_records(self.records, self.world, self.P, force=self.use_dist)      # the only collective of the path
+        self.last["res"] = res
+
+    def barrier(self):
+        import torch
+        if self.use_dist:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def run(self, steps, warmup, profile=True):
+        """timed region in the product configuration (streams, no instrumentation), then the same steps again on one stream with a
+        hipEvent pair around every kernel stage: with two streams the launches of different sub-batches overlap, so a launch's elapsed
+        time is not the kernel's own duration (the rocprofv3 summaries in profiles/ are taken the same way: bench.py --streams 1)."""
+        ctx = self.ctx
+        ctx.set_concurrency(self.args.streams); ctx.set_profiling(False)
+        for _ in range(warmup):
+            self.step()
+        self.barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        self.barrier()
+        dt = time.perf_counter() - t0
+        dt_serial = None
+        if profile:
+            ctx.set_concurrency(1); ctx.set_profiling(True)
+            self.step()
+            self.barrier()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                self.step(True)
+            self.barrier()
+            dt_serial = time.perf_counter() - t1
+            ctx.set_profiling(False); ctx.set_concurrency(self.args.streams)
+        return dt, dt_serial
+
+    # ---- algorithmic bytes of SURVEY.md §8(d) from the measured counters
+    def bytes_per_pair(self, res, proj_cur_per_pair, proj_ref_per_pair):
+        N, n_it = float(self.N), self.n_it
+        Mr = res["n_reference"].astype(np.float64); Mc = res["n_current"].astype(np.float64)
+        Ks = res["iter_candidates"].sum(1).astype(np.float64); Cs = res["iter_correspondences"].sum(1).astype(np.float64)
+        convert = 2 * 8.0 * N + 64.0 * (Mr + Mc)                                   # two frames: 8N + 64M each
+        fused = n_it * 8.0 * N + 72.0 * Ks + 28.0 * Cs                             # all iterations
+        project = proj_cur_per_pair * (16.0 * Mc + 4.0 * N) + proj_ref_per_pair * (16.0 * Mr + 4.0 * N)      # EXECUTED projections only
+        align = project + fused + 8.0 * N
+        return dict(convert=convert, fused=fused, project=project, align=align, Mr=Mr, Mc=Mc, Ks=Ks, Cs=Cs)
+
+    def report(self, steps, dt, dt_serial, world):
+        res = self.last["res"]; P = self.P
+        nsub = (P + self.args.sub_pairs - 1) // self.args.sub_pairs
+        pc = self.stage_n["project_cur"] / max(steps, 1) / nsub if dt_serial else 1.0
+        pr = self.stage_n["project_ref"] / max(steps, 1) / nsub if dt_serial else float(self.n_it)
+        b = self.bytes_per_pair(res, pc, pr)
+        total_step = float((b["convert"] + b["align"]).sum())
+        launches = max(self.stage_n["corr_linearize"], 1)
+        k_ms = self.stage_ms["corr_linearize"] / launches
+        k_bytes = float(b["fused"].sum()) * steps / launches
+        achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        conv_ms = sum(self.stage_ms[k] for k in STAGES[:6]) / max(steps, 1)
+        conv_GBps = float(b["convert"].sum()) / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tfile):
+            try:      # measured per pair-iteration by the PMC passes (profiles/), scaled to what one launch of this run covers; every
+                tj = json.load(open(tfile))      # term of the kernel's traffic is per pixel / per point, so other frame sizes scale with N
+                traffic = tj.get("k_corr_linearize_bytes_per_pair_iteration") * (self.N / tj.get("pixels_per_frame", 307200)) * (P * self.n_it * steps / launches)
+            except Exception:
+                traffic = None
+        dom = max(STAGES, key=lambda k: self.stage_ms[k])
+        roofline = {"bound": "hbm", "kernel": "k_corr_linearize", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "bytes_per_launch_algorithmic": k_bytes, "avg_launch_ms": k_ms, "launches": self.stage_n["corr_linearize"],
+                    "dominant_by_time": dom,
+                    "traffic_GBps": (traffic / (k_ms * 1e-3) / 1e9) if (traffic and k_ms > 0) else None,
+                    # the whole step (timed region, product configuration) and the converter (serial profiled pass) against the same peak
+                    "path_achieved_GBps": total_step * steps / dt / 1e9, "path_frac": total_step * steps / dt / 1e9 / HBM_PEAK_GBS,
+                    "converter_ms_per_step": conv_ms, "converter_achieved_GBps": conv_GBps, "converter_frac": conv_GBps / HBM_PEAK_GBS,
+                    "projections_per_pair": pc + pr,
+                    "measured_in": "serial profiled pass of the same K steps (one stream, hipEvent pair per kernel stage); "
+                                   "the timed region runs the streams without instrumentation",
+                    "serial_pass_alignments_per_s": (world * P * steps / dt_serial) if dt_serial else None}
+        return dict(value=world * P * steps / dt, ms_per_step=dt / steps * 1e3, roofline=roofline,
+                    path_roofline={"algorithmic_bytes_per_pair": total_step / P, "achieved_GBps": total_step * steps / dt / 1e9,
+                                   "frac_of_peak": total_step * steps / dt / 1e9 / HBM_PEAK_GBS,
+                                   "projections_counted_per_pair": pc + pr},
+                    stage_ms_per_step={k: self.stage_ms[k] / max(steps, 1) for k in STAGES},
+                    stage_launches_per_step={k: self.stage_n[k] / max(steps, 1) for k in STAGES},
+                    counters_mean={"M_ref": float(b["Mr"].mean()), "M_cur": float(b["Mc"].mean()), "K_sum": float(b["Ks"].mean()),
+                                   "C_sum": float(b["Cs"].mean()), "chi2_final": float(res["error"].mean()), "inliers_final": float(res["inliers"].mean())})
+
+    def close(self):
+        self.refs = self.curs = None
+        self.ctx.close()
+
+
+def closure_guesses(seeds, t_noise=0.01, q_noise=0.004):
+    """initial guesses of a loop-closure candidate batch (pwn_tracker/pwn_closer.cpp:132-137: iT * other.T from the odometry): the true
+    relative pose disturbed by a seeded error of <= 1 cm / ~0.5 deg per axis, with the z translation zeroed as
+    PwnMatcherBase::matchClouds does (pwn_matcher_base.cpp:114).  Column-major float32 [n, 16]."""
+    from g2o_frontend_amd import synth
+    g = np.empty((len(seeds), 16), np.float32)
+    for i, s in enumerate(seeds):
+        u = synth._uniform(s, 7, 6)
+        dv = np.concatenate([(2 * u[0:3] - 1) * t_noise, (2 * u[3:6] - 1) * q_noise])
+        T = (synth.pair_pose(s) @ synth.v2t(dv)).astype(np.float32)
+        T[2, 3] = 0.0; T[3] = (0, 0, 0, 1)
+        g[i] = T.T.reshape(-1)
+    return g
+
+
+def run_extras_vga(w: BatchWorkload, args):
+    """clouds are resident from the last step: the align-only and loop-closure lines of SURVEY.md §8(d)"""
+    import ctypes as C
+    from g2o_frontend_amd import api
+    from g2o_frontend_amd._lib import AlignResult, MatchResult
+    out = {}
+    P, steps, ctx = w.P, args.steps, w.ctx
+    refs, curs, _ = w.align_prep
+    p = w.aligner.params()
+    L = ctx._L
+
+    def stage_counts():
+        return {k: ctx.stage_ms(k)[1] for k in ("project_cur", "project_ref")}
+
+    # (1) align only, identity guess (warm cloud cache; the batch path takes the converter's own index images for the current cloud
+    #     and for the first reference projection)
+    res = (AlignResult * P)()
+    ctx.check(L.pwn_hip_align_batch(ctx.h, C.byref(p), P, refs, curs, None, res))
+    w.barrier(); a = time.perf_counter()
+    for _ in range(steps):
+        ctx.check(L.pwn_hip_align_batch(ctx.h, C.byref(p), P, refs, curs, None, res))
+    w.barrier(); dt = time.perf_counter() - a
+    ctx.set_profiling(True); ctx.check(L.pwn_hip_align_batch(ctx.h, C.byref(p), P, refs, curs, None, res)); sc = stage_counts(); ctx.set_profiling(False)
+    nsub = (P + args.sub_pairs - 1) // args.sub_pairs
+    r = np.frombuffer(res, dtype=api.ALIGN_RESULT_DTYPE, count=P)
+    b = w.bytes_per_pair(r, sc["project_cur"] / nsub, sc["project_ref"] / nsub)
+    out["align_only"] = {"alignments_per_s": P * steps / dt, "ms_per_step": dt / steps * 1e3, "guess": "identity",
+                         "projections_per_pair": (sc["project_cur"] + sc["project_ref"]) / nsub,
+                         "achieved_GBps": float(b["align"].sum()) * steps / dt / 1e9, "frac_of_peak": float(b["align"].sum()) * steps / dt / 1e9 / HBM_PEAK_GBS}
+    # (2) the loop-closure call proper: pwn_hip_match_batch = align with per-pair non-identity guesses + matchClouds' depth-agreement
+    #     score (pwn_matcher_base.cpp:114-119,153-182), acceptance of pwn_closer.cpp:138-141; every projection runs
+    g = closure_guesses(w.seeds)
+    scores = (MatchResult * P)()
+    gp = g.ctypes.data_as(C.c_void_p)
+    ctx.check(L.pwn_hip_match_batch(ctx.h, C.byref(p), P, refs, curs, gp, 50.0, res, scores))
+    w.barrier(); a = time.perf_counter()
+    for _ in range(steps):
+        ctx.check(L.pwn_hip_match_batch(ctx.h, C.byref(p), P, refs, curs, gp, 50.0, res, scores))
+    w.barrier(); dt = time.perf_counter() - a
+    ctx.set_profiling(True); ctx.check(L.pwn_hip_match_batch(ctx.h, C.byref(p), P, refs, curs, gp, 50.0, res, scores)); sc = stage_counts(); ctx.set_profiling(False)
+    r = np.frombuffer(res, dtype=api.ALIGN_RESULT_DTYPE, count=P)
+    b = w.bytes_per_pair(r, sc["project_cur"] / nsub, sc["project_ref"] / nsub)
+    acc = api.PwnCloserAcceptance()
+    accepted = sum(1 for m in scores if acc.accept(dict(image_nonZeros=m.image_non_zeros, image_outliers=m.image_outliers, image_inliers=m.image_inliers)))
+    from g2o_frontend_amd import synth
+    terr = max(float(np.abs(r["T"][i].reshape(4, 4).T[:3, 3] - synth.pair_pose(s)[:3, 3]).max()) for i, s in enumerate(w.seeds))
+    out["closure_match_batch"] = {"alignments_per_s": P * steps / dt, "ms_per_step": dt / steps * 1e3,
+                                  "guess": "true relative pose + seeded error <= 1 cm / 0.5 deg per axis, z translation zeroed (pwn_matcher_base.cpp:114)",
+                                  "projections_per_pair": (sc["project_cur"] + sc["project_ref"]) / nsub, "scores": True,
+                                  "accepted_by_closer_thresholds": accepted, "pairs": P, "max_translation_error_m": terr,
+                                  "achieved_GBps": float(b["align"].sum()) * steps / dt / 1e9,
+                                  "frac_of_peak": float(b["align"].sum()) * steps / dt / 1e9 / HBM_PEAK_GBS}
+    return out
+
+
+def run_tracker(device, frames_mm, poses, scale=1):
+    """BASELINE configs[2]: PwnTracker::processFrame (pwn_tracker/pwn_tracker.cpp:106-215) over a 200-frame VGA stream, matcher scale 1;
+    host float32 frames, uploaded inside the timed loop (the tracker's input is a host image)."""
+    from g2o_frontend_amd import api, synth
+    rows, cols, K = 480, 640, synth.K_VGA
+    _, conv, alig = conf(rows, cols)
+    ctx = api.Context(device, rows, cols, 2)
+    converter, al = build_objects(ctx, rows, cols, K, conv, alig)
+    alproj = api.PinholePointProjector(); alproj.setMinDistance(alig["min_distance"]); alproj.setMaxDistance(alig["max_distance"])
+    al.setProjector(alproj)                          # the tracker re-configures the aligner's projector per frame (pwn_tracker.cpp:122-130)
+    tracker = api.PwnTracker(al, converter); tracker.setScale(scale)
+    Km = np.array([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]], np.float32)
+    I = np.eye(4, dtype=np.float32)
+    frames = [ctx.DepthImage_convert_16UC1_to_32FC1(f) for f in frames_mm]
+    tracker.processFrame(frames[0], I, Km); tracker.processFrame(frames[1], I, Km); tracker.init()      # warm-up
+    t0 = time.perf_counter()
+    for d in frames:
+        tracker.processFrame(d, I, Km)
+    dt = time.perf_counter() - t0
+    true = np.linalg.inv(poses[0]) @ poses[len(frames) - 1]
+    err = float(np.abs(tracker.globalT()[:3, 3] - true[:3, 3]).max())
+    out = {"frames_per_s": len(frames) / dt, "frames": len(frames), "scale": scale, "ms_per_frame": dt / len(frames) * 1e3,
+           "keyframes": tracker.numKeyframes(), "final_translation_error_m": err,
+           "stream": "synth.trajectory_sweep(9): +-28 deg pan with sway, <= 2 cm and <= 1 deg per frame",
+           "input": "host float32 frames (PCIe upload inside the timed loop)"}
+    ctx.close()
+    return out
+
+
+def chi2_match(traces, res):
+    """max relative difference of the GPU's per-iteration chi2 (free-running, this run's headline results) from the CPU oracle's
+    fp64-accumulated chi2 of the same pairs (chi2 parity gate with every throughput number; bar 1e-5 at VGA)"""
+    worst64 = worst32 = worstT = 0.0
+    for t in traces:
+        g = res[t["seed"]]
+        n = int(g["iterations"])
+        for k in range(min(n, len(t["chi2_fp64"]))):
+            worst64 = max(worst64, abs(float(g["chi2"][k]) - t["chi2_fp64"][k]) / max(t["chi2_fp64"][k], 1e-30))
+            worst32 = max(worst32, abs(float(g["chi2"][k]) - t["chi2_fp32_serial"][k]) / max(t["chi2_fp32_serial"][k], 1e-30))
+        worstT = max(worstT, float(np.abs(g["T"].reshape(4, 4).T - np.asarray(t["T"])).max()))
+    return {"pairs": len(traces), "mode": "free-running 10 iterations, GPU vs CPU oracle on the same depth pairs",
+            "max_rel_diff_vs_fp64_accumulated_oracle": worst64, "bar": 1e-5, "ok": bool(worst64 <= 1e-5),
+            "max_rel_diff_vs_reference_fp32_serial_sums": worst32, "max_abs_pose_diff": worstT,
+            "note": "the fp32-serial figure is the distance between two summation orders of the same fp32 terms (tests allow 1e-4 / 5e-3 there)"}
+
+
+# ------------------------------------------------------------------------------------------------ CPU dry run of the N-rank plumbing
+def dry_run_cpu(args, rank, world):
+    """launcher -> ranks -> shard -> records (the real pwn_hip_align_result layout) -> all-gather (gloo) -> assemble, no GPU"""
+    import torch
+    import torch.distributed as dist
+    from g2o_frontend_amd import shard
+    from g2o_frontend_amd.api import ALIGN_RESULT_DTYPE
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    P = args.pairs
+    seeds = list(shard.shard_range(world * P, rank, world))
+    res = np.zeros(P, ALIGN_RESULT_DTYPE)
+    for i, s in enumerate(seeds):      # what pwn_hip_align_batch would have filled in for pair s
+        T = np.eye(4, dtype=np.float32); T[:3, 3] = (s, 2 * s, -s)
+        res["T"][i] = T.T.reshape(-1); res["error"][i] = 0.5 * s; res["inliers"][i] = 1000 + s; res["iterations"][i] = 10
+    rec = torch.from_numpy(shard.pack_results_raw(res, seeds))
+    g = shard.gather_records(rec, world, P)
+    t = torch.tensor([float(rank)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
+    if rank == 0:
+        allrec = shard.assemble(g.numpy(), world * P)
+        ok = all(allrec[p, 12] == p and allrec[p, 13] == 2 * p and allrec[p, 14] == -p and allrec[p, 17] == 1000 + p and allrec[p, 19] == p
+                 for p in range(world * P))
+        print(json.dumps({"dry_run": True, "n_gpus": world, "records": int(allrec.shape[0]), "records_ok": bool(ok), "max_rank_seen": int(t.item()),
+                          "pairs_per_gpu": P}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
-    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
-    rows, cols, P = args.rows, args.cols, args.pairs
-    N = rows * cols
-    K, conv, alig = conf(rows, cols)
-    n_it = alig["outer_iterations"] * alig["inner_iterations"]
-
     if args.cpu_baseline_only:
-        out = cpu_baseline(rows, cols, K, conv, alig, list(range(0, 64)), args.cpu_seconds)
-        try:      # all host cores beside the single-thread figure (bounded: as many pairs per core as ~cpu_seconds/2 of one core's work)
-            per_core = max(1, int(0.5 * args.cpu_seconds * out["value"]))
-            out["all_cores"] = cpu_baseline_all_cores(rows, cols, K, conv, alig, per_core)
-        except Exception as e:      # never let the baseline leg break the benchmark line
-            out["all_cores"] = {"error": str(e)[:200]}
-        print(json.dumps(out))
-        return
-    # CPU baseline first (rank 0 only), in a child process started before anything touches the GPU: the process that
-    # drives the GPU never loads the oracle library
+        return cpu_baseline_child(args)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N`: become the launcher; the ranks are children started before any GPU call (this process makes none)
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a number for a different GPU count", file=sys.stderr)
+        sys.exit(2)
+    if args.dry_run_cpu:
+        return dry_run_cpu(args, rank, world)
+    rows, cols, P = args.rows, args.cols, args.pairs
+    K, conv, alig = conf(rows, cols)
+    extras_on = rank == 0 and world == 1 and not args.no_extras      # the extra lines are single-GPU measurements
+
+    # CPU baseline first (rank 0 at N = 1 only: the other ranks of a multi-GPU run would wait for it), in a child process started
+    # before anything touches the GPU: the process that drives the GPU never loads the oracle library
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # at N = 1 only: the other ranks of a multi-GPU run would wait for it
-        import subprocess
+    traces = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--rows", str(rows), "--cols", str(cols),
-                              "--cpu-seconds", str(args.cpu_seconds)], capture_output=True, text=True, timeout=600)
+                              "--cpu-seconds", str(args.cpu_seconds)], capture_output=True, text=True, timeout=900)
         try:
             cpu = json.loads(out.stdout.strip().splitlines()[-1])
+            traces = cpu.pop("chi2_traces", None)
         except Exception:
             cpu = {"error": (out.stderr or out.stdout)[-300:]}
 
+    # synthetic inputs of this rank's shard (and of the extra lines), rendered on the CPU before the GPU is initialised
+    from g2o_frontend_amd import shard, synth
+    seeds = list(shard.shard_range(world * P, rank, world))          # contiguous shard of the global pair list
+    jobs = [("pair", s, rows, cols, K) for s in seeds]
+    n5 = 0; poses = None
+    if extras_on and not args.no_config5 and (rows, cols) == (480, 640):
+        n5 = 32
+        jobs += [("pair", s, 960, 1280, synth.K_1280) for s in range(n5)]
+    if extras_on and not args.no_tracker and (rows, cols) == (480, 640):
+        poses = synth.trajectory_sweep(9, args.tracker_frames)
+        jobs += [("frame", 9, poses[k].tolist(), 480, 640, synth.K_VGA, k) for k in range(args.tracker_frames)]
+    rendered = render_all(jobs, world)
+    frames_mm = rendered[:P]; frames5 = rendered[P:P + n5]; frames_trk = rendered[P + n5:]
+
     import torch
     import torch.distributed as dist
-    from g2o_frontend_amd import api, shard, synth
     torch.cuda.set_device(local)
     use_dist = world > 1 or os.environ.get("PWN_BENCH_FORCE_DIST") == "1"      # FORCE_DIST: exercise the RCCL path at world size 1
     if use_dist:
@@ -189,183 +595,88 @@ def main():
             sys.stdout.flush()
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
+    n_seen = dist.get_world_size() if use_dist else 1                            # the ranks the process group actually holds
 
-    slots = max(2, args.streams) * max(args.sub_frames, args.sub_pairs, 1)      # room for one sub-batch in flight per stream
-    ctx = api.Context(device=local, max_rows=rows, max_cols=cols, max_batch=slots)
-    ctx.set_subbatch(args.sub_frames, args.sub_pairs)
-    converter, aligner = build_objects(ctx, rows, cols, K, conv, alig)
-
-    # synthetic inputs of this rank's shard, uploaded to HBM (uint16 mm frames)
-    my_pairs = shard.shard_range(world * P, rank, world)          # contiguous shard of the global pair list
-    seeds = list(my_pairs)
-    ref_dev, cur_dev = [], []
-    for s in seeds:
-        ref_mm, cur_mm, _ = synth.make_pair(s, rows, cols, K)
-        ref_dev.append(torch.from_numpy(ref_mm.view(np.int16)).cuda())
-        cur_dev.append(torch.from_numpy(cur_mm.view(np.int16)).cuda())
-    refs = [api.Cloud(ctx, N) for _ in range(P)]
-    curs = [api.Cloud(ctx, N) for _ in range(P)]
-    records = torch.empty((P, shard.RECORD_FLOATS), dtype=torch.float32, device="cuda")
-
-    stage_names = ["u16_to_f32", "unproject", "integral", "integral_rows", "integral_cols", "stats", "project", "corr_linearize", "solve"]
-    stage_ms = {k: 0.0 for k in stage_names}
-    stage_n = {k: 0 for k in stage_names}
-    last = {}
-
-    dbg = os.environ.get("PWN_BENCH_DEBUG")
-    tm = {"convert": 0.0, "align": 0.0, "gather": 0.0}
-
-    conv_prep = converter.batchHandles(refs + curs, ref_dev + cur_dev)       # handle / pointer arrays built once
-    import ctypes as C
-    align_prep = ((C.c_void_p * P)(*[c.h for c in refs]), (C.c_void_p * P)(*[c.h for c in curs]), P)
-    records_host = torch.empty((P, shard.RECORD_FLOATS), dtype=torch.float32).pin_memory()
-
-    def step(profile):
-        t_a = time.perf_counter()
-        converter.computeBatch(refs + curs, ref_dev + cur_dev, raw_scale=0.001, prepared=conv_prep)
-        t_b = time.perf_counter()
-        if profile:
-            for k in stage_names[:6]:
-                ms, n = ctx.stage_ms(k); stage_ms[k] += ms; stage_n[k] += n
-        res = aligner.alignBatch(refs, curs, raw=True, prepared=align_prep)
-        t_c = time.perf_counter()
-        if profile:
-            for k in stage_names[6:]:
-                ms, n = ctx.stage_ms(k); stage_ms[k] += ms; stage_n[k] += n
-        records_host.numpy()[:] = shard.pack_results_raw(res, seeds)
-        records.copy_(records_host, non_blocking=False)
-        last["gathered"] = shard.gather_records(records, world, P, force=use_dist)      # RCCL all-gather: the only collective of the path
-        last["res"] = res
-        if dbg and not profile:
-            tm["convert"] += t_b - t_a; tm["align"] += t_c - t_b; tm["gather"] += time.perf_counter() - t_c
-
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # timed region: the product configuration (two streams, no event instrumentation)
-    ctx.set_concurrency(args.streams)
-    ctx.set_profiling(False)
-    for _ in range(args.warmup):
-        step(False)
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(False)
-    barrier()
-    dt = time.perf_counter() - t0
-    # per-kernel durations: the same K steps again on ONE stream with a hipEvent pair around every kernel stage (on the
-    # library's stream).  With two streams, launches of different sub-batches overlap and a launch's elapsed time is no
-    # longer the kernel's own duration, so the roofline figures come from this serial pass (rocprofv3 summaries in profiles/
-    # are taken the same way: bench.py --streams 1).
-    dt_serial = None
-    if not args.no_profile:
-        ctx.set_concurrency(1)
-        ctx.set_profiling(True)
-        step(False)
-        barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step(True)
-        barrier()
-        dt_serial = time.perf_counter() - t1
-        ctx.set_profiling(False)
-        ctx.set_concurrency(args.streams)
+    w = BatchWorkload(args, local, rows, cols, P, frames_mm, seeds, use_dist, world)
+    dt, dt_serial = w.run(args.steps, args.warmup, profile=not args.no_profile)
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-
-    if dbg and rank == 0:
-        print("host wall per step (ms, timed region + warmup):", {k: round(v / (args.steps + args.warmup) * 1e3, 2) for k, v in tm.items()}, file=sys.stderr)
-    res = last["res"]
+    rep = w.report(args.steps, dt, dt_serial, world)
     if rank == 0:
-        allrec = shard.assemble(last["gathered"].cpu().numpy(), world * P)      # every pair of every rank arrived exactly once
+        allrec = shard.assemble(w.last["gathered"].cpu().numpy(), world * P)      # every pair of every rank arrived exactly once
         assert allrec.shape[0] == world * P
-    # measured counters of SURVEY.md §8(d): M_r, M_c, K_i, C_i -> algorithmic bytes
-    Mr = res["n_reference"].astype(np.float64); Mc = res["n_current"].astype(np.float64)
-    Ks = res["iter_candidates"].sum(1).astype(np.float64); Cs = res["iter_correspondences"].sum(1).astype(np.float64)
-    bytes_convert = 2 * 8.0 * N + 64.0 * (Mr + Mc)                                   # two frames: 8N + 64M each
-    bytes_fused = n_it * 8.0 * N + 72.0 * Ks + 28.0 * Cs                              # per pair, all iterations
-    bytes_project = 16.0 * Mc + 4.0 * N + n_it * (16.0 * Mr + 4.0 * N)
-    bytes_align = bytes_project + bytes_fused + 8.0 * N
-    total_bytes_step = float((bytes_convert + bytes_align).sum())
 
     extra = {}
-    if args.align_only:
-        barrier(); a = time.perf_counter()
-        for _ in range(args.steps):
-            aligner.alignBatch(refs, curs, raw=True, prepared=align_prep)
-        barrier(); extra["align_only_alignments_per_s"] = world * P * args.steps / (time.perf_counter() - a)
     if not args.no_latency and rank == 0:
-        ctx.set_profiling(False)
         lat = []
         for _ in range(5):
             torch.cuda.synchronize(); a = time.perf_counter()
-            converter.computeBatch([refs[0], curs[0]], [ref_dev[0], cur_dev[0]], raw_scale=0.001)
-            aligner.alignBatch([refs[0]], [curs[0]])
+            w.converter.computeBatch([w.refs[0], w.curs[0]], [w.ref_dev[0], w.cur_dev[0]], raw_scale=0.001)
+            w.aligner.alignBatch([w.refs[0]], [w.curs[0]])
             lat.append((time.perf_counter() - a) * 1e3)
         extra["single_pair_latency_ms"] = float(np.median(lat))
-
+        w.step()                                                                   # clouds of all pairs resident again
+    if rank == 0 and traces:
+        extra["chi2_match"] = chi2_match(traces, w.last["res"])
     hbm_read = hbm_copy = None
     if rank == 0:
-        # the bandwidth this box actually delivers, next to the 8 TB/s spec figure (float4 streaming read / copy of 2 GiB)
-        try:
-            hbm_read, hbm_copy = ctx.measure_hbm(1 << 31)
+        try:      # the bandwidth this box actually delivers, next to the 8 TB/s spec figure (float4 streaming read / copy of 2 GiB)
+            hbm_read, hbm_copy = w.ctx.measure_hbm(1 << 31)
         except Exception:
             hbm_read = hbm_copy = None
+    if extras_on:
+        try:
+            extra.update(run_extras_vga(w, args))
+        except Exception as e:
+            extra["extras_error"] = repr(e)[:300]
+    w.close()
+    if extras_on and n5:
+        try:
+            a5 = argparse.Namespace(**vars(args)); a5.sub_frames = min(args.sub_frames, 2 * n5); a5.sub_pairs = min(args.sub_pairs, n5)
+            w5 = BatchWorkload(a5, local, 960, 1280, n5, frames5, list(range(n5)), False, 1)
+            s5 = max(2, min(args.steps, 5))
+            d5, d5s = w5.run(s5, 1, profile=True)
+            r5 = w5.report(s5, d5, d5s, 1)
+            extra["config5_1280x960"] = {"alignments_per_s": r5["value"], "ms_per_step": r5["ms_per_step"], "pairs_per_gpu": n5, "steps": s5,
+                                         "workload": "BASELINE configs[4] shard: 32 pairs of 1280x960 (256 over 8 GPUs), convert 2 frames + align",
+                                         "roofline": r5["roofline"], "path_roofline": r5["path_roofline"], "stage_ms_per_step": r5["stage_ms_per_step"]}
+            w5.close()
+        except Exception as e:
+            extra["config5_error"] = repr(e)[:300]
+    if extras_on and poses is not None:
+        try:
+            extra["tracker_config2"] = run_tracker(local, frames_trk, poses)
+        except Exception as e:
+            extra["tracker_error"] = repr(e)[:300]
+
     if rank == 0:
-        value = world * P * args.steps / dt
-        launches = max(stage_n["corr_linearize"], 1)
-        dom = max(stage_names, key=lambda k: stage_ms[k])
-        # dominant kernel: the fused correspondence+linearize pass (one launch = one iteration of one sub-batch)
-        k_ms = stage_ms["corr_linearize"] / launches
-        k_bytes = float(bytes_fused.sum()) * args.steps / launches
-        achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tfile):
-            try:
-                # measured per pair-iteration by the PMC passes (profiles/), scaled to the pairs one launch of this run covers
-                tj = json.load(open(tfile))
-                # measured at VGA; every term of the kernel's traffic is per pixel / per point, so other frame sizes scale with the pixel count
-                traffic = tj.get("k_corr_linearize_bytes_per_pair_iteration") * (N / tj.get("pixels_per_frame", 307200)) * (P * n_it * args.steps / launches)
-            except Exception:
-                traffic = None
+        rep["roofline"]["measured_hbm_read_GBps"] = hbm_read; rep["roofline"]["measured_hbm_copy_GBps"] = hbm_copy
+        if "chi2_match" in extra:      # the parity gate travels with the number (flat, so that summaries of the line keep it)
+            rep["roofline"]["chi2_max_rel_diff_vs_cpu"] = extra["chi2_match"]["max_rel_diff_vs_fp64_accumulated_oracle"]
         out = {
-            "metric": "depth-pair alignments/sec (640x480, 10 GN iters)", "value": value, "unit": "alignments/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+            "metric": "depth-pair alignments/sec (640x480, 10 GN iters)", "value": rep["value"], "unit": "alignments/s",
+            "n_gpus": n_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": rep["ms_per_step"],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"loop-closure batch: {P} independent {cols}x{rows} depth pairs per GPU "
                                    f"(u16 mm frames resident in HBM; per pair: convert 2 frames + Aligner::align, "
                                    f"{alig['outer_iterations']}x{alig['inner_iterations']} GN iterations); BASELINE configs[3] shard",
                        "pairs_per_gpu": P, "rows": rows, "cols": cols, "sub_frames": args.sub_frames, "sub_pairs": args.sub_pairs,
                        "streams": args.streams,
-                       "parallelism": f"independent pairs sharded over {world} GPU(s), RCCL all-gather of poses only"},
-            "roofline": {"bound": "hbm", "kernel": "k_corr_linearize", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_launch_algorithmic": k_bytes, "avg_launch_ms": k_ms, "launches": stage_n["corr_linearize"],
-                         "dominant_by_time": dom,
-                         "measured_hbm_GBps": {"read": hbm_read, "copy": hbm_copy},    # this box, float4 streaming kernels over 2 GiB; not frac's denominator
-                         "traffic_GBps": (traffic / (k_ms * 1e-3) / 1e9) if (traffic and k_ms > 0) else None,
-                         "measured_in": "serial profiled pass of the same K steps (one stream, hipEvent pair per kernel stage); "
-                                        "the timed region runs two streams without instrumentation",
-                         "serial_pass_alignments_per_s": (world * P * args.steps / dt_serial) if dt_serial else None},
+                       "parallelism": f"independent pairs sharded over {n_seen} GPU(s), RCCL all-gather of result records only"},
+            "roofline": rep["roofline"],
             "cpu_baseline": cpu,
-            "path_roofline": {"algorithmic_bytes_per_pair": total_bytes_step / P, "achieved_GBps": total_bytes_step * args.steps / dt / 1e9,
-                              "frac_of_peak": total_bytes_step * args.steps / dt / 1e9 / HBM_PEAK_GBS},
-            "stage_ms_per_step": {k: stage_ms[k] / args.steps for k in stage_names},
-            "stage_launches_per_step": {k: stage_n[k] / args.steps for k in stage_names},
-            "counters_mean": {"M_ref": float(Mr.mean()), "M_cur": float(Mc.mean()), "K_sum": float(Ks.mean()), "C_sum": float(Cs.mean()),
-                              "chi2_final": float(res["error"].mean()), "inliers_final": float(res["inliers"].mean())},
+            "path_roofline": rep["path_roofline"],
+            "stage_ms_per_step": rep["stage_ms_per_step"],
+            "stage_launches_per_step": rep["stage_launches_per_step"],
+            "counters_mean": rep["counters_mean"],
         }
         out.update(extra)
         print(json.dumps(out))
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
 
 
 if __name__ == "__main__":

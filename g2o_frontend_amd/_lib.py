@@ -100,6 +100,7 @@ PROTOTYPES = {
     "pwn_hip_align_images": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "pwn_hip_align_batch": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP]),
     "pwn_hip_align_with_priors": (_I, [_VP, _VP, _VP, _VP, _I, _VP, _VP]),
+    "pwn_hip_align_with_priors_ex": (_I, [_VP, _VP, _VP, _VP, _I, _VP, _VP, _VP]),
     "pwn_hip_align_batch_ex": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _F, _VP, _VP]),
     "pwn_hip_compute_statistics": (None, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "pwn_hip_match_score": (_I, [_VP, _F, _VP]),

@@ -147,8 +147,9 @@ class Cloud:
 
     def __del__(self):
         try:
-            if getattr(self, "h", None) and self.ctx.h:
-                self.ctx._L.pwn_hip_cloud_destroy(self.ctx.h, self.h)
+            if getattr(self, "h", None):
+                # a cloud that outlives its context is freed outright (pwn_hip_cloud_destroy(NULL, h)); ctx_destroy only frees pooled clouds
+                self.ctx._L.pwn_hip_cloud_destroy(self.ctx.h if self.ctx.h else None, self.h)
             self.h = None
         except Exception:
             pass
@@ -602,23 +603,26 @@ class Aligner:
         assert self._referenceCloud is not None and self._currentCloud is not None, "Aligner: missing cloud"
         p = self.params()
         r = AlignResult()
-        if statistics:
-            q = AlignStatistics()
+        q = AlignStatistics() if statistics else None
+        if self._priors:
+            # priors change the normal equations of every iteration (aligner.cpp:96-108); _computeStatistics still runs afterwards (:127)
+            arr = (Prior * len(self._priors))()
+            for a, (kind, mean, reft, info) in zip(arr, self._priors):
+                a.kind = kind; _set(a.mean, mean, 4); _set(a.reference_transform, reft, 4); _set(a.information, info, 6)
+            self.ctx.check(self.ctx._L.pwn_hip_align_with_priors_ex(self.ctx.h, C.byref(p), self._referenceCloud.h, self._currentCloud.h, len(arr), arr,
+                                                                    C.byref(r), C.byref(q) if statistics else None))
+        elif statistics:
             refs = (C.c_void_p * 1)(self._referenceCloud.h); curs = (C.c_void_p * 1)(self._currentCloud.h)
             self.ctx.check(self.ctx._L.pwn_hip_align_batch_ex(self.ctx.h, C.byref(p), 1, refs, curs, None, C.byref(r), 0.0, None, C.byref(q)))
+        else:
+            self.ctx.check(self.ctx._L.pwn_hip_align(self.ctx.h, C.byref(p), self._referenceCloud.h, self._currentCloud.h, C.byref(r)))
+        if statistics:
             self._omega = _from_colmajor(q.omega, 6); self._mean = np.array(list(q.mean), np.float32)
             self._translationalEigenRatio, self._rotationalEigenRatio = q.translational_eigen_ratio, q.rotational_eigen_ratio
             self._statistics = dict(mean=self._mean, omega=self._omega, translationalEigenRatio=q.translational_eigen_ratio,
                                     rotationalEigenRatio=q.rotational_eigen_ratio, H=_from_colmajor(q.H, 6), b=np.array(list(q.b), np.float32),
                                     error=q.error, inliers=q.inliers)
             self._linearizer._H, self._linearizer._b = self._statistics["H"], self._statistics["b"]
-        elif self._priors:
-            arr = (Prior * len(self._priors))()
-            for a, (kind, mean, reft, info) in zip(arr, self._priors):
-                a.kind = kind; _set(a.mean, mean, 4); _set(a.reference_transform, reft, 4); _set(a.information, info, 6)
-            self.ctx.check(self.ctx._L.pwn_hip_align_with_priors(self.ctx.h, C.byref(p), self._referenceCloud.h, self._currentCloud.h, len(arr), arr, C.byref(r)))
-        else:
-            self.ctx.check(self.ctx._L.pwn_hip_align(self.ctx.h, C.byref(p), self._referenceCloud.h, self._currentCloud.h, C.byref(r)))
         self._result = self._unpack(r)
         self._T, self._error, self._inliers = self._result["T"], r.error, r.inliers
         self._totalTime = r.total_time_ms

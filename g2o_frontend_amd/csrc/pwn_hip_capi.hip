@@ -251,7 +251,10 @@ AlignParams make_align_params(const pwn_hip_aligner_params* p) {
 
 int check_image(pwn_hip_ctx* ctx, int rows, int cols) {
   if (rows <= 0 || cols <= 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "image has zero size");
-  if ((size_t)rows * cols > ctx->N || rows > std::max(ctx->max_rows, ctx->max_cols))
+  // both sides are bounded: the hand-over / offset workspaces (rowoff_slot, carry_slot in pwn_hip_ctx_create) are sized for
+  // rows, cols <= max(max_rows, max_cols); a wide, short image with rows*cols <= N would overrun them
+  const int M = std::max(ctx->max_rows, ctx->max_cols);
+  if ((size_t)rows * cols > ctx->N || rows > M || cols > M)
     return fail(ctx, PWN_HIP_ERR_CAPACITY, "image larger than the context was created for");
   return PWN_HIP_OK;
 }
@@ -1116,6 +1119,8 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
   const bool rolling = (unsigned long long)nsub * tagsPerSub <= kZTag0;
   unsigned tagBase = kZTag0;
   if (rolling && nsub > 0) { if (int rc = take_tags(ctx, nsub * tagsPerSub, &tagBase)) return rc; }
+  // fixed tags leave words in the buffers that could beat (smaller tag wins) the tags a later rolling call draws: make that call clear first
+  if (!rolling) ctx->ztag_next = 0;
   unsigned tag0 = tagBase, lastRefTag = tag0 - (tagsPerSub - 1);
   if (int rc = plan_fork(ctx, plan)) return rc;
   for (int base = 0, kk = 0; base < n; base += sub, ++kk) {
@@ -1133,13 +1138,13 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
     if (s0 == 0 || kk == 0) { tag0 = subTag0; lastRefTag = subTag0 - (tagsPerSub - 1); }     // slot 0: what pwn_hip_align_images / pwn_hip_match_score read
     const unsigned subLastRefTag = subTag0 - (tagsPerSub - 1);
     if (!sub_own[kk]) {
-      StageTimer t(ctx, "project", st);
+      StageTimer t(ctx, "project_cur", st);
       hipLaunchKernelGGL(k_project, dim3((maxcap_cur + 256 * kProjectPointsPerThread - 1) / (256 * kProjectPointsPerThread), m), dim3(256), 0, st, pr, ap, 1, subTag0);
       hipLaunchKernelGGL(k_resolve_cur, dim3(std::min((N + 255) / 256, 1024), m), dim3(256), 0, st, pr, N, subTag0); }
     for (int i = 0; i < p->outer_iterations; ++i) {
       const unsigned tag = subTag0 - (unsigned)i;      // epoch of this outer iteration's reference projection
       const int ownRef = (i == 0 && sub_ownref[kk]) ? 1 : 0;
-      if (!ownRef) { StageTimer t(ctx, "project", st);
+      if (!ownRef) { StageTimer t(ctx, "project_ref", st);
         hipLaunchKernelGGL(k_project, dim3((maxcap_ref + 256 * kProjectPointsPerThread - 1) / (256 * kProjectPointsPerThread), m), dim3(256), 0, st, pr, ap, 0, tag); }
       for (int k = 0; k < p->inner_iterations; ++k) {
         const bool lastInner = (k == p->inner_iterations - 1);
@@ -1212,7 +1217,15 @@ int pwn_hip_match_batch(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n
 }
 int pwn_hip_align_with_priors(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, const pwn_hip_cloud* ref, const pwn_hip_cloud* cur, int n_priors,
                               const pwn_hip_prior* priors, pwn_hip_align_result* result) {
-  if (n_priors <= 0) return pwn_hip_align(ctx, p, ref, cur, result);
+  return pwn_hip_align_with_priors_ex(ctx, p, ref, cur, n_priors, priors, result, nullptr);
+}
+int pwn_hip_align_with_priors_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, const pwn_hip_cloud* ref, const pwn_hip_cloud* cur, int n_priors,
+                                 const pwn_hip_prior* priors, pwn_hip_align_result* result, pwn_hip_align_statistics* statistics) {
+  if (n_priors <= 0) {
+    pwn_hip_cloud* r[1] = { const_cast<pwn_hip_cloud*>(ref) };
+    pwn_hip_cloud* c[1] = { const_cast<pwn_hip_cloud*>(cur) };
+    return align_batch_impl(ctx, p, 1, r, c, nullptr, result, nullptr, 0.f, statistics);
+  }
   if (!ctx || !p || !ref || !cur || !priors || !result) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if (int rc = check_image(ctx, p->rows, p->cols)) return rc;
   if (p->min_distance < 0.f) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "min_distance must be >= 0");
@@ -1240,14 +1253,16 @@ int pwn_hip_align_with_priors(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p,
   HIPCHK(ctx, hipEventRecord(ctx->t0, st), PWN_HIP_ERR_LAUNCH);
   HIPCHK(ctx, hipMemcpyAsync(ctx->pairs_dev, ctx->pairs_host, sizeof(PairDesc), hipMemcpyHostToDevice, st), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipMemcpyAsync(ctx->state_ws, &hs, sizeof(PairState), hipMemcpyHostToDevice, st), PWN_HIP_ERR_COPY);
-  HIPCHK(ctx, hipMemsetAsync(ctx->zref_ws, 0xFF, (size_t)ctx->N * 8, st), PWN_HIP_ERR_COPY);
-  HIPCHK(ctx, hipMemsetAsync(ctx->zcur_ws, 0xFF, (size_t)ctx->N * 8, st), PWN_HIP_ERR_COPY);
-  hipLaunchKernelGGL(k_project, dim3((cur->d.capacity + 256 * kProjectPointsPerThread - 1) / (256 * kProjectPointsPerThread), 1), dim3(256), 0, st, ctx->pairs_dev, ap, 1, kZTag0);
-  hipLaunchKernelGGL(k_resolve_cur, dim3(std::min((N + 255) / 256, 1024), 1), dim3(256), 0, st, ctx->pairs_dev, N, kZTag0);
+  // z-buffer tags come from the context's running supply like the batch path's (a smaller tag wins atomicMin: fixed tags would
+  // leave words behind that beat a later call's)
+  unsigned tag0 = kZTag0;
+  if (int rc = take_tags(ctx, (unsigned)std::max(1, p->outer_iterations), &tag0)) return rc;
+  hipLaunchKernelGGL(k_project, dim3((cur->d.capacity + 256 * kProjectPointsPerThread - 1) / (256 * kProjectPointsPerThread), 1), dim3(256), 0, st, ctx->pairs_dev, ap, 1, tag0);
+  hipLaunchKernelGGL(k_resolve_cur, dim3(std::min((N + 255) / 256, 1024), 1), dim3(256), 0, st, ctx->pairs_dev, N, tag0);
   std::memset(result, 0, sizeof(*result));
   int it = 0;
   for (int i = 0; i < p->outer_iterations; ++i) {
-    const unsigned tag = kZTag0 - (unsigned)i;
+    const unsigned tag = tag0 - (unsigned)i;
     set_last_row(T);                                                                 // aligner.cpp:72
     hs.T = T; hs.invTcorr = iso_inverse(T);
     projector_matrices(ap.K, iso_mul(T, ap.refOffset), hs.KRt, iKRt, iK);            // :73
@@ -1278,6 +1293,26 @@ int pwn_hip_align_with_priors(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p,
     T = iso_inverse(invT);                                                           // :115-117
     float v[6]; t2v(T, v); T = v2t(v); set_last_row(T);
   }
+  const unsigned lastRefTag = tag0 - (unsigned)std::max(0, p->outer_iterations - 1);
+  if (statistics) {
+    // Aligner::_computeStatistics (aligner.cpp:127,152-199) runs after the loop whether or not priors exist: one more
+    // Linearizer::update at the final transform on the finder's last correspondences, H + I without the prior terms (:168-170)
+    std::memset(statistics, 0, sizeof(*statistics));
+    if (p->outer_iterations > 0) {
+      hs.invTcorrPrev = hs.invTcorr;
+      hs.invT = iso_inverse(T); set_last_row(hs.invT);                                // :165-167
+      HIPCHK(ctx, hipMemcpyAsync(ctx->state_ws, &hs, sizeof(PairState), hipMemcpyHostToDevice, st), PWN_HIP_ERR_COPY);
+      launch_corr_linearize<false, true>(ctx, nb, 1, st, ctx->pairs_dev, ap, lastRefTag, 1, 0);
+      hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, st, ctx->pairs_dev, nb, ctx->stats_dev);
+      HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
+      HIPCHK(ctx, hipMemcpyAsync(ctx->stats_host, ctx->stats_dev, sizeof(SolveOut), hipMemcpyDeviceToHost, st), PWN_HIP_ERR_COPY);
+      HIPCHK(ctx, hipStreamSynchronize(st), PWN_HIP_ERR_LAUNCH);
+      const SolveOut& so = ctx->stats_host[0];
+      std::memcpy(statistics->H, so.H, sizeof(statistics->H)); std::memcpy(statistics->b, so.b, sizeof(statistics->b));
+      statistics->error = so.chi2; statistics->inliers = so.inliers;
+      compute_statistics(so.H, T, statistics->mean, statistics->omega, &statistics->translational_eigen_ratio, &statistics->rotational_eigen_ratio);
+    }
+  }
   HIPCHK(ctx, hipEventRecord(ctx->t1, st), PWN_HIP_ERR_LAUNCH);
   HIPCHK(ctx, hipEventSynchronize(ctx->t1), PWN_HIP_ERR_LAUNCH);
   float ms = 0.f; (void)hipEventElapsedTime(&ms, ctx->t0, ctx->t1);
@@ -1286,7 +1321,7 @@ int pwn_hip_align_with_priors(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p,
   if (it > 0) { result->error = result->chi2[it - 1]; result->inliers = result->iter_inliers[it - 1]; }
   result->n_reference = ref->n_host; result->n_current = cur->n_host;
   ctx->img_rows = p->rows; ctx->img_cols = p->cols; ctx->img_valid = true;
-  ctx->img_ref_tag = kZTag0 - (unsigned)std::max(0, p->outer_iterations - 1); ctx->img_cur_tag = kZTag0;
+  ctx->img_ref_tag = lastRefTag; ctx->img_cur_tag = tag0;
   return PWN_HIP_OK;
 }
 int pwn_hip_align_batch_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* refs, pwn_hip_cloud* const* curs,

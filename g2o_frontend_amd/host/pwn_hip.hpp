@@ -426,17 +426,20 @@ class Aligner {
   virtual void align(bool fetchImages = false) {
     if (!_referenceCloud || !_currentCloud) throw Error(PWN_HIP_ERR_INVALID_ARGUMENT, "Aligner: missing cloud");
     const pwn_hip_aligner_params p = params();
-    if (!_priors.empty()) {                                                       // aligner.cpp:96-108: host-driven loop with the prior terms
-      _ctx->check(pwn_hip_align_with_priors(_ctx->handle(), &p, _referenceCloud->handle(), _currentCloud->handle(), (int)_priors.size(), _priors.data(), &_result));
+    pwn_hip_align_statistics q;
+    if (!_priors.empty()) {                                                       // aligner.cpp:96-108: host-driven loop with the prior terms;
+      _ctx->check(pwn_hip_align_with_priors_ex(_ctx->handle(), &p, _referenceCloud->handle(), _currentCloud->handle(), (int)_priors.size(), _priors.data(),
+                                               &_result, _computeStatistics ? &q : nullptr));     // _computeStatistics runs after it as always (:127)
     } else if (_computeStatistics) {
       pwn_hip_cloud* r = _referenceCloud->handle(); pwn_hip_cloud* c = _currentCloud->handle();
-      pwn_hip_align_statistics q;
       _ctx->check(pwn_hip_align_batch_ex(_ctx->handle(), &p, 1, &r, &c, nullptr, &_result, 0.f, nullptr, &q));
+    } else {
+      _ctx->check(pwn_hip_align(_ctx->handle(), &p, _referenceCloud->handle(), _currentCloud->handle(), &_result));
+    }
+    if (_computeStatistics) {
       std::memcpy(_omega.m, q.omega, sizeof(q.omega)); std::memcpy(_mean.v, q.mean, sizeof(q.mean));
       _translationalEigenRatio = q.translational_eigen_ratio; _rotationalEigenRatio = q.rotational_eigen_ratio;
       std::memcpy(_linearizer->_H.m, q.H, sizeof(q.H)); std::memcpy(_linearizer->_b.v, q.b, sizeof(q.b));
-    } else {
-      _ctx->check(pwn_hip_align(_ctx->handle(), &p, _referenceCloud->handle(), _currentCloud->handle(), &_result));
     }
     _T = Isometry3f(_result.T); _error = _result.error; _inliers = _result.inliers; _totalTime = _result.total_time_ms;
     _linearizer->_error = _error; _linearizer->_inliers = _inliers;

@@ -161,3 +161,34 @@ def K_matrix_colmajor(K) -> np.ndarray:
     """(fx,fy,cx,cy) -> column-major float32[9] camera matrix."""
     fx, fy, cx, cy = K
     return np.array([fx, 0, 0, 0, fy, 0, cx, cy, 1], dtype=np.float32)
+
+
+def trajectory_sweep(seed: int, n_frames: int, yaw_deg: float = 30.0, t_step: float = 0.02, r_step_deg: float = 1.0):
+    """Smooth seeded trajectory for BASELINE configs[2] that makes PwnTracker switch key-clouds (pwn_tracker/pwn_tracker.cpp:164-185):
+    the camera pans left and right by +-yaw_deg (one full period over the stream) while swaying a few centimetres, so the overlap with the
+    key-cloud falls below the new-frame fraction several times.  Per-frame motion stays <= t_step metres and <= r_step_deg degrees
+    (SURVEY.md §8(d) config 3); returned poses are camera-to-world, pose[0] = identity."""
+    u = _uniform(seed, 4, 8)
+    n = max(int(n_frames), 2)
+    A = np.deg2rad(yaw_deg)
+    w = 2.0 * np.pi / n
+    # the yaw rate A*w and the sway rate stay inside the per-frame limits whatever n is
+    A = min(A, 0.9 * np.deg2rad(r_step_deg) / w)
+    amp_t = min(0.25, 0.45 * t_step / w)
+    poses = []
+    for k in range(n_frames):
+        ph = w * k
+        yaw = A * np.sin(ph)
+        pitch = np.deg2rad(1.5) * np.sin(2.0 * ph + 6.28 * u[0]) - np.deg2rad(1.5) * np.sin(6.28 * u[0])
+        x = amp_t * (np.sin(ph + 6.28 * u[1]) - np.sin(6.28 * u[1]))
+        z = 0.6 * amp_t * (np.sin(2.0 * ph + 6.28 * u[2]) - np.sin(6.28 * u[2]))
+        y = 0.2 * amp_t * (np.sin(ph + 6.28 * u[3]) - np.sin(6.28 * u[3]))
+        cy_, sy_ = np.cos(yaw), np.sin(yaw)
+        cp_, sp_ = np.cos(pitch), np.sin(pitch)
+        Ry = np.array([[cy_, 0, sy_], [0, 1, 0], [-sy_, 0, cy_]])
+        Rx = np.array([[1, 0, 0], [0, cp_, -sp_], [0, sp_, cp_]])
+        T = np.eye(4)
+        T[:3, :3] = Ry @ Rx
+        T[:3, 3] = (x, y, z)
+        poses.append(T)
+    return poses

@@ -268,6 +268,12 @@ int pwn_hip_align_batch_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, in
  * n_priors = 0 is the device-resident loop of pwn_hip_align. */
 int pwn_hip_align_with_priors(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, const pwn_hip_cloud* reference,
                               const pwn_hip_cloud* current, int n_priors, const pwn_hip_prior* priors, pwn_hip_align_result* result);
+/* The same with Aligner::_computeStatistics (aligner.cpp:127): the reference runs it after every align(), priors or not, on
+ * Linearizer::H() + I at the final transform -- the prior terms are not part of that H (aligner.cpp:165-170).  statistics may
+ * be NULL (= pwn_hip_align_with_priors); n_priors = 0 is pwn_hip_align_batch_ex for one pair. */
+int pwn_hip_align_with_priors_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, const pwn_hip_cloud* reference,
+                                 const pwn_hip_cloud* current, int n_priors, const pwn_hip_prior* priors, pwn_hip_align_result* result,
+                                 pwn_hip_align_statistics* statistics);
 /* the host-side part alone: H = Linearizer::H() at the final transform, T = Aligner::T() */
 void pwn_hip_compute_statistics(const float H[36], const float T[16], float mean[6], float omega[36],
                                 float* translational_eigen_ratio, float* rotational_eigen_ratio);
@@ -313,7 +319,8 @@ void pwn_hip_t2v(const float T[16], float v[6]);
  * function k_solve_update runs on the device */
 void pwn_hip_ldlt_solve6(const float H[36], const float b[6], float x[6]);
 /* per-kernel device time (ms) of the stages of the last batch/single call, for bench.py:
- * names: "unproject","integral_rows","integral_cols","stats","project","corr_linearize","solve" */
+ * names: "unproject","integral","integral_rows","integral_cols","stats","project_cur","project_ref","corr_linearize","solve",
+ * "statistics","match_score" ("project": the stand-alone pwn_hip_project).  launches = timed launch groups (one per sub-batch). */
 int pwn_hip_last_stage_ms(pwn_hip_ctx* ctx, const char* stage, float* ms, int* launches);
 /* what this GPU's HBM delivers, for the roofline report (SURVEY 8(d) asks for the measured figure next to the 8 TB/s spec):
  * float4 streaming read and device-to-device copy of `bytes` (use >= 1 GiB: the Infinity Cache holds 256 MiB), best of 5,

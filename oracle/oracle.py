@@ -24,6 +24,36 @@ def build(force: bool = False) -> str:
     return _LIB_PATH
 
 
+def _cpu_tag() -> str:
+    """identifies the host CPU a -march=native build belongs to (model name + instruction-set flags)"""
+    import hashlib
+    model, flags = "unknown", ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("flags") and not flags:
+                flags = line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return hashlib.sha1((model + "|" + flags).encode()).hexdigest()[:12]
+
+
+def build_fast(force: bool = False) -> str:
+    """The timed CPU baseline's build of the same source: -O3 -march=native (still -ffp-contract=off, no fast-math: same results).
+    -march=native binds the binary to the CPU it was compiled on, so it is built on the machine that runs it (the GPU box's host),
+    into oracle/_fast/<cpu tag>/ (BASELINE.md section 3)."""
+    out_dir = os.path.join(_HERE, "_fast", _cpu_tag())
+    out = os.path.join(out_dir, "libpwn_oracle.so")
+    src = [os.path.join(_HERE, f) for f in ("pwn_oracle.cpp", "pwn_oracle.h")]
+    stale = (not os.path.exists(out)) or any(os.path.getmtime(s) > os.path.getmtime(out) for s in src)
+    if force or stale:
+        os.makedirs(out_dir, exist_ok=True)
+        subprocess.check_call([os.environ.get("CXX", "g++"), "-O3", "-march=native", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math",
+                               "-fopenmp", "-shared", "-o", out, src[0]])
+    return out
+
+
 class ConverterParams(C.Structure):
     _fields_ = [("K", C.c_float * 9), ("min_distance", C.c_float), ("max_distance", C.c_float),
                 ("world_radius", C.c_float), ("min_image_radius", C.c_int), ("max_image_radius", C.c_int),
@@ -56,8 +86,9 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        build()
-        L = C.CDLL(_LIB_PATH)
+        # PWN_ORACLE_VARIANT=fast (bench.py's cpu_baseline child only): the -O3 -march=native build of the same source
+        path = build_fast() if os.environ.get("PWN_ORACLE_VARIANT") == "fast" else build()
+        L = C.CDLL(path)
         L.orc_cloud_create.restype = C.c_void_p
         L.orc_cloud_destroy.argtypes = [C.c_void_p]
         L.orc_cloud_size.argtypes = [C.c_void_p]
@@ -85,6 +116,7 @@ def lib():
         L.orc_ldlt_solve6.argtypes = [C.c_void_p] * 3
         L.orc_num_threads.restype = C.c_int
         L.orc_set_num_threads.argtypes = [C.c_int]
+        L.orc_set_parallel_align.argtypes = [C.c_int]
         L.orc_set_trig_mode.argtypes = [C.c_int]
         L.orc_trig_eval.argtypes = [C.c_int, C.c_int] + [C.c_void_p] * 5
         L.orc_add_prior.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
@@ -468,3 +500,9 @@ def trig_eval(mode, y, x):
 
 def set_num_threads(n):
     lib().orc_set_num_threads(int(n))
+
+
+def set_parallel_align(on: bool):
+    """CorrespondenceFinder::compute / Linearizer::update over the OpenMP threads with the reference's partition minus its remainder
+    dropping (correspondencefinder.cpp:38-51, linearizer.cpp:32-39).  Off (default) = canonical one-thread loops.  Timed baseline only."""
+    lib().orc_set_parallel_align(1 if on else 0)

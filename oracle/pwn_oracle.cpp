@@ -525,6 +525,11 @@ struct orc_cloud {
 
 namespace {
 
+/* 0 (default): CorrespondenceFinder::compute and Linearizer::update run their canonical one-thread loops whatever the OpenMP thread
+ * count is (parity tests, golden vectors).  1: they use the reference's own thread partition without its remainder dropping -- the
+ * timed CPU baseline of bench.py only (orc_set_parallel_align). */
+int g_parallel_align = 0;
+
 /* ----------------------------------------- pointaccumulator.h / pointintegralimage.cpp ------ */
 /* 10 unique channels of (sum, squaredSum): x y z n xx xy xz yy yz zz.  The other 10 entries of the
  * reference's 4+16 floats are bitwise duplicates (p_i*p_j commutes, x*1 == x). */
@@ -693,48 +698,83 @@ void project_points(const Projector& pr, int rows, int cols, const V4* points, i
   }
 }
 
+/* acceptance tests of one pixel (correspondencefinder.cpp:60-99); returns 1 and the pair when accepted */
+inline bool correspondence_pixel(const orc_aligner_params* P, const orc_cloud* ref, const orc_cloud* cur, const M4& T, int ri, int ci,
+                                 float squaredThreshold, float minCurvatureRatio, float maxCurvatureRatio) {
+  const V4& cn = cur->normals[ci]; const V4& rn0 = ref->normals[ri];
+  const V4& cp = cur->points[ci];  const V4& rp0 = ref->points[ri];
+  if (dot4(cn, cn) == 0.0f || dot4(rn0, rn0) == 0.0f) return false;
+  V4 rp = iso_mul_v4(T, rp0); rp.v[3] = 1.0f;
+  V4 rn = iso_mul_v4(T, rn0); rn.v[3] = 0.0f;
+  if (dot4(cn, rn) < P->inlier_normal_angular_threshold) return false;
+  V4 dd = { { cp.v[0] - rp.v[0], cp.v[1] - rp.v[1], cp.v[2] - rp.v[2], cp.v[3] - rp.v[3] } };
+  if (dot4(dd, dd) > squaredThreshold) return false;
+  float rc = ref->stats[ri].curvature(), cc = cur->stats[ci].curvature();
+  if (rc < P->flat_curvature_threshold) rc = P->flat_curvature_threshold;
+  if (cc < P->flat_curvature_threshold) cc = P->flat_curvature_threshold;
+  const float ratio = (float)(((double)rc + 1e-5) / ((double)cc + 1e-5));
+  if (ratio < minCurvatureRatio || ratio > maxCurvatureRatio) return false;
+  return true;
+}
 int correspondences(const orc_aligner_params* P, const orc_cloud* ref, const orc_cloud* cur,
                     const int* refIndex, const int* curIndex, M4 T, int* corr, int* Kout) {
-  /* correspondencefinder.cpp:20-118, numThreads == 1 */
+  /* correspondencefinder.cpp:20-118.  One thread: the canonical loop.  More threads (the timed CPU baseline only): the reference's
+   * own scheme -- every thread takes a contiguous block of rows and fills its own segment, the segments are concatenated in thread
+   * order (:38-51,110-114) -- except that the blocks cover ALL rows (the reference drops the trailing rows % numThreads rows), so the
+   * list is the one-thread list whatever the thread count. */
   force_last_row(T);
   const float squaredThreshold = P->inlier_distance_threshold * P->inlier_distance_threshold;
   const float minCurvatureRatio = 1.0f / P->inlier_curvature_ratio_threshold;
   const float maxCurvatureRatio = P->inlier_curvature_ratio_threshold;
-  int C = 0, K = 0;
   const int rows = P->rows, cols = P->cols;
-  for (int r = 0; r < rows; ++r)
-    for (int c = 0; c < cols; ++c) {
-      const int ri = refIndex[(size_t)r * cols + c], ci = curIndex[(size_t)r * cols + c];
-      if (ri < 0 || ci < 0) continue;
-      ++K;
-      const V4& cn = cur->normals[ci]; const V4& rn0 = ref->normals[ri];
-      const V4& cp = cur->points[ci];  const V4& rp0 = ref->points[ri];
-      if (dot4(cn, cn) == 0.0f || dot4(rn0, rn0) == 0.0f) continue;
-      V4 rp = iso_mul_v4(T, rp0); rp.v[3] = 1.0f;
-      V4 rn = iso_mul_v4(T, rn0); rn.v[3] = 0.0f;
-      if (dot4(cn, rn) < P->inlier_normal_angular_threshold) continue;
-      V4 dd = { { cp.v[0] - rp.v[0], cp.v[1] - rp.v[1], cp.v[2] - rp.v[2], cp.v[3] - rp.v[3] } };
-      if (dot4(dd, dd) > squaredThreshold) continue;
-      float rc = ref->stats[ri].curvature(), cc = cur->stats[ci].curvature();
-      if (rc < P->flat_curvature_threshold) rc = P->flat_curvature_threshold;
-      if (cc < P->flat_curvature_threshold) cc = P->flat_curvature_threshold;
-      const float ratio = (float)(((double)rc + 1e-5) / ((double)cc + 1e-5));
-      if (ratio < minCurvatureRatio || ratio > maxCurvatureRatio) continue;
-      corr[2 * C] = ri; corr[2 * C + 1] = ci; ++C;
-    }
+  const int nt = g_parallel_align ? std::max(1, std::min(omp_get_max_threads(), rows)) : 1;
+  if (nt == 1) {
+    int C = 0, K = 0;
+    for (int r = 0; r < rows; ++r)
+      for (int c = 0; c < cols; ++c) {
+        const int ri = refIndex[(size_t)r * cols + c], ci = curIndex[(size_t)r * cols + c];
+        if (ri < 0 || ci < 0) continue;
+        ++K;
+        if (!correspondence_pixel(P, ref, cur, T, ri, ci, squaredThreshold, minCurvatureRatio, maxCurvatureRatio)) continue;
+        corr[2 * C] = ri; corr[2 * C + 1] = ci; ++C;
+      }
+    if (Kout) *Kout = K;
+    return C;
+  }
+  std::vector<std::vector<int> > seg(nt);
+  std::vector<int> Ks(nt, 0);
+#pragma omp parallel for num_threads(nt) schedule(static, 1)
+  for (int t = 0; t < nt; ++t) {
+    const int r0 = (int)((long long)rows * t / nt), r1 = (int)((long long)rows * (t + 1) / nt);
+    std::vector<int>& out = seg[t];
+    int K = 0;
+    for (int r = r0; r < r1; ++r)
+      for (int c = 0; c < cols; ++c) {
+        const int ri = refIndex[(size_t)r * cols + c], ci = curIndex[(size_t)r * cols + c];
+        if (ri < 0 || ci < 0) continue;
+        ++K;
+        if (!correspondence_pixel(P, ref, cur, T, ri, ci, squaredThreshold, minCurvatureRatio, maxCurvatureRatio)) continue;
+        out.push_back(ri); out.push_back(ci);
+      }
+    Ks[t] = K;
+  }
+  int C = 0, K = 0;
+  for (int t = 0; t < nt; ++t) {
+    std::memcpy(corr + 2 * (size_t)C, seg[t].data(), seg[t].size() * sizeof(int));
+    C += (int)(seg[t].size() / 2); K += Ks[t];
+  }
   if (Kout) *Kout = K;
   return C;
 }
 
+template <typename ACC> struct LinAcc {
+  ACC Htt[16], Htr[16], Hrr[16], bt[4], br[4], error; double errd; int inliers;
+  LinAcc() { for (int k = 0; k < 16; ++k) Htt[k] = Htr[k] = Hrr[k] = 0; for (int k = 0; k < 4; ++k) bt[k] = br[k] = 0; error = 0; errd = 0.0; inliers = 0; }
+};
+/* the loop body of linearizer.cpp:41-90 over the correspondences [i0, i1) */
 template <typename ACC>
-void linearize_impl(const orc_aligner_params* P, const orc_cloud* ref, const orc_cloud* cur, const int* corr, int C, M4 T,
-                    float* Hout, float* bout, float* chi2, double* chi2d, int* inliersOut) {
-  /* linearizer.cpp:17-115, numThreads == 1 */
-  force_last_row(T);
-  ACC Htt[16], Htr[16], Hrr[16], bt[4], br[4], error = 0; double errd = 0.0; int inliers = 0;
-  for (int k = 0; k < 16; ++k) Htt[k] = Htr[k] = Hrr[k] = 0;
-  for (int k = 0; k < 4; ++k) bt[k] = br[k] = 0;
-  for (int i = 0; i < C; ++i) {
+void linearize_range(const orc_aligner_params* P, const orc_cloud* ref, const orc_cloud* cur, const int* corr, int i0, int i1, const M4& T, LinAcc<ACC>& a) {
+  for (int i = i0; i < i1; ++i) {
     const int ri = corr[2 * i], ci = corr[2 * i + 1];
     V4 rp = iso_mul_v4(T, ref->points[ri]);  rp.v[3] = 1.0f;
     V4 rn = iso_mul_v4(T, ref->normals[ri]); rn.v[3] = 0.0f;
@@ -749,24 +789,50 @@ void linearize_impl(const orc_aligner_params* P, const orc_cloud* ref, const orc
       if (P->robust_kernel) kscale = std::sqrt(P->inlier_max_chi2 / localError);
       else continue;
     }
-    ++inliers;
+    ++a.inliers;
     const float term = kscale * localError;
-    error = error + (ACC)term; errd += (double)term;
+    a.error = a.error + (ACC)term; a.errd += (double)term;
     const M4 Sp = skew4(rp), Sn = skew4(rn);
     const M4 oPSp = m4_mul(oP, Sp);
     const M4 A = m4_mul(m4_mul(m4_transpose(Sp), oP), Sp);
     const M4 B = m4_mul(m4_mul(m4_transpose(Sn), oN), Sn);
     const V4 spe = m4_mul_v4(m4_transpose(Sp), ep), sne = m4_mul_v4(m4_transpose(Sn), en);
     for (int k = 0; k < 16; ++k) {
-      Htt[k] = Htt[k] + (ACC)oP.m[k];
-      Htr[k] = Htr[k] + (ACC)oPSp.m[k];
-      Hrr[k] = Hrr[k] + (ACC)(A.m[k] + B.m[k]);        /* Eigen 3.2: Hrr += (tmpA + tmpB) */
+      a.Htt[k] = a.Htt[k] + (ACC)oP.m[k];
+      a.Htr[k] = a.Htr[k] + (ACC)oPSp.m[k];
+      a.Hrr[k] = a.Hrr[k] + (ACC)(A.m[k] + B.m[k]);        /* Eigen 3.2: Hrr += (tmpA + tmpB) */
     }
     for (int k = 0; k < 4; ++k) {
-      bt[k] = bt[k] + (ACC)(kscale * ep.v[k]);
-      br[k] = br[k] + (ACC)(kscale * (spe.v[k] + sne.v[k]));
+      a.bt[k] = a.bt[k] + (ACC)(kscale * ep.v[k]);
+      a.br[k] = a.br[k] + (ACC)(kscale * (spe.v[k] + sne.v[k]));
     }
   }
+}
+template <typename ACC>
+void linearize_impl(const orc_aligner_params* P, const orc_cloud* ref, const orc_cloud* cur, const int* corr, int C, M4 T,
+                    float* Hout, float* bout, float* chi2, double* chi2d, int* inliersOut) {
+  /* linearizer.cpp:17-115.  One thread: the canonical serial sums.  More threads (the timed CPU baseline only): the reference's own
+   * scheme -- contiguous chunks of the list, per-thread partial sums, reduced serially in thread order (:33-39,93-108) -- with chunks
+   * that cover ALL correspondences (the reference drops the last C % numThreads).  Sums then differ from the one-thread ones in the
+   * last bits, exactly as the reference's do between thread counts. */
+  force_last_row(T);
+  const int nt = g_parallel_align ? std::max(1, std::min(omp_get_max_threads(), std::max(1, C / 256))) : 1;
+  LinAcc<ACC> tot;
+  if (nt == 1) {
+    linearize_range<ACC>(P, ref, cur, corr, 0, C, T, tot);
+  } else {
+    std::vector<LinAcc<ACC> > part(nt);
+#pragma omp parallel for num_threads(nt) schedule(static, 1)
+    for (int t = 0; t < nt; ++t)
+      linearize_range<ACC>(P, ref, cur, corr, (int)((long long)C * t / nt), (int)((long long)C * (t + 1) / nt), T, part[t]);
+    for (int t = 0; t < nt; ++t) {
+      for (int k = 0; k < 16; ++k) { tot.Htt[k] += part[t].Htt[k]; tot.Htr[k] += part[t].Htr[k]; tot.Hrr[k] += part[t].Hrr[k]; }
+      for (int k = 0; k < 4; ++k) { tot.bt[k] += part[t].bt[k]; tot.br[k] += part[t].br[k]; }
+      tot.error += part[t].error; tot.errd += part[t].errd; tot.inliers += part[t].inliers;
+    }
+  }
+  ACC* Htt = tot.Htt; ACC* Htr = tot.Htr; ACC* Hrr = tot.Hrr; ACC* bt = tot.bt; ACC* br = tot.br;
+  const ACC error = tot.error; const double errd = tot.errd; const int inliers = tot.inliers;
   /* linearizer.cpp:109-114 */
   float H[36];
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) {
@@ -1209,6 +1275,7 @@ void orc_trig_eval(int mode, int n, const float* y, const float* x, float* theta
   for (int i = 0; i < n; ++i) { theta[i] = trig_atan2(y[i], x[i]) * s_inv3; c[i] = trig_cos(theta[i]); s[i] = trig_sin(theta[i]); }
   g_trig_mode = saved;
 }
+void orc_set_parallel_align(int enabled) { g_parallel_align = enabled ? 1 : 0; }
 void orc_set_num_threads(int n) {
 #ifdef _OPENMP
   omp_set_num_threads(n > 0 ? n : 1);

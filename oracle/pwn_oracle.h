@@ -186,6 +186,11 @@ int  orc_cloud_load(orc_cloud* c, const char* filename, float T_out[16]);
 /* number of OpenMP threads the parallel (results-identical) loops will use */
 int  orc_num_threads(void);
 void orc_set_num_threads(int n);
+/* 1: CorrespondenceFinder::compute and Linearizer::update are spread over the OpenMP threads the way the reference does it
+ * (contiguous row blocks / correspondence chunks, per-thread partial sums reduced in thread order: correspondencefinder.cpp:38-51,
+ * 110-114, linearizer.cpp:32-39,93-108) but WITHOUT its remainder dropping; 0 (default): the canonical one-thread loops.  Only the
+ * timed CPU baseline switches it on. */
+void orc_set_parallel_align(int enabled);
 /* eigensolver trig: 0 (default, canonical) = fixed double-precision algorithms (+ - * / only, the same operations as the kernels) rounded
  * once to float; 1 = literal float libm calls as the reference makes them (last bit depends on the libm version); 2 = double libm rounded
  * to float */

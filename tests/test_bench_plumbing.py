@@ -1,0 +1,84 @@
+"""bench.py's host-side plumbing on the CPU: the N-rank launcher (`python bench.py --gpus N` starts N ranks itself), sharding,
+the result records in the real pwn_hip_align_result layout, the gloo all-gather, and the helpers of the extra bench lines."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _clean_env():
+    env = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return env
+
+
+def test_gpus_flag_launches_that_many_ranks_and_gathers_every_record():
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run-cpu", "--pairs", "8"], capture_output=True, text=True, timeout=300,
+                         env=_clean_env())
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout                       # ONE JSON line, from rank 0 only
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["records"] == 16 and j["records_ok"] and j["max_rank_seen"] == 1
+
+
+def test_single_rank_dry_run_and_world_size_mismatch_is_refused():
+    out = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--dry-run-cpu", "--pairs", "5"], capture_output=True, text=True, timeout=300, env=_clean_env())
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads(out.stdout.strip().splitlines()[-1])
+    assert j["n_gpus"] == 1 and j["records"] == 5 and j["records_ok"]
+    env = _clean_env(); env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run-cpu"], capture_output=True, text=True, timeout=300, env=env)
+    assert bad.returncode == 2 and "refusing" in bad.stderr
+
+
+def test_a_failing_rank_fails_the_launcher():
+    code = ("import sys, os; sys.argv=['bench.py']; sys.path.insert(0, %r); import bench;"
+            "import subprocess; real = subprocess.Popen;\n"
+            "def fake(cmd, env=None, stdout=None):\n"
+            "    r = int(env['RANK']); return real([sys.executable, '-c', 'import sys, time; time.sleep(0 if %%d else 30); sys.exit(%%d)' %% (r, 3 * r)])\n"
+            "bench.subprocess.Popen = fake; rc = bench.launch_ranks(2, []); sys.exit(rc)") % ROOT
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60, env=_clean_env())
+    assert out.returncode == 3, (out.returncode, out.stderr[-500:])     # rank 1 exits 3 at once; rank 0 (sleeping) is terminated, not waited for
+
+
+def test_closure_guesses_and_chi2_match_helpers():
+    sys.path.insert(0, ROOT)
+    import bench
+    from g2o_frontend_amd import synth
+    g = bench.closure_guesses([0, 5, 77])
+    assert g.shape == (3, 16) and g.dtype == np.float32
+    for i, s in enumerate([0, 5, 77]):
+        T = g[i].reshape(4, 4).T
+        assert T[2, 3] == 0.0 and np.array_equal(T[3], [0, 0, 0, 1])                 # pwn_matcher_base.cpp:114
+        true = synth.pair_pose(s)
+        assert np.abs(T[:2, 3] - true[:2, 3]).max() <= 0.012 and np.abs(T[:3, :3] - true[:3, :3]).max() < 0.02
+        assert not np.allclose(T[:3, :3], np.eye(3), atol=1e-4)                      # non-identity: the batch shortcut cannot fire
+    from g2o_frontend_amd.api import ALIGN_RESULT_DTYPE
+    res = np.zeros(2, ALIGN_RESULT_DTYPE)
+    res["iterations"] = 3; res["chi2"][0, :3] = (100.0, 50.0, 25.0); res["T"][0] = np.eye(4, dtype=np.float32).reshape(-1)
+    tr = [{"seed": 0, "chi2_fp64": [100.0, 50.0005, 25.0], "chi2_fp32_serial": [100.0, 50.0, 25.1], "T": np.eye(4).tolist()}]
+    m = bench.chi2_match(tr, res)
+    assert abs(m["max_rel_diff_vs_fp64_accumulated_oracle"] - 0.0005 / 50.0005) < 1e-9 and m["ok"] and m["max_abs_pose_diff"] == 0.0
+    assert abs(m["max_rel_diff_vs_reference_fp32_serial_sums"] - 0.1 / 25.1) < 1e-6
+    tr[0]["chi2_fp64"][1] = 50.1
+    assert not bench.chi2_match(tr, res)["ok"]
+
+
+def test_render_pool_keeps_job_order():
+    sys.path.insert(0, ROOT)
+    import bench
+    from g2o_frontend_amd import synth
+    K = synth.scaled_K(synth.K_VGA, 4)
+    jobs = [("pair", s, 60, 80, K) for s in range(5)] + [("frame", 9, np.eye(4).tolist(), 60, 80, K, 3)]
+    got = bench.render_all(jobs, world=1)
+    for s in range(5):
+        ref, cur, _ = synth.make_pair(s, 60, 80, K)
+        assert np.array_equal(got[s][0], ref) and np.array_equal(got[s][1], cur)
+    assert np.array_equal(got[5], synth.render_depth_mm(9, np.eye(4), 60, 80, K, hole_stream=3))

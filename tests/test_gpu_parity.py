@@ -510,6 +510,16 @@ def test_error_paths(ctx):
     small_cloud = api.Cloud(ctx, 10)
     with pytest.raises(PwnHipError):
         converter.compute(small_cloud, np.full((120, 160), 1.0, np.float32))
+    # a wide, short image with rows*cols <= the context's pixel budget but cols > max(max_rows, max_cols): the strip hand-over
+    # workspaces are sized for sides <= that maximum, so it is refused, alone and in a batch
+    assert ctx.max_rows * ctx.max_cols >= 17 * 18070 and 18070 > max(ctx.max_rows, ctx.max_cols)
+    wide = np.full((17, 18070), 1.0, np.float32)
+    with pytest.raises(PwnHipError) as e:
+        converter.compute(api.Cloud(ctx, 17 * 18070), wide)
+    assert e.value.code == 6
+    with pytest.raises(PwnHipError) as e:
+        converter.computeBatch([api.Cloud(ctx, 17 * 18070) for _ in range(16)], [wide] * 16)
+    assert e.value.code == 6
 
 
 @pytest.mark.parametrize("rows,cols", [(113, 150), (97, 131), (33, 70), (17, 65), (16, 64), (121, 63), (5, 300)])

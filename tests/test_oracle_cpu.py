@@ -7,10 +7,12 @@ SE(3) conventions) is checked against brute-force / finite-difference evaluation
 recover the known camera motion and the known plane normals of the synthetic scene; (4) committed golden
 vectors (tests/golden/) freeze its outputs bit for bit.
 """
+import os
+
 import numpy as np
 import pytest
 
-from conftest import case_params, make_depth_pair
+from conftest import ROOT, case_params, make_depth_pair
 
 
 def rand_rot(rng, scale=0.3):
@@ -369,3 +371,57 @@ def test_synthetic_generator_is_deterministic_and_plausible():
     for p, q in zip(tr[:-1], tr[1:]):
         d = np.linalg.inv(p) @ q
         assert np.linalg.norm(d[:3, 3]) <= 0.021 and np.arccos(np.clip((np.trace(d[:3, :3]) - 1) / 2, -1, 1)) <= np.deg2rad(1.01)
+
+
+def test_parallel_align_variant_keeps_the_canonical_list(oracle):
+    """The timed CPU baseline's OpenMP variant of CorrespondenceFinder::compute / Linearizer::update (the reference's thread partition
+    without its remainder dropping: correspondencefinder.cpp:38-51, linearizer.cpp:32-39): the correspondence list is the one-thread list
+    exactly, whatever the thread count; H, b, chi2 differ only by the order of the per-thread partial sums."""
+    O = oracle
+    rows, cols, K, conv, alig = case_params("small")
+    ref, cur, _, _, _ = make_depth_pair("small", 1)
+    cp = O.converter_params(K=K, **conv); ap = O.aligner_params(rows, cols, K=K, **alig)
+    cr, ridx, _ = O.convert(cp, ref); cc, cidx, _ = O.convert(cp, cur)
+    T = np.eye(4, dtype=np.float32)
+    try:
+        O.set_parallel_align(False)
+        c1, k1 = O.correspondences(ap, cr, cc, ridx, cidx, T)
+        l1 = O.linearize(ap, cr, cc, c1, T)
+        for threads in (3, 7):                                   # 120 rows: 7 does not divide them -- the reference would drop a row
+            O.set_num_threads(threads); O.set_parallel_align(True)
+            cN, kN = O.correspondences(ap, cr, cc, ridx, cidx, T)
+            assert kN == k1 and np.array_equal(cN, c1)
+            lN = O.linearize(ap, cr, cc, c1, T)
+            assert lN["inliers"] == l1["inliers"]
+            assert abs(lN["chi2"] - l1["chi2"]) <= 1e-4 * abs(l1["chi2"])
+            assert np.abs(lN["H"] - l1["H"]).max() <= 1e-4 * np.abs(l1["H"]).max()
+    finally:
+        O.set_parallel_align(False); O.set_num_threads(8)
+
+
+def test_fast_build_of_the_oracle_is_bit_identical():
+    """bench.py times the -O3 -march=native build of the oracle source; same results as the -O2 checker build."""
+    import json
+    import subprocess
+    import sys
+    code = (
+        "import os, sys, json, hashlib\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "if sys.argv[1] == 'fast': os.environ['PWN_ORACLE_VARIANT'] = 'fast'\n"
+        "from conftest import case_params, make_depth_pair\n"
+        "from oracle import oracle as O\n"
+        "rows, cols, K, conv, alig = case_params('small')\n"
+        "ref, cur, _, _, _ = make_depth_pair('small', 1)\n"
+        "cp = O.converter_params(K=K, **conv); ap = O.aligner_params(rows, cols, K=K, **alig)\n"
+        "cr, _, _ = O.convert(cp, ref); cc, _, _ = O.convert(cp, cur)\n"
+        "r = O.align(ap, cr, cc)\n"
+        "a = cr.arrays()\n"
+        "h = hashlib.sha1(b''.join(a[k].tobytes() for k in ('points', 'normals', 'curvature', 'omega_p', 'omega_n'))).hexdigest()\n"
+        "print(json.dumps(dict(h=h, chi2=[float(i['chi2']) for i in r['iterations']], T=r['T'].astype(float).tolist())))\n"
+    ) % (ROOT, os.path.join(ROOT, "tests"))
+    outs = []
+    for variant in ("canonical", "fast"):
+        p = subprocess.run([sys.executable, "-c", code, variant], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs.append(json.loads(p.stdout.strip().splitlines()[-1]))
+    assert outs[0] == outs[1]

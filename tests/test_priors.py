@@ -66,3 +66,72 @@ def test_align_with_priors_matches_oracle(oracle, small, kind):
     g2 = aligner.align()
     assert np.abs(g2["T"] - free["T"]).max() < 1e-5
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_priors_and_statistics_together(oracle, small):
+    """The reference adds the priors inside the loop (aligner.cpp:96-108) AND runs _computeStatistics afterwards (:127) in the same
+    align(); neither may be dropped when both are asked for (the two mirrors each dropped one of them)."""
+    from g2o_frontend_amd import api, synth
+    from test_gpu_parity import gpu_objects, _check_alignment
+    d = small
+    ctx = api.Context(0, d["rows"], d["cols"], 2)
+    _, converter, aligner = gpu_objects(ctx, "small")
+    gref, gcur = api.Cloud(ctx, d["rows"] * d["cols"]), api.Cloud(ctx, d["rows"] * d["cols"])
+    converter.compute(gref, d["ref"]); converter.compute(gcur, d["cur"])
+    mean = synth.v2t(np.array([0.06, -0.03, -0.02, 0.01, -0.015, 0.01])).astype(np.float32)
+    info = (np.diag([4e5, 4e5, 4e5, 2e6, 2e6, 2e6]) + 1e4).astype(np.float32)
+    ap = oracle.aligner_params(d["rows"], d["cols"], K=d["K"], accumulate_fp64=1, **d["alig"])
+    oracle.clear_priors(); oracle.add_prior(0, mean, info)
+    o = oracle.align(ap, d["cr"], d["cc"])
+    os_ = oracle.align_statistics(ap, d["cr"], d["cc"], o["T"])      # the 11th update: H of the linearizer alone, no prior terms (:165-170)
+    aligner.setReferenceCloud(gref); aligner.setCurrentCloud(gcur)
+    aligner.addRelativePrior(mean, info)
+    only_priors = aligner.align()
+    aligner._omega[:] = -1.0
+    both = aligner.align(statistics=True)
+    assert np.array_equal(only_priors["T"], both["T"]) and np.array_equal(only_priors["chi2"], both["chi2"])      # the priors were not dropped
+    _check_alignment(o, both)
+    st = aligner._statistics
+    hs = np.abs(os_["H"]).max()
+    assert np.abs(st["H"] - os_["H"]).max() <= 2e-2 * hs                          # free-running 120x160 bar of test_statistics
+    assert np.abs(aligner.omega() - os_["omega"]).max() <= 0.2 * np.abs(os_["omega"]).max()
+    again = oracle.compute_statistics(st["H"], both["T"])                          # the statistics are those of the returned H and T
+    assert np.abs(again["omega"] - aligner.omega()).max() <= 1e-3 * np.abs(again["omega"]).max()
+    assert np.abs(st["mean"] - oracle.t2v(both["T"])).max() < 1e-4
+    ctx.close()
+
+
+@pytest.mark.gpu
+def test_fixed_tag_paths_do_not_poison_later_alignments(oracle, small):
+    """z-buffer epoch tags: a smaller tag wins atomicMin.  A priors alignment with many outer iterations between two one-iteration
+    alignments must not leave words behind that beat the later call's tags: same result as on a fresh context."""
+    from g2o_frontend_amd import api, synth
+    from test_gpu_parity import gpu_objects
+    d = small
+
+    def run(with_priors_call):
+        ctx = api.Context(0, d["rows"], d["cols"], 2)
+        _, converter, aligner = gpu_objects(ctx, "small")
+        gref, gcur = api.Cloud(ctx, d["rows"] * d["cols"]), api.Cloud(ctx, d["rows"] * d["cols"])
+        converter.compute(gref, d["ref"]); converter.compute(gcur, d["cur"])
+        aligner.setReferenceCloud(gref); aligner.setCurrentCloud(gcur)
+        aligner.setOuterIterations(1)
+        first = aligner.align()
+        if with_priors_call:
+            aligner.setOuterIterations(10)
+            aligner.addRelativePrior(synth.v2t(np.array([0.3, 0.2, -0.2, 0.05, -0.05, 0.05])).astype(np.float32), np.eye(6, dtype=np.float32) * 1e7)
+            aligner.align()                                  # projects the reference from ten quite different poses
+            aligner.clearPriors()
+            aligner.setOuterIterations(1)
+        last = aligner.align(images=True)
+        imgs = dict(aligner.correspondenceFinder()._images)
+        ctx.close()
+        return first, last, imgs
+
+    f0, l0, i0 = run(False)
+    f1, l1, i1 = run(True)
+    assert np.array_equal(f0["T"], f1["T"])
+    assert np.array_equal(l0["T"], l1["T"]) and np.array_equal(l0["chi2"], l1["chi2"]) and np.array_equal(l0["K"], l1["K"])
+    for k in i0:
+        assert np.array_equal(i0[k], i1[k]), k

@@ -8,45 +8,7 @@ from conftest import case_params
 pytestmark = pytest.mark.gpu
 
 
-class OracleTracker:
-    """processFrame restated on top of the oracle (test-side twin of g2o_frontend_amd.api.PwnTracker)."""
-
-    def __init__(self, O, conv, alig, scale, fraction):
-        self.O, self.conv, self.alig, self.scale, self.fraction = O, conv, alig, scale, fraction
-        self.prev = None
-        I = np.eye(4, dtype=np.float32)
-        self.globalT, self.prevT, self.prevOff = I.copy(), I.copy(), I.copy()
-        self.counter = 0; self.keyframes = 0
-
-    def makeCloud(self, K, off, depth):
-        O = self.O
-        Ks = (np.asarray(K, np.float32) * (np.float32(1.0) / np.float32(self.scale))).astype(np.float32); Ks[2, 2] = 1
-        k4 = (float(Ks[0, 0]), float(Ks[1, 1]), float(Ks[0, 2]), float(Ks[1, 2]))
-        d = O.depth_scale(depth, self.scale)
-        c, _, _ = O.convert(O.converter_params(K=k4, sensor_offset=off, **self.conv), d)
-        return c, d.shape[0], d.shape[1], k4
-
-    def processFrame(self, depth, off, K):
-        O = self.O
-        cur, r, c, k4 = self.makeCloud(K, off, depth)
-        out = dict(newFrame=False)
-        if self.prev is not None:
-            guess = O.iso_mul(O.iso_mul(O.iso_inverse(self.prevT), self.globalT), np.eye(4, dtype=np.float32))
-            ap = O.aligner_params(r, c, K=k4, initial_guess=guess, reference_sensor_offset=self.prevOff, current_sensor_offset=off,
-                                  accumulate_fp64=1, **self.alig)
-            res = O.align(ap, self.prev, cur)
-            self.globalT = O.iso_mul(self.prevT, res["T"]) if res["inliers"] > 0 else O.iso_mul(self.globalT, guess)
-            self.globalT[3] = (0, 0, 0, 1)
-            out.update(inliers=res["inliers"], error=res["error"])
-            if np.float32(res["inliers"]) / np.float32(r * c) < self.fraction:
-                out["newFrame"] = True; self.keyframes += 1
-                self.prev, self.prevT = cur, self.globalT.copy()
-        else:
-            out["newFrame"] = True; self.prev, self.prevT, self.prevOff = cur, self.globalT.copy(), np.asarray(off, np.float32).copy()
-            self.keyframes += 1
-        self.counter += 1
-        out["globalT"] = self.globalT.copy()
-        return out
+from oracle_tracker import OracleTracker  # noqa: E402  (processFrame restated on top of the oracle)
 
 
 def test_processFrame_trajectory_and_keyframes_match_oracle(oracle):
@@ -99,4 +61,60 @@ def test_cloud_cache_lru_and_reconversion(oracle):
     assert np.array_equal(cache.get(0).arrays()["points"], ref[0]) and cache.misses == 4        # evicted -> converted again, same bits
     cache.get(2); cache.get(1)
     assert cache.misses == 5 and cache.hits == 2
+    ctx.close()
+
+
+def test_config2_full_size_stream_matches_oracle():
+    """BASELINE configs[2] at its stated size: the 200-frame VGA stream of synth.trajectory_sweep(9) through PwnTracker::processFrame
+    (pwn_tracker/pwn_tracker.cpp:106-215) at matcher scale 1 with the reference's new-frame fraction 0.4 -- a trajectory that switches the
+    key-cloud five times (:164-185).  Every frame against the oracle tracker's record of the same stream (tests/golden/tracker_vga_sweep.json,
+    made by tests/golden/make_tracker_golden.py): key-frame decisions identical, inliers within a few correspondences, globalT within the
+    free-running pose bar accumulated along the chain; the oracle is re-run live on a prefix that contains the first switch to show the file
+    is the oracle's output; size-independent properties on all 200 frames."""
+    import json
+    import os
+    from g2o_frontend_amd import api, synth
+    from test_gpu_parity import gpu_objects
+    from oracle import oracle as O
+    gold = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "tracker_vga_sweep.json")))
+    n, rows, cols = gold["frames"], gold["rows"], gold["cols"]
+    assert (n, rows, cols, gold["scale"]) == (200, 480, 640, 1)
+    _, _, K, conv, alig = case_params("vga")
+    ctx = api.Context(0, rows, cols, 2)
+    _, converter, aligner = gpu_objects(ctx, "vga")
+    alproj = api.PinholePointProjector(); alproj.setMinDistance(alig["min_distance"]); alproj.setMaxDistance(alig["max_distance"])
+    aligner.setProjector(alproj)
+    tracker = api.PwnTracker(aligner, converter); tracker.setScale(1); tracker.setNewFrameInliersFraction(gold["newFrameInliersFraction"])
+    otr = OracleTracker(O, conv, alig, 1, gold["newFrameInliersFraction"])
+    Km = np.array([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]], np.float32)
+    I = np.eye(4, dtype=np.float32)
+    poses = synth.trajectory_sweep(gold["seed"], n)
+    live_prefix = 30                                    # the oracle costs ~0.45 s per VGA frame; the first switch is at frame 24
+    keyframes, worst_pose, worst_inl = [], 0.0, 0
+    for k in range(n):
+        depth = ctx.DepthImage_convert_16UC1_to_32FC1(synth.render_depth_mm(gold["seed"], poses[k], rows, cols, K, hole_stream=k))
+        g = tracker.processFrame(depth, I, Km)
+        e = gold["per_frame"][k]
+        if k < live_prefix:
+            o = otr.processFrame(depth, I, Km)
+            assert o["newFrame"] == e["newFrame"] and int(o.get("inliers", 0)) == e["inliers"], k
+            assert np.array_equal(o["globalT"].reshape(-1).astype(np.float32), np.asarray(e["globalT"], np.float32)), k
+        assert g["newFrame"] == e["newFrame"], (k, g.get("inliers"), e["inliers"])
+        if g["newFrame"]:
+            keyframes.append(k)
+        if k > 0:
+            worst_inl = max(worst_inl, abs(g["inliers"] - e["inliers"]))
+            assert abs(g["inliers"] - e["inliers"]) <= 64, (k, g["inliers"], e["inliers"])                # of ~150 000
+            assert g["inliers"] > 0 and g["aligned"]
+        dT = np.abs(g["globalT"].reshape(-1) - np.asarray(e["globalT"], np.float32)).max()
+        worst_pose = max(worst_pose, float(dT))
+        assert dT < 2e-4, (k, dT)                       # free-running chain: 1e-5-class per alignment, chained over the key-frames
+        # properties that hold at any size: globalT is a rigid transform and follows the true camera motion
+        R = g["globalT"][:3, :3].astype(np.float64)
+        assert np.abs(R.T @ R - np.eye(3)).max() < 1e-4 and np.array_equal(g["globalT"][3], [0, 0, 0, 1])
+        true = np.linalg.inv(poses[0]) @ poses[k]
+        assert np.abs(g["globalT"][:3, 3] - true[:3, 3]).max() < 0.02, (k, g["globalT"][:3, 3], true[:3, 3])
+    assert keyframes == gold["keyframes"] and len(keyframes) - 1 >= 3          # >= 3 key-cloud switches after the first frame
+    assert tracker.numKeyframes() == len(keyframes)
+    print(f"config2: key-frames {keyframes}, worst |inliers diff| {worst_inl}, worst |globalT diff| {worst_pose:.2e}")
     ctx.close()

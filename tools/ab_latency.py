@@ -15,7 +15,7 @@ converter, aligner = bench.build_objects(ctx, rows, cols, K, conv, alig)
 r, c, _ = synth.make_pair(0, rows, cols, K)
 rd = torch.from_numpy(r.view(np.int16)).cuda(); cd = torch.from_numpy(c.view(np.int16)).cuda()
 a, b = api.Cloud(ctx, rows * cols), api.Cloud(ctx, rows * cols)
-names = ["unproject", "integral", "integral_rows", "integral_cols", "stats", "project", "corr_linearize", "solve"]
+names = ["unproject", "integral", "integral_rows", "integral_cols", "stats", "project_cur", "project_ref", "corr_linearize", "solve"]
 for prof in (False, True):
     ctx.set_profiling(prof)
     tc, ta, st = [], [], {k: 0.0 for k in names}
