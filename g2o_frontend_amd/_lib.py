@@ -121,6 +121,7 @@ PROTOTYPES = {
     "pwn_hip_cloud_load": (_I, [_VP, _VP, C.c_char_p, _VP]),
     "pwn_hip_last_stage_ms": (_I, [_VP, C.c_char_p, C.POINTER(_F), C.POINTER(_I)]),
     "pwn_hip_set_profiling": (_I, [_VP, _I]),
+    "pwn_hip_debug_withhold_carry": (_I, [_VP, _I, _I, _I, _I, _I]),
     "pwn_hip_measure_hbm": (_I, [_VP, C.c_size_t, _VP, _VP]),
 }
 

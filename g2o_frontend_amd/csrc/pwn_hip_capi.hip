@@ -64,6 +64,7 @@ struct pwn_hip_ctx {
   uint16_t* raw_ws = nullptr;
   unsigned long long* carry_ws = nullptr; size_t carry_slot = 0; size_t rowoff_slot = 0;   // single-pass integral image: hand-over words, strip offsets
   unsigned convert_epoch = 0; int* fault_dev = nullptr;
+  int spin_limit = kSpinLimit; int dbg_withhold = -1;        // pwn_hip_debug_withhold_carry (test hook)
   // align workspaces (per slot)
   unsigned long long* zref_ws = nullptr; unsigned long long* zcur_ws = nullptr; int* curidx_ws = nullptr; double* partials_ws = nullptr; PairState* state_ws = nullptr;
   int nblocks_max = 0;
@@ -198,8 +199,9 @@ void collect_stage_times(pwn_hip_ctx* ctx) {
 Mat4 forced(const float* T) { Mat4 m = mat4_from(T); set_last_row(m); return m; }
 bool is_identity(const Mat4& m) { const Mat4 I = mat4_identity(); for (int i = 0; i < 16; ++i) if (m.m[i] != I.m[i]) return false; return true; }
 
-ConvertParams make_convert_params(const pwn_hip_converter_params* p, const float* T, int rows, int cols, int keep_stats) {
+ConvertParams make_convert_params(const pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float* T, int rows, int cols, int keep_stats) {
   ConvertParams cp;
+  cp.spinLimit = ctx ? ctx->spin_limit : kSpinLimit; cp.dbgWithhold = ctx ? ctx->dbg_withhold : -1;
   cp.rows = rows; cp.cols = cols;
   const Mat3 K = mat3_from(p->K);
   Mat4 KRt; Mat3 iK;
@@ -391,7 +393,7 @@ int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, cons
   if (int rc = check_image(ctx, rows, cols)) return rc;
   const size_t N = (size_t)rows * cols;
   ctx->stages.clear();
-  const ConvertParams cp = make_convert_params(p, nullptr, rows, cols, keep_stats);
+  const ConvertParams cp = make_convert_params(ctx, p, nullptr, rows, cols, keep_stats);
   const StreamPlan plan = make_plan(ctx, ctx->sub_frames, n);
   const int sub = plan.sub;
   if (int rc = ensure_desc(ctx, n)) return rc;
@@ -592,6 +594,17 @@ int pwn_hip_ctx_set_concurrency(pwn_hip_ctx* ctx, int streams) {
   if (!ctx || streams < 1 || streams > 4) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "streams must be 1..4");
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
   ctx->concurrency = streams;
+  return PWN_HIP_OK;
+}
+// Test hook for the strip hand-over of the converter's integral-image kernels: one hand-over word (strip, band, chain) of every
+// frame is not written, so the chain to its right times out after `spin_limit` polls (0 = the default, ~1 s), the launch raises
+// its fault flag and the convert call returns PWN_HIP_ERR_LAUNCH instead of hanging.  strip < 0 switches the hook off.
+int pwn_hip_debug_withhold_carry(pwn_hip_ctx* ctx, int strip, int band, int chain, int rows, int spin_limit) {
+  if (!ctx) return fail(nullptr, PWN_HIP_ERR_INVALID_ARGUMENT, "null ctx");
+  if (strip < 0) { ctx->dbg_withhold = -1; ctx->spin_limit = kSpinLimit; return PWN_HIP_OK; }
+  if (band < 0 || chain < 0 || chain >= kII_Chains || rows <= 0 || band >= bands_of(rows)) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "bad hand-over word");
+  ctx->dbg_withhold = (strip * bands_of(rows) + band) * kII_Chains + chain;
+  ctx->spin_limit = spin_limit > 0 ? spin_limit : kSpinLimit;
   return PWN_HIP_OK;
 }
 int pwn_hip_set_profiling(pwn_hip_ctx* ctx, int enabled) {
@@ -883,7 +896,7 @@ int pwn_hip_unproject(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const
   if (int rc = check_image(ctx, rows, cols)) return rc;
   const size_t N = (size_t)rows * cols;
   cloud->idx_valid = false;                      // the cloud gets new points
-  const ConvertParams cp = make_convert_params(p, T, rows, cols, 0);
+  const ConvertParams cp = make_convert_params(ctx, p, T, rows, cols, 0);
   const float* d = nullptr;
   if (int rc = stage_depth(ctx, depth, N, &d)) return rc;
   HIPCHK(ctx, hipMemsetAsync(cloud->d.Nm, 0, sizeof(float4) * (size_t)cloud->d.capacity, ctx->stream), PWN_HIP_ERR_COPY);
@@ -903,7 +916,7 @@ int pwn_hip_project_intervals(pwn_hip_ctx* ctx, const pwn_hip_converter_params* 
   if (!ctx || !p || !depth || !interval_image) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if (int rc = check_image(ctx, rows, cols)) return rc;
   const size_t N = (size_t)rows * cols;
-  const ConvertParams cp = make_convert_params(p, nullptr, rows, cols, 0);
+  const ConvertParams cp = make_convert_params(ctx, p, nullptr, rows, cols, 0);
   const float* d = nullptr;
   if (int rc = stage_depth(ctx, depth, N, &d)) return rc;
   CloudDev none; std::memset(&none, 0, sizeof(none)); none.count = ctx->scratch_count; none.capacity = 0;

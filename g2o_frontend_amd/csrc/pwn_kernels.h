@@ -79,6 +79,8 @@ struct ConvertParams {
   int hasOffset;
   Mat4 offset;               // sensor offset with last row forced
   int keepStats;
+  int spinLimit;             // polls of a strip hand-over word before a waiting lane gives up and raises the fault flag (kSpinLimit)
+  int dbgWithhold;           // test hook (pwn_hip_debug_withhold_carry): index of one hand-over word that is NOT written, -1 = none
 };
 
 struct PairState {
@@ -460,7 +462,7 @@ __global__ void __launch_bounds__(256) k_unproject_integral_rows(const FrameDesc
       unsigned long long w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int spins = 0;
       while ((unsigned)(w >> 32) != epoch) {
-        if (++spins >= (1 << 20)) { atomicExch(fault, 1); break; }       // a starved chain finishes with garbage instead of hanging the device
+        if (++spins >= cp.spinLimit) { atomicExch(fault, 1); break; }    // a starved chain finishes with garbage instead of hanging the device
         __builtin_amdgcn_s_sleep(1);
         w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -478,7 +480,7 @@ __global__ void __launch_bounds__(256) k_unproject_integral_rows(const FrameDesc
 #pragma unroll
       for (int c = 0; c < 16; ++c) t[c0 + c] = vals[c];
     }
-    if (s + 1 < S)
+    if (s + 1 < S && (s * NB + band) * kII_ChainsRows + tid != cp.dbgWithhold)
       __hip_atomic_store(f.carry + ((size_t)s * NB + band) * kII_ChainsRows + tid,
                          ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(carry), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
@@ -630,7 +632,7 @@ __global__ void __launch_bounds__(kII_Threads) k_unproject_integral(const FrameD
             unsigned long long w = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int spins = 0;
             while ((unsigned)(w >> 32) != epoch && !starved) {    // after one time-out this lane stops waiting: the launch is lost anyway
-              if (++spins >= kSpinLimit) { atomicExch(fault, 1); starved = true; break; }
+              if (++spins >= cp.spinLimit) { atomicExch(fault, 1); starved = true; break; }
               __builtin_amdgcn_s_sleep(1);
               w = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
@@ -695,7 +697,7 @@ __global__ void __launch_bounds__(kII_Threads) k_unproject_integral(const FrameD
 #pragma unroll
         for (int cc = 0; cc < 16; ++cc) t[c0 + cc] = vals[cc];
       }
-      if (s + 1 < S)
+      if (s + 1 < S && (s * NB + band) * kII_Chains + tid != cp.dbgWithhold)
         __hip_atomic_store(gcarry + ((size_t)s * NB + band) * kII_Chains + tid,
                            ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(carry),
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

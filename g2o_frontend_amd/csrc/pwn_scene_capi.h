@@ -113,7 +113,7 @@ int pwn_hip_cloud_gaussians(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p,
   if (int rc = ensure_gauss(ctx, cloud)) return rc;
   if (int rc = ensure_desc(ctx, 1)) return rc;
   const size_t N = (size_t)rows * cols;
-  const ConvertParams cp = make_convert_params(p, nullptr, rows, cols, 0);
+  const ConvertParams cp = make_convert_params(ctx, p, nullptr, rows, cols, 0);
   Mat4 KRt, iKRt; Mat3 iK;
   projector_matrices(mat3_from(p->K), mat4_identity(), KRt, iKRt, iK);
   const float* d = nullptr;

@@ -326,6 +326,11 @@ int pwn_hip_last_stage_ms(pwn_hip_ctx* ctx, const char* stage, float* ms, int* l
  * float4 streaming read and device-to-device copy of `bytes` (use >= 1 GiB: the Infinity Cache holds 256 MiB), best of 5,
  * GB/s; the copy counts bytes read + written.  Allocates and frees 2 x bytes. */
 int pwn_hip_measure_hbm(pwn_hip_ctx* ctx, size_t bytes, float* read_gbps, float* copy_gbps);
+/* TEST HOOK.  The converter's integral-image kernels hand the running sums of a strip to the strip on its right through tagged words,
+ * polled with a bound: a word that never arrives raises a fault flag and the convert call returns PWN_HIP_ERR_LAUNCH ("strip hand-over
+ * timed out") instead of hanging the device.  This call makes that happen on purpose: the word (strip, band, chain) of every frame of
+ * rows x * images is withheld and the poll bound is lowered to spin_limit polls (0 = the default).  strip < 0 switches the hook off. */
+int pwn_hip_debug_withhold_carry(pwn_hip_ctx* ctx, int strip, int band, int chain, int rows, int spin_limit);
 /* enable/disable hipEvent timing around every kernel launch (adds host overhead; default off) */
 int pwn_hip_set_profiling(pwn_hip_ctx* ctx, int enabled);
 
