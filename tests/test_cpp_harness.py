@@ -152,17 +152,11 @@ def test_scene_mapping_harness_matches_oracle(tmp_path, oracle):
     assert np.abs(G[:3, 3] - true[:3, 3]).max() < 0.02
 
 
-@pytest.mark.gpu
-def test_tracker_closer_harness_matches_python_mirror(tmp_path):
-    """tools/pwn_hip_tracker_app.cpp -- PwnTracker::processFrame with key-cloud switching, the closure pass through CloudCache + batched
-    matchClouds + PwnCloser's acceptance rule, Aligner statistics (omega, eigen ratios) and SE(3) priors, all over the C++ mirror --
-    against the same flow written with the Python mirror.  Both are thin layers over the same C-ABI calls with the same arguments, so
-    every number must agree to the last digit printed (%.9g round-trips a float)."""
-    from g2o_frontend_amd import api, build, synth
-    from oracle import oracle as O          # parameter tables only
+def _run_tracker_app(tmp_path, n=5):
+    """tools/pwn_hip_tracker_app on a 5-frame VGA stream at matcher scale 4: every frame a key-frame (fraction 2.0), a cache of two clouds"""
+    from g2o_frontend_amd import build, synth
     build.build_tools()
     exe = os.path.join(ROOT, "tools", "pwn_hip_tracker_app")
-    n = 5
     poses = synth.trajectory(13, n)
     frames = [synth.render_depth_mm(13, poses[k], 480, 640, synth.K_VGA, hole_stream=k) for k in range(n)]
     lst = []
@@ -180,6 +174,92 @@ def test_tracker_closer_harness_matches_python_mirror(tmp_path):
     hits_line = [l for l in open(prefix + "_closures.txt") if l.startswith("#")][0].split()
     extras = {l.split()[0]: np.array(l.split()[1:], np.float64) for l in open(prefix + "_extras.txt")}
     assert track.shape == (n, 22) and clos.shape == (n * (n - 1) // 2, 24)
+    return n, poses, frames, track, clos, hits_line, extras
+
+
+@pytest.mark.gpu
+def test_tracker_closer_harness_matches_oracle(tmp_path, oracle):
+    """The same C++ program against the ORACLE running the same flow (not against the other mirror): PwnTracker::processFrame
+    (pwn_tracker/pwn_tracker.cpp:106-215) through tests/oracle_tracker.py, the closure pass as matchClouds (pwn_matcher_base.cpp:88-183: guess
+    with z reset, align, depth-agreement score) + matchFrames' acceptance (pwn_closer.cpp:138-141), _computeStatistics, priors.
+    Free-running bars of the 120x160 configuration: counters within a few flipped correspondences, poses 5e-5."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from g2o_frontend_amd import synth
+    from oracle_tracker import OracleTracker
+    from test_statistics import omega_tolerance
+    O = oracle
+    n, poses, frames, track, clos, hits_line, extras = _run_tracker_app(tmp_path)
+    conv, alig = O.QVGA4_CONF_CONVERTER, O.QVGA4_CONF_ALIGNER
+    K = synth.K_VGA
+    Kmat = np.array([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]], np.float32)
+    I = np.eye(4, dtype=np.float32)
+    otr = OracleTracker(O, conv, alig, 4, 2.0)
+    depth = [O.convert_16u_to_32f(f) for f in frames]
+    keyPoses, clouds = [], []
+    for k in range(n):
+        o = otr.processFrame(depth[k], I, Kmat)
+        g = track[k]
+        assert (int(g[0]), bool(g[1])) == (k, o["newFrame"])
+        if k > 0:
+            assert bool(g[2]) and abs(int(g[3]) - o["inliers"]) <= 4 and abs(g[4] - o["error"]) <= 1e-2 * o["error"], (k, g[:6], o)
+        assert np.abs(g[6:].astype(np.float32).reshape(4, 4).T - o["globalT"]).max() < 5e-5, k
+        keyPoses.append(o["globalT"]); clouds.append(otr.prev)
+    K4 = synth.scaled_K(K, 4)
+    acc_nonzero, acc_outliers, acc_inliers = 3000, 100000, 1000                   # pwn_closer.cpp:56-58 with the harness' outlier threshold
+    row, accepted = 0, 0
+    for a in range(n):
+        for b in range(a):
+            guess = O.iso_mul(O.iso_inverse(keyPoses[b]), keyPoses[a]).astype(np.float32)
+            guess[2, 3] = 0.0                                                        # pwn_matcher_base.cpp:114
+            ap = O.aligner_params(120, 160, K=K4, initial_guess=guess, accumulate_fp64=1, **alig)
+            o = O.align(ap, clouds[b], clouds[a], images=True)
+            sc = O.match_score(o["ref_depth"], o["cur_depth"], 50.0)
+            g = clos[row]; row += 1
+            assert (int(g[0]), int(g[1])) == (b, a)
+            assert abs(int(g[3]) - o["inliers"]) <= 8, (g[:8], o["inliers"])
+            assert abs(int(g[4]) - sc["image_nonZeros"]) <= 16 and abs(int(g[6]) - sc["image_inliers"]) <= 16 and abs(int(g[5]) - sc["image_outliers"]) <= 16, (g[:8], sc)
+            assert abs(g[7] - sc["image_reprojectionDistance"]) <= 2e-2 * sc["image_reprojectionDistance"] + 1e-3
+            assert np.abs(g[8:].astype(np.float32).reshape(4, 4).T - o["T"]).max() < 1e-4       # the guesses are the two trackers' own key poses (5e-5 apart)
+            ok = not (sc["image_nonZeros"] < acc_nonzero or sc["image_outliers"] > acc_outliers or sc["image_inliers"] < acc_inliers)
+            margin = min(abs(sc["image_nonZeros"] - acc_nonzero), abs(sc["image_inliers"] - acc_inliers))
+            if margin > 16:
+                assert bool(g[2]) == ok, (g[:8], sc)
+            accepted += int(bool(g[2]))
+    assert accepted >= 1
+    # Aligner::_computeStatistics on frames 0 -> 1 (identity guess), per-entry bars measured on the oracle's own chain (test_statistics.omega_tolerance)
+    ap = O.aligner_params(120, 160, K=K4, accumulate_fp64=1, **alig)
+    o = O.align(ap, clouds[0], clouds[1])
+    os_ = O.align_statistics(ap, clouds[0], clouds[1], o["T"])
+    e = extras["statistics"]
+    Hg = e[39:75].astype(np.float32).reshape(6, 6).T; omg = e[3:39].astype(np.float32).reshape(6, 6).T
+    assert np.abs(e[75:91].astype(np.float32).reshape(4, 4).T - o["T"]).max() < 5e-5
+    dH = np.abs(Hg - os_["H"]).max() / np.abs(os_["H"]).max()
+    assert dH <= 2e-2
+    tol_om, tol_ratio = omega_tolerance(O, os_["H"], o["T"], dH)
+    assert (np.abs(omg.astype(np.float64) - os_["omega"]) <= tol_om).all()
+    assert abs(e[1] - os_["translationalEigenRatio"]) <= tol_ratio[0] and abs(e[2] - os_["rotationalEigenRatio"]) <= tol_ratio[1]
+    # two priors (absolute + relative, both identity / 1000 I) on the same pair
+    O.clear_priors(); O.add_prior(1, I, np.eye(6, dtype=np.float32) * 1000, reference_transform=I); O.add_prior(0, I, np.eye(6, dtype=np.float32) * 1000)
+    try:
+        op = O.align(ap, clouds[0], clouds[1])
+    finally:
+        O.clear_priors()
+    e = extras["priors"]
+    assert int(e[0]) == 2 and abs(int(e[1]) - op["inliers"]) <= 4 and abs(e[2] - op["error"]) <= 1e-2 * op["error"]
+    assert np.abs(e[3:19].astype(np.float32).reshape(4, 4).T - op["T"]).max() < 5e-5
+    assert np.abs(op["T"] - o["T"]).max() > 1e-5                              # the priors did change the estimate
+
+
+@pytest.mark.gpu
+def test_tracker_closer_harness_matches_python_mirror(tmp_path):
+    """tools/pwn_hip_tracker_app.cpp -- PwnTracker::processFrame with key-cloud switching, the closure pass through CloudCache + batched
+    matchClouds + PwnCloser's acceptance rule, Aligner statistics (omega, eigen ratios) and SE(3) priors, all over the C++ mirror --
+    against the same flow written with the Python mirror.  Both are thin layers over the same C-ABI calls with the same arguments, so
+    every number must agree to the last digit printed (%.9g round-trips a float)."""
+    from g2o_frontend_amd import api, synth
+    from oracle import oracle as O          # parameter tables only
+    n, poses, frames, track, clos, hits_line, extras = _run_tracker_app(tmp_path)
 
     # the same flow with the Python mirror
     conv, alig = O.QVGA4_CONF_CONVERTER, O.QVGA4_CONF_ALIGNER

@@ -53,11 +53,12 @@ def test_oracle_statistics_against_float64_model(oracle):
 
 
 def test_product_host_statistics_match_oracle(oracle):
-    """pwn_hip_compute_statistics is host code of the product (no GPU needed)."""
+    """pwn_hip_compute_statistics is host code of the product (no GPU needed): the same operations in the same order as the oracle's
+    restatement of aligner.cpp:152-199, so for the same H and T the two agree to the last bit."""
     from g2o_frontend_amd import _lib
     L = _lib.lib()
     rng = np.random.default_rng(1)
-    for _ in range(20):
+    for _ in range(200):
         H, T = random_system(rng)
         o = oracle.compute_statistics(H, T)
         Hc = np.ascontiguousarray(H.T.reshape(-1)); Tc = np.ascontiguousarray(T.T.reshape(-1))
@@ -65,9 +66,37 @@ def test_product_host_statistics_match_oracle(oracle):
         L.pwn_hip_compute_statistics(Hc.ctypes.data_as(C.c_void_p), Tc.ctypes.data_as(C.c_void_p), mean.ctypes.data_as(C.c_void_p),
                                      om.ctypes.data_as(C.c_void_p), C.byref(tr), C.byref(rr))
         om = om.reshape(6, 6).T
-        assert np.abs(mean - o["mean"]).max() < 1e-6
-        assert np.abs(om - o["omega"]).max() <= 1e-4 * np.abs(o["omega"]).max()
-        assert abs(tr.value - o["translationalEigenRatio"]) <= 1e-4 * tr.value and abs(rr.value - o["rotationalEigenRatio"]) <= 1e-4 * rr.value
+        assert np.array_equal(mean, o["mean"]) and np.array_equal(om, o["omega"])
+        assert tr.value == o["translationalEigenRatio"] and rr.value == o["rotationalEigenRatio"]
+
+
+def omega_tolerance(oracle, H, T, dH_rel, n=24, seed=0):
+    """Per-entry tolerance for comparing omega = f(H, T) computed from two nearly equal H (GPU vs oracle sums of the same terms).
+    The reference's chain -- JacobiSVD solve, LLT, sigma points, 6x6 inverse, all in fp32 (aligner.cpp:172-190) -- is not a smooth function
+    of H at the level of its own rounding: moving H in its last bits moves omega_ij by the chain's rounding noise, which depends on the
+    conditioning of H and differs from entry to entry.  So the bar for entry (i, j) is measured, not guessed: the largest change of
+    omega_ij over `n` copies of H whose entries are disturbed by the relative amount `dH_rel` by which the two H actually differ
+    (at least 2^-22: last-bit noise), times 4, plus the first-order term 3 * dH_rel * max|H| (see below), plus 1e-6 of
+    sqrt(omega_ii omega_jj).  With the same iterate on both sides (dH_rel = 1e-5) this is ~6e-5 of max|omega|; free-running at
+    120x160, where a flipped correspondence moves H by up to 1e-2, it is correspondingly wider -- the width is the measured dH, not a guess."""
+    rng = np.random.default_rng(seed)
+    base = oracle.compute_statistics(H, T)
+    rel = max(float(dH_rel), 2.0 ** -22)
+    spread = np.zeros((6, 6)); ratio_spread = np.zeros(2)
+    for _ in range(n):
+        E = rng.uniform(-1, 1, size=(6, 6)); E = (E + E.T) / 2
+        Hp = (H.astype(np.float64) + rel * np.abs(H).max() * E).astype(np.float32)      # dH_rel is relative to max|H|, like the measured difference
+        sp = oracle.compute_statistics(Hp, T)
+        spread = np.maximum(spread, np.abs(sp["omega"].astype(np.float64) - base["omega"]))
+        ratio_spread = np.maximum(ratio_spread, [abs(sp["translationalEigenRatio"] - base["translationalEigenRatio"]),
+                                                 abs(sp["rotationalEigenRatio"] - base["rotationalEigenRatio"])])
+    d = np.sqrt(np.abs(np.diag(base["omega"]).astype(np.float64)))
+    # first-order term: omega = J^-T (H + I) J^-1 with J the Jacobian of the sigma-point remap p -> t2v(T v2t(p)^-1), |J| ~ 1 for the
+    # centimetre-scale T of this path, so an entry of omega moves by about what the entries of H moved (3x allows for |J| != 1 and for
+    # a structured difference -- a few whole correspondences -- that random symmetric noise of the same size does not model)
+    first_order = 3.0 * rel * float(np.abs(H).max())
+    ratios = np.array([base["translationalEigenRatio"], base["rotationalEigenRatio"]])
+    return 4 * spread + first_order + 1e-6 * np.outer(d, d), 4 * ratio_spread + (10.0 * rel + 1e-6) * ratios
 
 
 @pytest.mark.gpu
@@ -91,14 +120,35 @@ def test_align_statistics_match_oracle(oracle, name, seed):
     assert np.array_equal(plain["T"], g["T"]) and np.array_equal(plain["chi2"], g["chi2"])      # statistics do not disturb the alignment
     st = aligner._statistics
     hs = np.abs(os_["H"]).max()
-    tol = 1e-4 if name == "vga" else 2e-2          # free-running: one flipped correspondence at 120x160 is ~1e-4..1e-2 of H
-    assert np.abs(st["H"] - os_["H"]).max() <= tol * hs
-    assert np.abs(aligner.omega() - os_["omega"]).max() <= 10 * tol * np.abs(os_["omega"]).max()
-    assert abs(aligner.translationalEigenRatio() - os_["translationalEigenRatio"]) <= 10 * tol * os_["translationalEigenRatio"]
-    assert abs(aligner.rotationalEigenRatio() - os_["rotationalEigenRatio"]) <= 10 * tol * os_["rotationalEigenRatio"]
+    # (a) free-running: the two H are sums over correspondence sets that may differ by a few flipped correspondences (120x160: ~1e-4..1e-2
+    #     of H, VGA: below 1e-4); omega is compared entry by entry against a bar derived from how far the two H are apart (omega_tolerance)
+    tol = 1e-4 if name == "vga" else 2e-2
+    dH = np.abs(st["H"] - os_["H"]).max() / hs
+    assert dH <= tol
+    tol_om, tol_ratio = omega_tolerance(oracle, os_["H"], o["T"], dH)
+    d_om = np.abs(aligner.omega().astype(np.float64) - os_["omega"])
+    assert (d_om <= tol_om).all(), (d_om / tol_om).max()
+    assert abs(aligner.translationalEigenRatio() - os_["translationalEigenRatio"]) <= tol_ratio[0]
+    assert abs(aligner.rotationalEigenRatio() - os_["rotationalEigenRatio"]) <= tol_ratio[1]
     assert np.abs(st["mean"] - oracle.t2v(g["T"])).max() < 1e-4
     assert aligner.solutionValid() == (not (os_["rotationalEigenRatio"] > 50 or os_["translationalEigenRatio"] > 50))
-    # host statistics of the GPU's own H are what the host function gives for that H (exactly the same code path)
+    # (b) the 6x6 statistics of the GPU's own H and T are the oracle's for that H and T, bit for bit (same host arithmetic)
     again = oracle.compute_statistics(st["H"], g["T"])
-    assert np.abs(again["omega"] - aligner.omega()).max() <= 1e-3 * np.abs(again["omega"]).max()
+    assert np.array_equal(again["omega"], aligner.omega()) and np.array_equal(again["mean"], st["mean"])
+    assert again["translationalEigenRatio"] == aligner.translationalEigenRatio() and again["rotationalEigenRatio"] == aligner.rotationalEigenRatio()
+    # (c) teacher-forced: the extra Linearizer::update from the ORACLE's final transform (one outer iteration with that guess, then the
+    #     statistics pass at the result) is not available through the ABI; what is: H of pwn_hip_linearize on the oracle's last
+    #     correspondences at the oracle's final transform -- the same inputs on both sides: 1e-5 of max|H|, then omega within the bar of (a)
+    Tlast = o["iterations"][-1]["T_before"]                                     # the finder's transform of the last outer iteration
+    ri = oracle.project(K, Tlast, ap.min_distance, ap.max_distance, rows, cols, oref.arrays()["points"])
+    ci = oracle.project(K, np.eye(4), ap.min_distance, ap.max_distance, rows, cols, ocur.arrays()["points"])
+    corr, _ = oracle.correspondences(ap, oref, ocur, ri[0], ci[0], oracle.iso_inverse(Tlast))
+    invT = oracle.iso_inverse(o["T"])
+    lo = oracle.linearize(ap, oref, ocur, corr, invT)
+    lg = aligner.linearize(corr, invT)
+    assert np.abs(lg["H"] - lo["H"]).max() <= 1e-5 * np.abs(lo["H"]).max()
+    so, sg = oracle.compute_statistics(lo["H"], o["T"]), oracle.compute_statistics(lg["H"], o["T"])
+    tol_om, tol_ratio = omega_tolerance(oracle, lo["H"], o["T"], 1e-5, seed=1)
+    assert (np.abs(sg["omega"].astype(np.float64) - so["omega"]) <= tol_om).all()
+    assert abs(sg["translationalEigenRatio"] - so["translationalEigenRatio"]) <= tol_ratio[0] and abs(sg["rotationalEigenRatio"] - so["rotationalEigenRatio"]) <= tol_ratio[1]
     ctx.close()
