@@ -320,7 +320,16 @@ int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, h
     // throughput path: the integral planes are written once; a frame is a chain of strips * bands hand-over steps, so it
     // needs several frames in flight to fill the device
     { StageTimer t(ctx, "unproject", st);          // ordered compaction: valid pixels per (row, strip) and their offsets
-      hipLaunchKernelGGL(k_strip_count, dim3(cp.rows, n), dim3(256), 0, st, fr, cp);
+      // frames of one call are all raw uint16 or all float (convert_batch_impl); 16-byte loads need 16-byte aligned rows
+      const bool raw = ctx->frames_host[base].raw != nullptr;
+      bool aligned = cp.cols % (raw ? 8 : 4) == 0;
+      for (int i = 0; i < n && aligned; ++i) {
+        const FrameDesc& fd = ctx->frames_host[base + i];
+        aligned = ((uintptr_t)(raw ? (const void*)fd.raw : (const void*)fd.depth) & 15u) == 0;
+      }
+      if (aligned && raw) hipLaunchKernelGGL(k_strip_count<true>, dim3((cp.rows + 3) / 4, n), dim3(256), 0, st, fr, cp);
+      else if (aligned) hipLaunchKernelGGL(k_strip_count<false>, dim3((cp.rows + 3) / 4, n), dim3(256), 0, st, fr, cp);
+      else hipLaunchKernelGGL(k_strip_count_any, dim3(cp.rows, n), dim3(256), 0, st, fr, cp);
       hipLaunchKernelGGL(k_row_offsets, dim3(n), dim3(1024), 0, st, fr, cp.rows * strips_of(cp.cols)); }
     { StageTimer t(ctx, "integral", st);           // unProject + intervals + the three integral-image passes
       const unsigned epoch = ++ctx->convert_epoch;

@@ -150,6 +150,7 @@ __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 template <typename T> using gptr = T __attribute__((address_space(1)))*;
 template <typename T> __device__ __forceinline__ gptr<T> as_global(T* p) { return (gptr<T>)(uintptr_t)p; }
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 load4(gptr<const v4f> p) { const v4f v = *p; return make_float4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ void store4(gptr<v4f> p, const float4 v) { v4f t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *p = t; }
 // force a wave-uniform value into a scalar register
@@ -322,7 +323,8 @@ __global__ void __launch_bounds__(256) k_unproject(const FrameDesc* __restrict__
 // left-to-right order: one thread per (row, channel) chain, tiles staged through LDS so that all global
 // traffic is row-coalesced.  grid = (ceil(rows/16), frames), block = 256.
 #ifndef PWN_IR_ROWS
-#define PWN_IR_ROWS 16      // band height of the integral-image kernels (a multiple of 4: one row per compute wave and step)
+#define PWN_IR_ROWS 8       // band height of the integral-image kernels (a multiple of 4: one row per compute wave and step); measured on
+                           // MI355X: the hand-over wavefront of the strip kernel fills and drains in half the time with 8-row bands: -7 % against 16
 #endif
 constexpr int kIR_Rows = PWN_IR_ROWS, kIR_Cols = 64, kIR_Stride = kIR_Cols + 1;
 static_assert(kIR_Rows % 4 == 0 && (kIR_Rows & (kIR_Rows - 1)) == 0 && kIR_Rows <= 64, "band height");
@@ -522,8 +524,47 @@ __host__ __device__ __forceinline__ int strips_of(int cols) { return (cols + kIR
 __host__ __device__ __forceinline__ int bands_of(int rows) { return (rows + kIR_Rows - 1) / kIR_Rows; }
 
 // valid pixels per (row, 64-column strip); k_row_offsets over rows*strips entries turns them into point-index offsets.
-// grid = (rows, frames), block = 256
+// One wave per image row, 16 bytes per lane and load (8 uint16 or 4 float pixels), so a 640-pixel row is two (five) wave loads instead
+// of ten dependent 128-byte ones; the per-lane counts are summed over the 8 (16) lanes of a strip with xor shuffles (small integers:
+// exact).  Needs rows that start 16-byte aligned (cols % 8 == 0 resp. cols % 4 == 0), else k_strip_count_any.
+// grid = (ceil(rows / 4), frames), block = 256
+template <bool RAW>
 __global__ void __launch_bounds__(256) k_strip_count(const FrameDesc* __restrict__ frames, ConvertParams cp) {
+  const FrameDesc& f = frames[blockIdx.y];
+  const int wave = threadIdx.x >> 6, lane = lane_id();
+  const int r = blockIdx.x * 4 + wave, S = strips_of(cp.cols);
+  if (r >= cp.rows) return;
+  constexpr int PX = RAW ? 8 : 4;                      // pixels per lane and load
+  constexpr int LPS = kIR_Cols / PX;                   // lanes per strip
+  const float scale = f.raw_scale;
+  for (int c0 = 0; c0 < cp.cols; c0 += 64 * PX) {
+    const int c = c0 + lane * PX;
+    int cnt = 0;
+    if (c < cp.cols) {                                 // cols % PX == 0: a lane's pixels are all inside or all outside the row
+      float d[PX];
+      if (RAW) {
+        const v4u w = *(gptr<const v4u>)(as_global(f.raw) + ((size_t)r * cp.cols + c));
+        const unsigned u[4] = { w.x, w.y, w.z, w.w };
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned lo = u[k] & 0xFFFFu, hi = u[k] >> 16;
+          d[2 * k] = lo ? scale * (float)lo : 0.0f; d[2 * k + 1] = hi ? scale * (float)hi : 0.0f;      // pwn_static.cpp:54-68
+        }
+      } else {
+        const v4f w = *(gptr<const v4f>)(as_global(f.depth) + ((size_t)r * cp.cols + c));
+        d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
+      }
+#pragma unroll
+      for (int k = 0; k < PX; ++k) cnt += !(d[k] < cp.minD || d[k] > cp.maxD);
+    }
+#pragma unroll
+    for (int off = 1; off < LPS; off <<= 1) cnt += __shfl_xor(cnt, off, 64);
+    const int s = c / kIR_Cols;
+    if ((lane & (LPS - 1)) == 0 && c < cp.cols) f.rowoff[r * S + s] = cnt;
+  }
+}
+// any width / alignment.  grid = (rows, frames), block = 256
+__global__ void __launch_bounds__(256) k_strip_count_any(const FrameDesc* __restrict__ frames, ConvertParams cp) {
   const FrameDesc& f = frames[blockIdx.y];
   const int r = blockIdx.x, S = strips_of(cp.cols);
   const int wave = threadIdx.x >> 6, lane = lane_id();
@@ -548,6 +589,9 @@ __device__ __forceinline__ void lds_barrier() {
 // band, hand-over words of the current one) and passes the values on through LDS; it never stores to global memory.
 #ifndef PWN_II_X
 #define PWN_II_X 0   // timing experiments only: 1 = no plane stores, 2 = no point/index/interval stores, 4 = no hand-over wait
+#endif
+#ifndef PWN_II_NT
+#define PWN_II_NT 3  // 1 = non-temporal plane stores, 2 = non-temporal index/interval stores, 3 = both (measured: strip kernel -5 %, k_stats after it -4 %)
 #endif
 constexpr int kII_Threads = 320;
 __global__ void __launch_bounds__(kII_Threads) k_unproject_integral(const FrameDesc* __restrict__ frames, ConvertParams cp, int nframes,
@@ -675,8 +719,8 @@ __global__ void __launch_bounds__(kII_Threads) k_unproject_integral(const FrameD
             itv = (px > py) ? (int)px : (int)py;
           }
           if (!(PWN_II_X & 2) || idx == -12345) {
-          gindex[(unsigned)(r * cols + c)] = idx;
-          ginterval[(unsigned)(r * cols + c)] = itv; }
+          if (PWN_II_NT & 2) { __builtin_nontemporal_store(idx, gindex + (unsigned)(r * cols + c)); __builtin_nontemporal_store(itv, ginterval + (unsigned)(r * cols + c)); }
+          else { gindex[(unsigned)(r * cols + c)] = idx; ginterval[(unsigned)(r * cols + c)] = itv; } }
         }
 #pragma unroll
         for (int k = 0; k < kIntegralChannels; ++k) tile[(k * kIR_Rows + lr) * kIR_Stride + lane] = v[k];
@@ -720,7 +764,10 @@ __global__ void __launch_bounds__(kII_Threads) k_unproject_integral(const FrameD
           if (c < cols && (!(PWN_II_X & 1) || vc == 12345.678f)) {
             const gptr<float> dst = gintegral + ((size_t)ch * N + (size_t)r0 * cols + c);
 #pragma unroll
-            for (int r = 0; r < kIR_Rows; ++r) if (r0 + r < rows) dst[(unsigned)(r * cols)] = vals[r];
+            for (int r = 0; r < kIR_Rows; ++r) if (r0 + r < rows) {
+              if (PWN_II_NT & 1) __builtin_nontemporal_store(vals[r], dst + (unsigned)(r * cols));
+              else dst[(unsigned)(r * cols)] = vals[r];
+            }
           }
         }
       }

@@ -121,15 +121,18 @@ def test_align_statistics_match_oracle(oracle, name, seed):
     st = aligner._statistics
     hs = np.abs(os_["H"]).max()
     # (a) free-running: the two H are sums over correspondence sets that may differ by a few flipped correspondences (120x160: ~1e-4..1e-2
-    #     of H, VGA: below 1e-4); omega is compared entry by entry against a bar derived from how far the two H are apart (omega_tolerance)
+    #     of H, VGA: below 1e-4)
     tol = 1e-4 if name == "vga" else 2e-2
     dH = np.abs(st["H"] - os_["H"]).max() / hs
     assert dH <= tol
-    tol_om, tol_ratio = omega_tolerance(oracle, os_["H"], o["T"], dH)
-    d_om = np.abs(aligner.omega().astype(np.float64) - os_["omega"])
-    assert (d_om <= tol_om).all(), (d_om / tol_om).max()
-    assert abs(aligner.translationalEigenRatio() - os_["translationalEigenRatio"]) <= tol_ratio[0]
-    assert abs(aligner.rotationalEigenRatio() - os_["rotationalEigenRatio"]) <= tol_ratio[1]
+    # free-running, omega = f(H, T) differs through BOTH inputs (the two final transforms are 1e-5-class apart as well), so this leg only
+    # bounds the whole difference by the size of the input difference; the entry-by-entry bars are applied where the inputs are the same
+    # on both sides: (b) and (c) below
+    dT = np.abs(g["T"] - o["T"]).max()
+    rel_om = np.linalg.norm(aligner.omega().astype(np.float64) - os_["omega"]) / np.linalg.norm(os_["omega"].astype(np.float64))
+    assert rel_om <= 20 * dH + 100 * dT + 1e-4, (rel_om, dH, dT)
+    assert abs(aligner.translationalEigenRatio() - os_["translationalEigenRatio"]) <= (20 * dH + 100 * dT + 1e-3) * os_["translationalEigenRatio"]
+    assert abs(aligner.rotationalEigenRatio() - os_["rotationalEigenRatio"]) <= (20 * dH + 100 * dT + 1e-3) * os_["rotationalEigenRatio"]
     assert np.abs(st["mean"] - oracle.t2v(g["T"])).max() < 1e-4
     assert aligner.solutionValid() == (not (os_["rotationalEigenRatio"] > 50 or os_["translationalEigenRatio"] > 50))
     # (b) the 6x6 statistics of the GPU's own H and T are the oracle's for that H and T, bit for bit (same host arithmetic)
