@@ -55,6 +55,9 @@ def parse(argv=None):
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run only the CPU baseline leg and print its JSON")
     ap.add_argument("--no-profile", action="store_true", help="skip the serial profiled pass (roofline fields become 0)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the batch calls use in the timed region (1 = serial)")
+    ap.add_argument("--render-workers", type=int, default=0,
+                    help="processes that render the synthetic frames (0 = automatic; 1 = in this process: required under rocprofv3, whose preloaded "
+                         "library has initialised the GPU before Python starts -- no child process may be started from such a process)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="launcher / sharding / gather plumbing only, on the CPU with the gloo backend (no GPU, no kernels): used by tests")
     return ap.parse_args(argv)
@@ -139,12 +142,12 @@ def _render_job(job):
     return synth.render_depth_mm(seed, np.asarray(pose), rows, cols, K, hole_stream=hole_stream)
 
 
-def render_all(jobs, world):
+def render_all(jobs, world, workers=0):
     """the synthetic uint16 frames of all jobs, rendered by a pool of CPU processes (spawned before the GPU is initialised)"""
     import concurrent.futures as cf
     import multiprocessing as mp
     ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    workers = max(1, min(16, ncpu // max(world, 1), len(jobs)))
+    workers = max(1, min(16, ncpu // max(world, 1), len(jobs))) if workers <= 0 else workers
     if workers == 1:
         return [_render_job(j) for j in jobs]
     with cf.ProcessPoolExecutor(max_workers=workers, mp_context=mp.get_context("spawn")) as ex:
@@ -238,12 +241,15 @@ def cpu_baseline_child(args):
     for s in range(0, 3):
         ref_mm, cur_mm, _ = synth.make_pair(s, rows, cols, K)
         cr, _, _ = O.convert(cp, O.convert_16u_to_32f(ref_mm)); cc, _, _ = O.convert(cp, O.convert_16u_to_32f(cur_mm))
-        r64 = O.align(ap64, cr, cc)
+        r64 = O.align(ap64, cr, cc, images=True)
         r32 = O.align(apar, cr, cc)
+        import zlib
         traces.append({"seed": s, "chi2_fp64": [float(it["chi2_fp64"]) for it in r64["iterations"]],
                        "chi2_fp32_serial": [float(it["chi2"]) for it in r32["iterations"]], "T": r64["T"].astype(float).tolist(),
                        "T_before": [it["T_before"].astype(float).tolist() for it in r64["iterations"]],
-                       "counters": [[int(it["K"]), int(it["C"]), int(it["inliers"])] for it in r64["iterations"]]})
+                       "counters": [[int(it["K"]), int(it["C"]), int(it["inliers"])] for it in r64["iterations"]],
+                       # the finder's index images of the last outer iteration (the bit-exact contract of the projector)
+                       "index_crc": [zlib.crc32(np.ascontiguousarray(r64["ref_index"]).tobytes()), zlib.crc32(np.ascontiguousarray(r64["cur_index"]).tobytes())]})
     out["chi2_traces"] = traces
     print(json.dumps(out))
 
@@ -506,7 +512,8 @@ def chi2_match(traces, res, w=None):
     if w is not None and traces and "T_before" in traces[0]:
         al = w.aligner
         outer, guess = al._outerIterations, al._initialGuess.copy()
-        worst_tf, counters_equal, n_it = 0.0, True, 0
+        import zlib
+        worst_tf, counters_equal, index_equal, n_it = 0.0, True, True, 0
         al.setOuterIterations(1)
         try:
             for t in traces:
@@ -514,14 +521,20 @@ def chi2_match(traces, res, w=None):
                 al.setReferenceCloud(w.refs[i]); al.setCurrentCloud(w.curs[i])
                 for k, Tb in enumerate(t["T_before"]):
                     al.setInitialGuess(np.asarray(Tb, np.float32))
-                    g = al.align()
+                    last = k == len(t["T_before"]) - 1 and "index_crc" in t
+                    g = al.align(images=last)
                     worst_tf = max(worst_tf, abs(float(g["chi2"][0]) - t["chi2_fp64"][k]) / max(t["chi2_fp64"][k], 1e-30))
                     counters_equal = counters_equal and [int(g["K"][0]), int(g["C"][0]), int(g["iter_inliers"][0])] == t["counters"][k]
+                    if last:
+                        f = al.correspondenceFinder()
+                        index_equal = index_equal and [zlib.crc32(f.referenceIndexImage().tobytes()), zlib.crc32(f.currentIndexImage().tobytes())] == t["index_crc"]
                     n_it += 1
         finally:
             al.setOuterIterations(outer); al.setInitialGuess(guess)
         out.update(mode="teacher-forced: each oracle iteration re-run on the GPU from the oracle's iterate (same inputs both sides)",
-                   max_rel_diff=worst_tf, iterations_checked=n_it, counters_equal=bool(counters_equal), ok=bool(worst_tf <= 1e-5 and counters_equal))
+                   max_rel_diff=worst_tf, iterations_checked=n_it, counters_equal=bool(counters_equal),
+                   projector_index_images_bit_exact=bool(index_equal), ok=bool(worst_tf <= 1e-5 and counters_equal and index_equal),
+                   canonical_choices="single-thread semantics of the finder / linearizer; eigensolver trig by the shared double-precision algorithm (DESIGN.md section 2)")
     else:
         out.update(mode="free-running only", max_rel_diff=worst64, ok=bool(worst64 <= 1e-5))
     return out
@@ -600,7 +613,7 @@ def main():
     if extras_on and not args.no_tracker and (rows, cols) == (480, 640):
         poses = synth.trajectory_sweep(9, args.tracker_frames)
         jobs += [("frame", 9, poses[k].tolist(), 480, 640, synth.K_VGA, k) for k in range(args.tracker_frames)]
-    rendered = render_all(jobs, world)
+    rendered = render_all(jobs, world, args.render_workers)
     frames_mm = rendered[:P]; frames5 = rendered[P:P + n5]; frames_trk = rendered[P + n5:]
 
     import torch

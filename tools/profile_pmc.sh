@@ -3,7 +3,8 @@
 # usage (on the GPU box, from the repo root): bash tools/profile_pmc.sh <outdir> [bench args...]
 set -u
 OUT=${1:-gpurun_out/pmc}; shift || true
-ARGS=${@:---pairs 128 --steps 1 --warmup 1 --no-cpu-baseline --no-latency --no-profile --streams 1}
+# no child processes under rocprofv3 (its preloaded library has initialised the GPU): no CPU baseline child, frames rendered in-process
+ARGS=${@:---pairs 128 --steps 1 --warmup 1 --no-cpu-baseline --no-latency --no-profile --no-extras --render-workers 1 --streams 1}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
 run() { name=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d "$OUT/$name" -- python3 bench.py $ARGS > "$OUT/$name.json" 2> "$OUT/$name.err"; }
