@@ -1082,9 +1082,9 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
   const int sub = plan.sub;
   if (int rc = ensure_desc(ctx, n)) return rc;
   HIPCHK(ctx, hipEventRecord(ctx->t0, ctx->stream), PWN_HIP_ERR_LAUNCH);
-  // Batch calls that do not need the current depth image afterwards (no matchClouds score, no finder images: those belong to single
-  // alignments) skip the projection of a current cloud whose own index image is that projection's result.
-  const bool batch_shortcut = n > 1 && !scores && is_identity(forced(p->current_sensor_offset));
+  // Batch calls (the finder's images belong to single alignments) skip the projection of a current cloud whose own index image is that
+  // projection's result; the matchClouds score then reads the current depth image off the cloud itself (k_match_score, curOwn).
+  const bool batch_shortcut = n > 1 && is_identity(forced(p->current_sensor_offset));
   std::vector<char> own_index((size_t)std::max(n, 1), 0), own_ref((size_t)std::max(n, 1), 0);
   const bool ident_ref = is_identity(forced(p->reference_sensor_offset));
   // descriptors + initial states of all pairs; workspace slots are reused round-robin across sub-batches
@@ -1188,7 +1188,7 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
     if (scores && p->outer_iterations > 0) {
       StageTimer t(ctx, "match_score", st);     // the z-buffers of this sub-batch still hold the finder's last depth images
       hipLaunchKernelGGL(k_match_score, dim3(std::min((N + 255) / 256, 256), m), dim3(256), 0, st, pr, N, subLastRefTag, subTag0, 1000.0f,
-                         match_threshold, ctx->match_dev + base);
+                         match_threshold, ctx->match_dev + base, sub_own[kk] ? 1 : 0);
     }
     HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
   }
@@ -1362,7 +1362,7 @@ int pwn_hip_match_score(pwn_hip_ctx* ctx, float threshold, pwn_hip_match_result*
   HIPCHK(ctx, hipMemcpyAsync(ctx->pairs_dev, ctx->pairs_host, sizeof(PairDesc), hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipMemsetAsync(ctx->match_dev, 0, sizeof(MatchAcc), ctx->stream), PWN_HIP_ERR_COPY);
   hipLaunchKernelGGL(k_match_score, dim3(std::min((N + 255) / 256, 256), 1), dim3(256), 0, ctx->stream, ctx->pairs_dev, N, ctx->img_ref_tag, ctx->img_cur_tag, 1000.0f,
-                     threshold, ctx->match_dev);
+                     threshold, ctx->match_dev, 0);
   HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
   HIPCHK(ctx, hipMemcpyAsync(ctx->match_host, ctx->match_dev, sizeof(MatchAcc), hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);

@@ -1577,12 +1577,19 @@ __global__ void __launch_bounds__(kAlignBlock) k_linearize_list(CloudDev ref, Cl
 // exactly in 1/64 fixed point with integer atomics -> bitwise reproducible.  out[pair] = {nonZeros, inliers, sum64, tiny}.
 struct MatchAcc { unsigned long long nonZeros, inliers; long long sum64; unsigned long long tiny; };
 __device__ __forceinline__ unsigned short depth_to_u16(float d, float scale) { return (d < FLT_MAX) ? (unsigned short)(scale * d) : (unsigned short)0; }
+// curOwn: the current cloud was not projected (batch path, identity current offset): its depth image is read off the cloud through its
+// own index image -- pixel -> point -> z.  With an identity offset the projector's depth is the point's z bit for bit (row 2 of K*R
+// is (0, 0, 1), K*t is 0: d = ((0*x + 0*y) + 1*z) + 0*1), and every point lands on its own pixel (see pwn_hip_cloud::idximg).
 __global__ void __launch_bounds__(256) k_match_score(const PairDesc* __restrict__ pairs, int n, unsigned refTag, unsigned curTag, float scale,
-                                                     float threshold, MatchAcc* __restrict__ out) {
+                                                     float threshold, MatchAcc* __restrict__ out, int curOwn) {
   const PairDesc& pd = pairs[blockIdx.y];
   int nz = 0, inl = 0; long long sum = 0; int tiny = 0;
+  const int ncur = curOwn ? min(*pd.cur.count, pd.cur.capacity) : 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    const unsigned short c = depth_to_u16(zkey_depth(pd.zcur[i], curTag), scale);
+    float dc;
+    if (curOwn) { const int ci = pd.curidx[i]; dc = (ci >= 0 && ci < ncur) ? pd.cur.P[ci].z : FLT_MAX; }
+    else dc = zkey_depth(pd.zcur[i], curTag);
+    const unsigned short c = depth_to_u16(dc, scale);
     const unsigned short r = depth_to_u16(zkey_depth(pd.zref[i], refTag), scale);
     if (c > 0 && r > 0) {
       ++nz;

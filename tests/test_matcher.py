@@ -137,10 +137,21 @@ def test_matchCloudsBatch_equals_single(ctx, oracle):
         mm = synth.render_depth_mm(31, pose, rows, cols, K, hole_stream=k + 1)
         c, _, _, _ = matcher.makeCloud(Km, I, oracle.convert_16u_to_32f(mm))
         others.append(c); guesses.append(np.eye(4))
-    single = [matcher.matchClouds(current, o, I, I, Km, rows, cols, g) for o, g in zip(others, guesses)]
-    batch = matcher.matchCloudsBatch([current] * 3, others, I, I, Km, rows, cols, guesses)
+    # identity guesses: the batch path takes the clouds' own index images for the current projection and the first reference projection and
+    # reads the current depth image of the score off the cloud; non-identity guesses: only the current side.  Both must equal the single calls
+    # (which project everything) bit for bit.
+    moved = [synth.v2t(np.array([0.01 * (k + 1), -0.005, 0.0, 0.002, -0.001 * k, 0.001])) for k in range(3)]
+    for gs in (guesses, moved):
+        single = [matcher.matchClouds(current, o, I, I, Km, rows, cols, g) for o, g in zip(others, gs)]
+        batch = matcher.matchCloudsBatch([current] * 3, others, I, I, Km, rows, cols, gs)
+        for s, b in zip(single, batch):
+            assert np.array_equal(s["transform"], b["transform"])
+            for k in ("image_nonZeros", "image_outliers", "image_inliers", "cloud_inliers"):
+                assert s[k] == b[k], k
+            assert s["image_reprojectionDistance"] == b["image_reprojectionDistance"]
+    # the same with the roles swapped: many currents against one reference
+    single = [matcher.matchClouds(o, current, I, I, Km, rows, cols, g) for o, g in zip(others, moved)]
+    batch = matcher.matchCloudsBatch(others, [current] * 3, I, I, Km, rows, cols, moved)
     for s, b in zip(single, batch):
-        assert np.array_equal(s["transform"], b["transform"])
-        for k in ("image_nonZeros", "image_outliers", "image_inliers", "cloud_inliers"):
-            assert s[k] == b[k], k
+        assert np.array_equal(s["transform"], b["transform"]) and s["image_nonZeros"] == b["image_nonZeros"] and s["image_inliers"] == b["image_inliers"]
         assert s["image_reprojectionDistance"] == b["image_reprojectionDistance"]
