@@ -66,7 +66,9 @@ struct pwn_hip_ctx {
   unsigned convert_epoch = 0; int* fault_dev = nullptr;
   int spin_limit = kSpinLimit; int dbg_withhold = -1;        // pwn_hip_debug_withhold_carry (test hook)
   // align workspaces (per slot)
-  unsigned long long* zref_ws = nullptr; unsigned long long* zcur_ws = nullptr; int* curidx_ws = nullptr; double* partials_ws = nullptr; PairState* state_ws = nullptr;
+  unsigned long long* zref_ws = nullptr;        // 64-bit z-buffer of the stand-alone projection and of Merger::merge (one image)
+  unsigned* z32ref_ws = nullptr; unsigned* z32cur_ws = nullptr;      // the aligner's 32-bit z-buffers (tag | index), one image per slot
+  int* curidx_ws = nullptr; double* partials_ws = nullptr; PairState* state_ws = nullptr;
   int nblocks_max = 0;
   // descriptors (one entry per frame / pair of a batch call; grown on demand)
   int desc_cap = 0;
@@ -78,10 +80,12 @@ struct pwn_hip_ctx {
   SolveOut* solve_dev = nullptr; int* counters_dev = nullptr; int2* corr_ws = nullptr; int* scratch_count = nullptr;
   float* io_ws = nullptr;   // N*16 floats staging for cloud up/download
   // images of the last single align
-  int img_rows = 0, img_cols = 0; bool img_valid = false; unsigned img_ref_tag = kZTag0, img_cur_tag = kZTag0;
+  int img_rows = 0, img_cols = 0; bool img_valid = false; unsigned img_ref_tag = kZ32Tag0, img_cur_tag = kZ32Tag0;
+  int img_pair = 0;                         // descriptor (pairs_host / pairs_dev entry) of the pair whose images sit in workspace slot 0
   // z-buffer epoch tags are handed out in descending order ACROSS batch calls (a smaller tag wins, so whatever earlier calls left in
   // the buffers reads as empty): the buffers are cleared only when the 12-bit tag space is used up, not once per alignment
-  unsigned ztag_next = 0;
+  unsigned ztag_next = 0;                   // 64-bit buffer (scene stage)
+  unsigned z32tag_next = 0;                 // 32-bit buffers (aligner)
   std::string err;
   bool profiling = false;
   std::map<std::string, StageAcc> stages;
@@ -116,6 +120,12 @@ template <bool SAME_T, bool FULL_H>
 void launch_corr_linearize(const pwn_hip_ctx* ctx, int nb, int m, hipStream_t st, const PairDesc* pr, const AlignParams& ap, unsigned tag, int usePrevTc, int ownRef) {
   if ((long long)nb * m <= ctx->num_cus) hipLaunchKernelGGL((k_corr_linearize_lat<SAME_T, FULL_H>), dim3(nb, m), dim3(kLatBlock), 0, st, pr, ap, tag, usePrevTc, ownRef);
   else hipLaunchKernelGGL((k_corr_linearize<SAME_T, FULL_H>), dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, tag, usePrevTc, ownRef);
+}
+
+// projection of one cloud of each of the m pairs (which: 0 = reference, 1 = current): four points per thread when the launch is large
+void launch_project(int capacity, int m, hipStream_t st, const PairDesc* pr, const AlignParams& ap, int which, unsigned tag) {
+  if (m >= 8) hipLaunchKernelGGL((k_project<4>), dim3((capacity + 1023) / 1024, m), dim3(256), 0, st, pr, ap, which, tag);
+  else hipLaunchKernelGGL((k_project<1>), dim3((capacity + 255) / 256, m), dim3(256), 0, st, pr, ap, which, tag);
 }
 
 int fail(pwn_hip_ctx* ctx, int code, const std::string& msg) {
@@ -260,16 +270,27 @@ int check_image(pwn_hip_ctx* ctx, int rows, int cols) {
     return fail(ctx, PWN_HIP_ERR_CAPACITY, "image larger than the context was created for");
   return PWN_HIP_OK;
 }
-// first (largest) of `need` consecutive descending z-buffer tags; clears every slot of both z-buffers when the tag space is used up
+// first (largest) of `need` consecutive descending tags of the 64-bit z-buffer (scene stage); clears it when the tag space is used up
 int take_tags(pwn_hip_ctx* ctx, unsigned need, unsigned* first) {
-  if (need > kZTag0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "more projections per alignment than z-buffer epoch tags");
+  if (need > kZTag0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "more projections than z-buffer epoch tags");
   if (ctx->ztag_next < need) {
-    HIPCHK(ctx, hipMemsetAsync(ctx->zref_ws, 0xFF, (size_t)ctx->max_batch * ctx->N * 8, ctx->stream), PWN_HIP_ERR_COPY);
-    HIPCHK(ctx, hipMemsetAsync(ctx->zcur_ws, 0xFF, (size_t)ctx->max_batch * ctx->N * 8, ctx->stream), PWN_HIP_ERR_COPY);
+    HIPCHK(ctx, hipMemsetAsync(ctx->zref_ws, 0xFF, ctx->N * 8, ctx->stream), PWN_HIP_ERR_COPY);
     ctx->ztag_next = kZTag0;
   }
   *first = ctx->ztag_next;
   ctx->ztag_next -= need;
+  return PWN_HIP_OK;
+}
+// the same for the aligner's 32-bit z-buffers (11-bit tags): clears every slot of both when the tag space is used up
+int take_tags32(pwn_hip_ctx* ctx, unsigned need, unsigned* first) {
+  if (need > kZ32Tag0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "more projections per alignment than z-buffer epoch tags");
+  if (ctx->z32tag_next < need) {
+    HIPCHK(ctx, hipMemsetAsync(ctx->z32ref_ws, 0xFF, (size_t)ctx->max_batch * ctx->N * 4, ctx->stream), PWN_HIP_ERR_COPY);
+    HIPCHK(ctx, hipMemsetAsync(ctx->z32cur_ws, 0xFF, (size_t)ctx->max_batch * ctx->N * 4, ctx->stream), PWN_HIP_ERR_COPY);
+    ctx->z32tag_next = kZ32Tag0;
+  }
+  *first = ctx->z32tag_next;
+  ctx->z32tag_next -= need;
   return PWN_HIP_OK;
 }
 int align_nblocks(int N) { return (N + kAlignBlock * kPixPerThread - 1) / (kAlignBlock * kPixPerThread); }
@@ -537,8 +558,9 @@ int pwn_hip_ctx_create(pwn_hip_ctx** out, int device, int max_rows, int max_cols
   ALLOC(ctx->fault_dev, sizeof(int));
   if (hipMemset(ctx->carry_ws, 0, B * ctx->carry_slot * sizeof(unsigned long long)) != hipSuccess || hipMemset(ctx->fault_dev, 0, sizeof(int)) != hipSuccess) {
     pwn_hip_ctx_destroy(ctx); return fail(nullptr, PWN_HIP_ERR_ALLOCATION, "hipMemset of the hand-over workspace failed"); }
-  ALLOC(ctx->zref_ws, B * N * sizeof(unsigned long long));
-  ALLOC(ctx->zcur_ws, B * N * sizeof(unsigned long long));
+  ALLOC(ctx->zref_ws, N * sizeof(unsigned long long));
+  ALLOC(ctx->z32ref_ws, B * N * sizeof(unsigned));
+  ALLOC(ctx->z32cur_ws, B * N * sizeof(unsigned));
   ALLOC(ctx->curidx_ws, B * N * sizeof(int));
   ALLOC(ctx->partials_ws, B * (size_t)ctx->nblocks_max * kAccN * sizeof(double));
   ALLOC(ctx->solve_dev, sizeof(SolveOut));
@@ -557,7 +579,7 @@ int pwn_hip_ctx_destroy(pwn_hip_ctx* ctx) {
   if (!ctx) return PWN_HIP_OK;
   (void)hipSetDevice(ctx->device);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  void* dev[] = { ctx->depth_ws, ctx->raw_ws, ctx->index_ws, ctx->interval_ws, ctx->integral_ws, ctx->rowoff_ws, ctx->carry_ws, ctx->fault_dev, ctx->zref_ws, ctx->zcur_ws, ctx->curidx_ws,
+  void* dev[] = { ctx->depth_ws, ctx->raw_ws, ctx->index_ws, ctx->interval_ws, ctx->integral_ws, ctx->rowoff_ws, ctx->carry_ws, ctx->fault_dev, ctx->zref_ws, ctx->z32ref_ws, ctx->z32cur_ws, ctx->curidx_ws,
                   ctx->partials_ws, ctx->state_ws, ctx->frames_dev, ctx->pairs_dev, ctx->raw_dev, ctx->counts_dev, ctx->solve_dev, ctx->counters_dev,
                   ctx->corr_ws, ctx->scratch_count, ctx->io_ws };
   for (void* p : dev) if (p) (void)hipFree(p);
@@ -1094,8 +1116,8 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
     const int slot = plan.slot0(i / sub) + i % sub;
     PairDesc& pd = ctx->pairs_host[i];
     pd.ref = r->d; pd.cur = c->d;
-    pd.zref = ctx->zref_ws + (size_t)slot * ctx->N;
-    pd.zcur = ctx->zcur_ws + (size_t)slot * ctx->N;
+    pd.zref = ctx->z32ref_ws + (size_t)slot * ctx->N;
+    pd.zcur = ctx->z32cur_ws + (size_t)slot * ctx->N;
     pd.curidx = ctx->curidx_ws + (size_t)slot * ctx->N;
     // the converter's own index image is what projecting the current cloud would give (see pwn_hip_cloud::idximg)
     pd.refidx0 = nullptr;
@@ -1117,6 +1139,7 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
     st.invT = st.invTcorr; set_last_row(st.invT);
     Mat4 iKRt; Mat3 iK;
     projector_matrices(ap.K, iso_mul(T, ap.refOffset), st.KRt, iKRt, iK);
+    st.KRtLast = st.KRt;
     projector_matrices(ap.K, mat4_from(p->current_sensor_offset), st.KRtCur, iKRt, iK);
     st.it = 0;
   }
@@ -1138,11 +1161,12 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
   // more sub-batches than the tag space holds falls back to the fixed tags and clears the slots of every sub-batch.
   const unsigned tagsPerSub = (unsigned)std::max(1, p->outer_iterations);
   const unsigned nsub = (unsigned)((n + sub - 1) / sub);
-  const bool rolling = (unsigned long long)nsub * tagsPerSub <= kZTag0;
-  unsigned tagBase = kZTag0;
-  if (rolling && nsub > 0) { if (int rc = take_tags(ctx, nsub * tagsPerSub, &tagBase)) return rc; }
+  if (tagsPerSub > kZ32Tag0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "more projections per alignment than z-buffer epoch tags");
+  const bool rolling = (unsigned long long)nsub * tagsPerSub <= kZ32Tag0;
+  unsigned tagBase = kZ32Tag0;
+  if (rolling && nsub > 0) { if (int rc = take_tags32(ctx, nsub * tagsPerSub, &tagBase)) return rc; }
   // fixed tags leave words in the buffers that could beat (smaller tag wins) the tags a later rolling call draws: make that call clear first
-  if (!rolling) ctx->ztag_next = 0;
+  if (!rolling) ctx->z32tag_next = 0;
   unsigned tag0 = tagBase, lastRefTag = tag0 - (tagsPerSub - 1);
   if (int rc = plan_fork(ctx, plan)) return rc;
   for (int base = 0, kk = 0; base < n; base += sub, ++kk) {
@@ -1152,22 +1176,22 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
     const size_t s0 = (size_t)plan.slot0(kk);
     int maxcap_ref = 0, maxcap_cur = 0;
     for (int i = 0; i < m; ++i) { maxcap_ref = std::max(maxcap_ref, refs[base + i]->d.capacity); maxcap_cur = std::max(maxcap_cur, curs[base + i]->d.capacity); }
-    const unsigned subTag0 = rolling ? tagBase - (unsigned)kk * tagsPerSub : kZTag0;
+    const unsigned subTag0 = rolling ? tagBase - (unsigned)kk * tagsPerSub : kZ32Tag0;
     if (!rolling) {      // z-buffers start empty; slots are contiguous
-      HIPCHK(ctx, hipMemsetAsync(ctx->zref_ws + s0 * ctx->N, 0xFF, (size_t)m * ctx->N * 8, st), PWN_HIP_ERR_COPY);
-      HIPCHK(ctx, hipMemsetAsync(ctx->zcur_ws + s0 * ctx->N, 0xFF, (size_t)m * ctx->N * 8, st), PWN_HIP_ERR_COPY);
+      HIPCHK(ctx, hipMemsetAsync(ctx->z32ref_ws + s0 * ctx->N, 0xFF, (size_t)m * ctx->N * 4, st), PWN_HIP_ERR_COPY);
+      HIPCHK(ctx, hipMemsetAsync(ctx->z32cur_ws + s0 * ctx->N, 0xFF, (size_t)m * ctx->N * 4, st), PWN_HIP_ERR_COPY);
     }
-    if (s0 == 0 || kk == 0) { tag0 = subTag0; lastRefTag = subTag0 - (tagsPerSub - 1); }     // slot 0: what pwn_hip_align_images / pwn_hip_match_score read
+    if (s0 == 0 || kk == 0) { tag0 = subTag0; lastRefTag = subTag0 - (tagsPerSub - 1); ctx->img_pair = base; }     // slot 0: what pwn_hip_align_images / pwn_hip_match_score read
     const unsigned subLastRefTag = subTag0 - (tagsPerSub - 1);
     if (!sub_own[kk]) {
       StageTimer t(ctx, "project_cur", st);
-      hipLaunchKernelGGL(k_project, dim3((maxcap_cur + 256 * kProjectPointsPerThread - 1) / (256 * kProjectPointsPerThread), m), dim3(256), 0, st, pr, ap, 1, subTag0);
+      launch_project(maxcap_cur, m, st, pr, ap, 1, subTag0);
       hipLaunchKernelGGL(k_resolve_cur, dim3(std::min((N + 255) / 256, 1024), m), dim3(256), 0, st, pr, N, subTag0); }
     for (int i = 0; i < p->outer_iterations; ++i) {
       const unsigned tag = subTag0 - (unsigned)i;      // epoch of this outer iteration's reference projection
       const int ownRef = (i == 0 && sub_ownref[kk]) ? 1 : 0;
       if (!ownRef) { StageTimer t(ctx, "project_ref", st);
-        hipLaunchKernelGGL(k_project, dim3((maxcap_ref + 256 * kProjectPointsPerThread - 1) / (256 * kProjectPointsPerThread), m), dim3(256), 0, st, pr, ap, 0, tag); }
+        launch_project(maxcap_ref, m, st, pr, ap, 0, tag); }
       for (int k = 0; k < p->inner_iterations; ++k) {
         const bool lastInner = (k == p->inner_iterations - 1);
         { StageTimer t(ctx, "corr_linearize", st);
@@ -1266,7 +1290,9 @@ int pwn_hip_align_with_priors_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params*
   hipStream_t st = ctx->stream;
   PairDesc& pd = ctx->pairs_host[0];
   pd.ref = ref->d; pd.cur = cur->d;
-  pd.zref = ctx->zref_ws; pd.zcur = ctx->zcur_ws; pd.curidx = ctx->curidx_ws; pd.partials = ctx->partials_ws; pd.state = ctx->state_ws;
+  pd.zref = ctx->z32ref_ws; pd.zcur = ctx->z32cur_ws; pd.curidx = ctx->curidx_ws; pd.partials = ctx->partials_ws; pd.state = ctx->state_ws;
+  pd.refidx0 = nullptr;
+  ctx->img_pair = 0;
   PairState& hs = ctx->state_host[0];
   std::memset(&hs, 0, sizeof(hs));
   Mat4 T = mat4_from(p->initial_guess); set_last_row(T);
@@ -1277,9 +1303,9 @@ int pwn_hip_align_with_priors_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params*
   HIPCHK(ctx, hipMemcpyAsync(ctx->state_ws, &hs, sizeof(PairState), hipMemcpyHostToDevice, st), PWN_HIP_ERR_COPY);
   // z-buffer tags come from the context's running supply like the batch path's (a smaller tag wins atomicMin: fixed tags would
   // leave words behind that beat a later call's)
-  unsigned tag0 = kZTag0;
-  if (int rc = take_tags(ctx, (unsigned)std::max(1, p->outer_iterations), &tag0)) return rc;
-  hipLaunchKernelGGL(k_project, dim3((cur->d.capacity + 256 * kProjectPointsPerThread - 1) / (256 * kProjectPointsPerThread), 1), dim3(256), 0, st, ctx->pairs_dev, ap, 1, tag0);
+  unsigned tag0 = kZ32Tag0;
+  if (int rc = take_tags32(ctx, (unsigned)std::max(1, p->outer_iterations), &tag0)) return rc;
+  launch_project(cur->d.capacity, 1, st, ctx->pairs_dev, ap, 1, tag0);
   hipLaunchKernelGGL(k_resolve_cur, dim3(std::min((N + 255) / 256, 1024), 1), dim3(256), 0, st, ctx->pairs_dev, N, tag0);
   std::memset(result, 0, sizeof(*result));
   int it = 0;
@@ -1288,12 +1314,13 @@ int pwn_hip_align_with_priors_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params*
     set_last_row(T);                                                                 // aligner.cpp:72
     hs.T = T; hs.invTcorr = iso_inverse(T);
     projector_matrices(ap.K, iso_mul(T, ap.refOffset), hs.KRt, iKRt, iK);            // :73
+    hs.KRtLast = hs.KRt;
     Mat4 invT = iso_inverse(T);                                                      // :84
     for (int k = 0; k < p->inner_iterations; ++k, ++it) {
       set_last_row(invT);                                                            // :86
       hs.invT = invT;
       HIPCHK(ctx, hipMemcpyAsync(ctx->state_ws, &hs, sizeof(PairState), hipMemcpyHostToDevice, st), PWN_HIP_ERR_COPY);
-      if (k == 0) hipLaunchKernelGGL(k_project, dim3((ref->d.capacity + 256 * kProjectPointsPerThread - 1) / (256 * kProjectPointsPerThread), 1), dim3(256), 0, st, ctx->pairs_dev, ap, 0, tag);
+      if (k == 0) launch_project(ref->d.capacity, 1, st, ctx->pairs_dev, ap, 0, tag);
       if (k == 0) launch_corr_linearize<true, true>(ctx, nb, 1, st, ctx->pairs_dev, ap, tag, 0, 0);
       else launch_corr_linearize<false, true>(ctx, nb, 1, st, ctx->pairs_dev, ap, tag, 0, 0);
       hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, st, ctx->pairs_dev, nb, ctx->stats_dev);
@@ -1358,11 +1385,10 @@ int pwn_hip_match_score(pwn_hip_ctx* ctx, float threshold, pwn_hip_match_result*
   if (!ctx || !out) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if (!ctx->img_valid) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "no alignment has run on this context");
   const int N = ctx->img_rows * ctx->img_cols;
-  ctx->pairs_host[0].zref = ctx->zref_ws; ctx->pairs_host[0].zcur = ctx->zcur_ws;       // slot 0 = the pair of the last single align
-  HIPCHK(ctx, hipMemcpyAsync(ctx->pairs_dev, ctx->pairs_host, sizeof(PairDesc), hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
+  // the descriptor of the pair in slot 0 is still in pairs_dev (clouds, z-buffers, state with the projection matrices)
   HIPCHK(ctx, hipMemsetAsync(ctx->match_dev, 0, sizeof(MatchAcc), ctx->stream), PWN_HIP_ERR_COPY);
-  hipLaunchKernelGGL(k_match_score, dim3(std::min((N + 255) / 256, 256), 1), dim3(256), 0, ctx->stream, ctx->pairs_dev, N, ctx->img_ref_tag, ctx->img_cur_tag, 1000.0f,
-                     threshold, ctx->match_dev, 0);
+  hipLaunchKernelGGL(k_match_score, dim3(std::min((N + 255) / 256, 256), 1), dim3(256), 0, ctx->stream, ctx->pairs_dev + ctx->img_pair, N, ctx->img_ref_tag,
+                     ctx->img_cur_tag, 1000.0f, threshold, ctx->match_dev, 0);
   HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
   HIPCHK(ctx, hipMemcpyAsync(ctx->match_host, ctx->match_dev, sizeof(MatchAcc), hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
@@ -1381,11 +1407,10 @@ int pwn_hip_align_images(pwn_hip_ctx* ctx, int* ref_index, float* ref_depth, int
   for (int pass = 0; pass < 2; ++pass) {
     int* oi = pass == 0 ? ref_index : cur_index; float* od = pass == 0 ? ref_depth : cur_depth;
     if (!oi && !od) continue;
-    const unsigned long long* z = pass == 0 ? ctx->zref_ws : ctx->zcur_ws;   // slot 0 = last pair of the last sub-batch... single align: the pair
     int* di = oi ? (is_device_ptr(oi) ? oi : ctx->index_ws) : nullptr;
     float* dd = od ? (is_device_ptr(od) ? od : ctx->depth_ws) : nullptr;
-    hipLaunchKernelGGL(k_zbuf_resolve, dim3((unsigned)std::min<size_t>((N + 255) / 256, 2048)), dim3(256), 0, ctx->stream, z, (int)N, di, dd,
-                       pass == 0 ? ctx->img_ref_tag : ctx->img_cur_tag);
+    hipLaunchKernelGGL(k_pair_images, dim3((unsigned)std::min<size_t>((N + 255) / 256, 2048)), dim3(256), 0, ctx->stream, ctx->pairs_dev + ctx->img_pair, pass,
+                       pass == 0 ? ctx->img_ref_tag : ctx->img_cur_tag, (int)N, di, dd);
     HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
     if (oi && di != oi) HIPCHK(ctx, hipMemcpyAsync(oi, di, N * 4, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
     if (od && dd != od) HIPCHK(ctx, hipMemcpyAsync(od, dd, N * 4, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);

@@ -8,7 +8,8 @@
 //           Om[k*cap + i], k = 3*r + c                     (point information matrix, 9 planes)
 //   images: row-major int32 / float32, lanes along image x (row-coalesced loads)
 //   integral image: 10 planes [ch][rows][cols] (x y z n xx xy xz yy yz zz)
-//   z-buffer: uint64 per pixel = epoch tag (12 b) | float_bits(depth) (31 b) | point index (21 b); empty = ~0
+//   z-buffer of the aligner: uint32 per pixel = epoch tag (11 b) | point index (21 b), empty = ~0 (kZ32Tag0);
+//   z-buffer of the stand-alone projection / Merger: uint64 = epoch tag (12 b) | float_bits(depth) (31 b) | point index (21 b)
 // Arithmetic follows the reference's evaluation order (left-to-right inner products, no FMA:
 // compiled with -ffp-contract=off) so integer outputs are bit-exact and fp32 outputs differ from
 // the CPU path only through libm-vs-ocml trig and summation order of the H/b reduction.
@@ -42,6 +43,19 @@ __host__ __device__ __forceinline__ int zkey_index(unsigned long long k, unsigne
 __host__ __device__ __forceinline__ float zkey_depth(unsigned long long k, unsigned tag) {
   return ((unsigned)(k >> 52) == tag) ? __builtin_bit_cast(float, (unsigned)((k >> kZIndexBits) & 0x7fffffffu)) : FLT_MAX;
 }
+
+// Z-buffer of the ALIGNER (round 2): 32 bits per pixel = epoch tag (11 b) | point index (21 b), empty = ~0.  The depth is not stored:
+// a pixel's first point under the current tag arrives by one atomicMin (a smaller tag beats whatever older projections left, like
+// in the 64-bit form); only when two points of the SAME projection meet in a pixel -- a few per cent -- does the later one compare
+// depths (it recomputes the other's from the cloud) and install the nearer one, ties to the lower index, with a compare-and-swap loop
+// (project_point32).  Same winner as the reference's sequential `>` test (pinholepointprojector.cpp:61), half the atomic bytes (the
+// projection runs at the memory-side atomic rate: tools/micro/zbuf_atomics.hip, 78 us against 122 us for the bare scatter), half the
+// z-buffer bytes in the fused pass.  Depth images (matchClouds score, CorrespondenceFinder::*DepthImage()) are recomputed from the
+// winning point with the projection's own matrix: the same expression, the same bits.
+constexpr unsigned kZ32Tag0 = 0x7FEu;       // 0x7FF is the tag of the empty word
+constexpr unsigned kZ32IndexMask = (1u << kZIndexBits) - 1u;
+__host__ __device__ __forceinline__ unsigned z32key(unsigned tag, int i) { return (tag << kZIndexBits) | (unsigned)i; }
+__host__ __device__ __forceinline__ int z32_index(unsigned w, unsigned tag) { return ((w >> kZIndexBits) == tag) ? (int)(w & kZ32IndexMask) : -1; }
 
 constexpr int kClsMask = 3;      // Nm[i].w: class of the normal information matrix (0 zero, 1 flat, 2 non-flat)
 
@@ -89,6 +103,7 @@ struct PairState {
   Mat4 invTcorrPrev; // the one of the last executed outer iteration (the finder's correspondences that _computeStatistics reuses)
   Mat4 invT;       // Linearizer::_T
   Mat4 KRt;        // projector matrix of the next reference projection
+  Mat4 KRtLast;    // projector matrix of the reference projection executed last (its depth image is recomputed with it)
   Mat4 KRtCur;     // projector matrix of the current-cloud projection
   int   it;
   int   pad[3];
@@ -100,8 +115,8 @@ struct PairState {
 
 struct PairDesc {
   CloudDev ref, cur;
-  unsigned long long* zref;
-  unsigned long long* zcur;
+  unsigned* zref;          // 32-bit z-buffers (tag | index), one word per pixel
+  unsigned* zcur;
   int* curidx;             // index image of the current cloud (resolved once from zcur, or the converter's own image)
   const int* refidx0;      // optional: index image of the reference cloud for the FIRST outer iteration (the converter's own image when the
                            // initial guess is the identity: that projection returns it), else nullptr
@@ -1033,29 +1048,94 @@ __device__ __forceinline__ void project_point(const Mat4& KRt, float minD, float
   atomicMin(&z[(size_t)y * cols + x], zkey(tag, d, i));
 #endif
 }
-#ifndef PWN_PROJECT_PPT
-#define PWN_PROJECT_PPT 1
-#endif
-constexpr int kProjectPointsPerThread = PWN_PROJECT_PPT;      // grid.x = ceil(capacity / (256 * kProjectPointsPerThread))
+// depth of a point under a projector matrix: the third row of _project (pinholepointprojector.h:224-233), same expression as project_point
+__device__ __forceinline__ float point_depth(const Mat4& KRt, const float4 p) {
+  return dot4seq(KRt(2,0), p.x, KRt(2,1), p.y, KRt(2,2), p.z, KRt(2,3), 1.0f);
+}
+// 32-bit z-buffer insert (see kZ32Tag0) in two steps, so that a thread with several points has all its atomics in flight before it
+// looks at the first returned word.  z32_insert: the projection and the atomicMin; w = nullptr when the point is rejected.
+struct Z32Pending { unsigned* w; unsigned key, old; float d; };
+__device__ __forceinline__ Z32Pending z32_insert(const Mat4& KRt, float minD, float maxD, int rows, int cols, const float4 p, int i, unsigned* z, unsigned tag) {
+  Z32Pending r; r.w = nullptr; r.key = 0u; r.old = ~0u; r.d = 0.f;
+  const float ix = dot4seq(KRt(0,0), p.x, KRt(0,1), p.y, KRt(0,2), p.z, KRt(0,3), 1.0f);
+  const float iy = dot4seq(KRt(1,0), p.x, KRt(1,1), p.y, KRt(1,2), p.z, KRt(1,3), 1.0f);
+  const float d  = dot4seq(KRt(2,0), p.x, KRt(2,1), p.y, KRt(2,2), p.z, KRt(2,3), 1.0f);
+  if (d < minD || d > maxD) return r;
+  const float inv = 1.0f / d;
+  const float fx = roundf(ix * inv), fy = roundf(iy * inv);
+  // int conversion of out-of-range floats is undefined on the CPU; such points are rejected by the bounds test
+  if (!(fx >= 0.f && fx < (float)cols && fy >= 0.f && fy < (float)rows)) return r;
+  r.w = &z[(size_t)(int)fy * cols + (int)fx];
+  r.key = z32key(tag, i); r.d = d;
+  r.old = atomicMin(r.w, r.key);
+  return r;
+}
+// z32_settle: nothing to do for the first point of this projection in its pixel (older tags and the empty word are larger than any key of
+// the current tag); otherwise make sure the word ends up with the nearest of every point this thread gets to see, ties to the lower index.
+// P: the cloud's points (to evaluate the depth of a point met in the pixel).
+__device__ __forceinline__ void z32_settle(const Z32Pending& q, const Mat4& KRt, const float4* __restrict__ P, unsigned tag) {
+  if (!q.w || (q.old >> kZIndexBits) != tag) return;
+  int best = (int)(q.key & kZ32IndexMask); float dbest = q.d;
+  unsigned cur = q.old < q.key ? q.old : q.key;       // what the word holds after the atomicMin, unless someone changed it since
+  unsigned seen = q.old;
+  for (int guard = 0; guard < 1024; ++guard) {
+    const int j = (int)(seen & kZ32IndexMask);
+    if (j != best) {
+      const float dj = point_depth(KRt, P[j]);
+      if (dj < dbest || (dj == dbest && j < best)) { best = j; dbest = dj; }
+    }
+    const unsigned want = z32key(tag, best);
+    if (cur == want) break;
+    const unsigned r = atomicCAS(q.w, cur, want);
+    if (r == cur) break;                              // installed
+    seen = r; cur = r;                                // somebody else wrote (same tag): weigh its point too and try again
+  }
+}
+// PPT points per thread: all loads first, then all atomicMin's, then the (rare) collisions -- with one point per thread the wave waits
+// for every returned word before it does anything else (measured per 64-pair launch: 134 us with 1 point per thread, 104 with 2, 101
+// with 4; the 64-bit no-return atomicMin it replaces: 131).  Small launches (single alignments) keep 1: they need the workgroups.
+// grid.x = ceil(capacity / (256 * PPT))
+template <int PPT>
 __global__ void __launch_bounds__(256) k_project(const PairDesc* __restrict__ pairs, AlignParams ap, int which, unsigned tag) {
+  constexpr int kProjectPointsPerThread = PPT;
   const PairDesc& pd = pairs[blockIdx.y];
   const CloudDev& cl = which ? pd.cur : pd.ref;
   const int n = min(*cl.count, cl.capacity);
   const int i0 = blockIdx.x * 256 * kProjectPointsPerThread + threadIdx.x;
   if (i0 >= n) return;
   const Mat4 KRt = uniform_iso(which ? pd.state->KRtCur : pd.state->KRt);
-  unsigned long long* z = which ? pd.zcur : pd.zref;
+  unsigned* z = which ? pd.zcur : pd.zref;
   float4 p[kProjectPointsPerThread];
 #pragma unroll
   for (int j = 0; j < kProjectPointsPerThread; ++j) { const int i = i0 + 256 * j; if (i < n) p[j] = cl.P[i]; }      // loads first
+  Z32Pending q[kProjectPointsPerThread];
 #pragma unroll
-  for (int j = 0; j < kProjectPointsPerThread; ++j) { const int i = i0 + 256 * j; if (i < n) project_point(KRt, ap.minD, ap.maxD, ap.rows, ap.cols, p[j], i, z, tag); }
+  for (int j = 0; j < kProjectPointsPerThread; ++j) {
+    const int i = i0 + 256 * j;
+    if (i < n) q[j] = z32_insert(KRt, ap.minD, ap.maxD, ap.rows, ap.cols, p[j], i, z, tag); else q[j].w = nullptr;
+  }
+#pragma unroll
+  for (int j = 0; j < kProjectPointsPerThread; ++j) z32_settle(q[j], KRt, cl.P, tag);
 }
 // current-cloud z-buffer -> int index image, once per alignment.  grid = (blocks, pairs)
 __global__ void k_resolve_cur(const PairDesc* __restrict__ pairs, int n, unsigned tag) {
   const PairDesc& pd = pairs[blockIdx.y];
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    pd.curidx[i] = zkey_index(pd.zcur[i], tag);
+    pd.curidx[i] = z32_index(pd.zcur[i], tag);
+}
+// CorrespondenceFinder::{reference,current}{Index,Depth}Image() of a pair after its alignment: index from the 32-bit z-buffer, depth
+// recomputed from the winning point with the matrix its projection used; empty pixels -1 / FLT_MAX (pinholepointprojector.cpp:41-42)
+__global__ void k_pair_images(const PairDesc* __restrict__ pairs, int which, unsigned tag, int n, int* __restrict__ index, float* __restrict__ depth) {
+  const PairDesc& pd = pairs[0];
+  const CloudDev& cl = which ? pd.cur : pd.ref;
+  const unsigned* z = which ? pd.zcur : pd.zref;
+  const Mat4 KRt = which ? pd.state->KRtCur : pd.state->KRtLast;
+  const int np = min(*cl.count, cl.capacity);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const int k = z32_index(z[i], tag);
+    if (index) index[i] = k;
+    if (depth) depth[i] = (k >= 0 && k < np) ? point_depth(KRt, cl.P[k]) : FLT_MAX;
+  }
 }
 // stand-alone projection with an explicit matrix (pwn_hip_project)
 __global__ void __launch_bounds__(256) k_project_single(CloudDev cl, Mat4 KRt, float minD, float maxD, int rows, int cols,
@@ -1297,7 +1377,7 @@ struct Candidate {
 struct PairPtrs {
   gptr<const v4f> refP, refN, curP, curN;
   gptr<const float> curOm, curOmN;
-  gptr<const unsigned long long> zref;
+  gptr<const unsigned> zref;
   gptr<const int> curidx, refidx0;
   unsigned cap;      // capacity of the current cloud (plane stride)
 };
@@ -1306,7 +1386,7 @@ __device__ __forceinline__ PairPtrs pair_ptrs(const PairDesc& pd) {
   q.refP = as_global((const v4f*)pd.ref.P); q.refN = as_global((const v4f*)pd.ref.Nm);
   q.curP = as_global((const v4f*)pd.cur.P); q.curN = as_global((const v4f*)pd.cur.Nm);
   q.curOm = as_global((const float*)pd.cur.Om); q.curOmN = as_global((const float*)pd.cur.OmN);
-  q.zref = as_global((const unsigned long long*)pd.zref); q.curidx = as_global((const int*)pd.curidx);
+  q.zref = as_global((const unsigned*)pd.zref); q.curidx = as_global((const int*)pd.curidx);
   q.refidx0 = as_global(pd.refidx0);
   q.cap = (unsigned)pd.cur.capacity;
   return q;
@@ -1408,9 +1488,9 @@ __global__ void PWN_CL_EU_ATTR __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_co
     ri = -1; ci = -1;
     if (j < PPT && pix < N) {
 #if PWN_CL_X & 4
-      ri = q.refidx0 ? q.refidx0[(unsigned)pix] : zkey_index(q.zref[(unsigned)pix], tag);
+      ri = q.refidx0 ? q.refidx0[(unsigned)pix] : z32_index(q.zref[(unsigned)pix], tag);
 #else
-      ri = ownRefIndex ? q.refidx0[(unsigned)pix] : zkey_index(q.zref[(unsigned)pix], tag);      // wave-uniform choice
+      ri = ownRefIndex ? q.refidx0[(unsigned)pix] : z32_index(q.zref[(unsigned)pix], tag);      // wave-uniform choice
 #endif
       ci = q.curidx[(unsigned)pix];
     }
@@ -1472,7 +1552,7 @@ __global__ void __launch_bounds__(kLatBlock) k_corr_linearize_lat(const PairDesc
     const int pix = pix0 + (q + 4 * r) * kAlignBlock;
     ri[r] = -1; ci[r] = -1;
     if (pix < N) {
-      ri[r] = ownRefIndex ? pp.refidx0[(unsigned)pix] : zkey_index(pp.zref[(unsigned)pix], tag);
+      ri[r] = ownRefIndex ? pp.refidx0[(unsigned)pix] : z32_index(pp.zref[(unsigned)pix], tag);
       ci[r] = pp.curidx[(unsigned)pix];
     }
   }
@@ -1584,13 +1664,15 @@ __global__ void __launch_bounds__(256) k_match_score(const PairDesc* __restrict_
                                                      float threshold, MatchAcc* __restrict__ out, int curOwn) {
   const PairDesc& pd = pairs[blockIdx.y];
   int nz = 0, inl = 0; long long sum = 0; int tiny = 0;
-  const int ncur = curOwn ? min(*pd.cur.count, pd.cur.capacity) : 0;
+  const int ncur = min(*pd.cur.count, pd.cur.capacity), nref = min(*pd.ref.count, pd.ref.capacity);
+  const Mat4 KRtRef = uniform_iso(pd.state->KRtLast), KRtCur = uniform_iso(pd.state->KRtCur);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
-    float dc;
-    if (curOwn) { const int ci = pd.curidx[i]; dc = (ci >= 0 && ci < ncur) ? pd.cur.P[ci].z : FLT_MAX; }
-    else dc = zkey_depth(pd.zcur[i], curTag);
+    float dc = FLT_MAX, dr = FLT_MAX;
+    if (curOwn) { const int ci = pd.curidx[i]; if (ci >= 0 && ci < ncur) dc = pd.cur.P[ci].z; }
+    else { const int ci = z32_index(pd.zcur[i], curTag); if (ci >= 0 && ci < ncur) dc = point_depth(KRtCur, pd.cur.P[ci]); }
+    { const int ri = z32_index(pd.zref[i], refTag); if (ri >= 0 && ri < nref) dr = point_depth(KRtRef, pd.ref.P[ri]); }
     const unsigned short c = depth_to_u16(dc, scale);
-    const unsigned short r = depth_to_u16(zkey_depth(pd.zref[i], refTag), scale);
+    const unsigned short r = depth_to_u16(dr, scale);
     if (c > 0 && r > 0) {
       ++nz;
       const float ad = fabsf((float)c - (float)r);
@@ -1701,6 +1783,7 @@ __global__ void __launch_bounds__(256) k_solve_update(const PairDesc* __restrict
     invT = Tinv;
     Mat4 KRt, iKRt; Mat3 iK;
     projector_matrices(ap.K, iso_mul(T, ap.refOffset), KRt, iKRt, iK);
+    st.KRtLast = st.KRt;        // the reference projection of this outer iteration (what the finder's depth image belongs to)
     st.KRt = KRt;
   }
   set_last_row(invT);

@@ -157,7 +157,7 @@ void pwn_hip_default_aligner_params(pwn_hip_aligner_params* p);
 
 /* ------------------------------------------------------------------ clouds ------------------- */
 /* capacity = maximum number of points (rows*cols of the images it will be converted from); at most 2^21 = 2 097 152
- * (the z-buffer packs epoch | depth | index into one 64-bit word) */
+ * (the z-buffers keep the point index in 21 bits of their words) */
 int pwn_hip_cloud_create(pwn_hip_ctx* ctx, int capacity, pwn_hip_cloud** cloud);
 int pwn_hip_cloud_destroy(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud);
 int pwn_hip_cloud_size(pwn_hip_ctx* ctx, const pwn_hip_cloud* cloud, int* n);    /* Cloud::points().size() */
