@@ -572,3 +572,55 @@ def test_odd_image_sizes(oracle, rows, cols):
             assert np.array_equal(r["T"].view(np.uint32), g["T"].view(np.uint32)) and np.array_equal(r["chi2"].view(np.uint32), g["chi2"].view(np.uint32))
     finally:
         ctx.close()
+
+
+@pytest.mark.parametrize("shrink", [1, 4])
+def test_aligner_finder_images_bit_exact_and_collisions(oracle, shrink):
+    """The aligner's own z-buffer (32-bit tag | index words; points of one projection that meet in a pixel are settled by depth with a
+    compare-and-swap loop) against the oracle's sequential projector: CorrespondenceFinder::{reference,current}{Index,Depth}Image() after
+    Aligner::align, bit for bit.  shrink = 4 projects VGA clouds into a 120x160 image: 16 points per pixel fight for every word (the
+    reference's `>` keeps the nearest, ties the lowest index: pinholepointprojector.cpp:61).  Single alignment (one point per thread)
+    and a batch of 9 (four points per thread) must agree bit for bit as well."""
+    from g2o_frontend_amd import api, synth
+    rows, cols, K, conv, alig = case_params("vga")
+    ref, cur, _, _, _ = make_depth_pair("vga", 3)
+    ctx = api.Context(0, rows, cols, 16)
+    try:
+        _, converter, aligner = gpu_objects(ctx, "vga")
+        gref, gcur = api.Cloud(ctx, rows * cols), api.Cloud(ctx, rows * cols)
+        converter.compute(gref, ref); converter.compute(gcur, cur)
+        cp, _ = oracle_params(oracle, "vga")
+        oref, _, _ = oracle.convert(cp, ref); ocur, _, _ = oracle.convert(cp, cur)
+        r2, c2 = rows // shrink, cols // shrink
+        K2 = synth.scaled_K(K, shrink) if shrink > 1 else K
+        for p in (aligner.projector(),):
+            p.setCameraMatrix([[K2[0], 0, K2[2]], [0, K2[1], K2[3]], [0, 0, 1]]); p.setImageSize(r2, c2)
+        aligner.correspondenceFinder().setImageSize(r2, c2)
+        aligner.setReferenceCloud(gref); aligner.setCurrentCloud(gcur)
+        guesses = [np.eye(4, dtype=np.float32), synth.v2t(np.array([0.03, -0.02, 0.01, 0.01, -0.02, 0.015])).astype(np.float32)]
+        for outer in (1, 3):
+            aligner.setOuterIterations(outer)
+            for g0 in guesses:
+                aligner.setInitialGuess(g0)
+                ap = oracle.aligner_params(r2, c2, K=K2, initial_guess=g0, accumulate_fp64=1, **dict(alig, outer_iterations=outer))
+                o = oracle.align(ap, oref, ocur, images=True)
+                if outer > 1:
+                    # free-running iterates may differ in their last bits: compare the images of the LAST projection from the oracle's iterate
+                    aligner.setOuterIterations(1); aligner.setInitialGuess(o["iterations"][-1]["T_before"])
+                g = aligner.align(images=True)
+                f = aligner.correspondenceFinder()
+                assert np.array_equal(f.referenceIndexImage(), o["ref_index"]) and np.array_equal(f.currentIndexImage(), o["cur_index"])
+                assert np.array_equal(f.referenceDepthImage().view(np.uint32), o["ref_depth"].view(np.uint32))
+                assert np.array_equal(f.currentDepthImage().view(np.uint32), o["cur_depth"].view(np.uint32))
+                if shrink > 1:
+                    assert int((o["ref_index"] >= 0).sum()) < len(oref) // 8              # the collisions are real: most points lose
+                aligner.setOuterIterations(outer)
+        # batch (>= 8 pairs: four points per thread, all atomics in flight) == single (one point per thread)
+        aligner.setOuterIterations(3); aligner.setInitialGuess(guesses[1])
+        single = aligner.align()
+        batch = aligner.alignBatch([gref] * 9, [gcur] * 9, initialGuesses=[guesses[1]] * 9)
+        for b in batch:
+            assert np.array_equal(b["T"].view(np.uint32), single["T"].view(np.uint32)) and np.array_equal(b["chi2"].view(np.uint32), single["chi2"].view(np.uint32))
+            assert np.array_equal(b["K"], single["K"]) and np.array_equal(b["C"], single["C"])
+    finally:
+        ctx.close()
