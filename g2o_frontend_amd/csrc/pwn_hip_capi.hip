@@ -82,6 +82,7 @@ struct pwn_hip_ctx {
   // images of the last single align
   int img_rows = 0, img_cols = 0; bool img_valid = false; unsigned img_ref_tag = kZ32Tag0, img_cur_tag = kZ32Tag0;
   int img_pair = 0;                         // descriptor (pairs_host / pairs_dev entry) of the pair whose images sit in workspace slot 0
+  const pwn_hip_cloud* img_ref_cloud = nullptr; const pwn_hip_cloud* img_cur_cloud = nullptr;      // its clouds: the depth images are recomputed from their points
   // z-buffer epoch tags are handed out in descending order ACROSS batch calls (a smaller tag wins, so whatever earlier calls left in
   // the buffers reads as empty): the buffers are cleared only when the 12-bit tag space is used up, not once per alignment
   unsigned ztag_next = 0;                   // 64-bit buffer (scene stage)
@@ -132,6 +133,11 @@ int fail(pwn_hip_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg;
   g_err = msg;
   return code;
+}
+// The finder's depth images of the last alignment are recomputed from the clouds' points (the z-buffer keeps indices only): anything
+// that changes or frees one of those clouds ends the validity of pwn_hip_align_images / pwn_hip_match_score for that alignment.
+void cloud_changes(pwn_hip_ctx* ctx, const pwn_hip_cloud* c) {
+  if (ctx && c && (c == ctx->img_ref_cloud || c == ctx->img_cur_cloud)) { ctx->img_valid = false; ctx->img_ref_cloud = nullptr; ctx->img_cur_cloud = nullptr; }
 }
 #define HIPCHK(ctx, call, code)                                                                               \
   do {                                                                                                        \
@@ -306,6 +312,7 @@ int ensure_desc(pwn_hip_ctx* ctx, int n) {
   ctx->frames_dev = nullptr; ctx->pairs_dev = nullptr; ctx->raw_dev = nullptr; ctx->counts_dev = nullptr; ctx->state_ws = nullptr;
   ctx->frames_host = nullptr; ctx->pairs_host = nullptr; ctx->raw_host = nullptr; ctx->state_host = nullptr; ctx->counts_host = nullptr;
   ctx->desc_cap = 0;
+  ctx->img_valid = false;                    // the descriptor of the last alignment's pair goes with the old arrays
   const size_t B = (size_t)std::max(n, 16);
   HIPCHK(ctx, hipMalloc((void**)&ctx->frames_dev, B * sizeof(FrameDesc)), PWN_HIP_ERR_ALLOCATION);
   HIPCHK(ctx, hipMalloc((void**)&ctx->pairs_dev, B * sizeof(PairDesc)), PWN_HIP_ERR_ALLOCATION);
@@ -432,6 +439,7 @@ int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, cons
   for (int i = 0; i < n; ++i) {
     pwn_hip_cloud* c = clouds[i];
     if (!c || !frames[i]) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null frame or cloud");
+    cloud_changes(ctx, c);
     if (keep_stats) { if (int rc = ensure_stats(ctx, c)) return rc; }
     c->has_stats = keep_stats != 0;
     c->n_gauss = 0;                              // the cloud's Gaussians (if any) belonged to its previous content
@@ -734,6 +742,7 @@ int pwn_hip_cloud_create(pwn_hip_ctx* ctx, int capacity, pwn_hip_cloud** out) {
 }
 int pwn_hip_cloud_destroy(pwn_hip_ctx* ctx, pwn_hip_cloud* c) {
   if (!c) return PWN_HIP_OK;
+  cloud_changes(ctx, c);
   // plain clouds (no scene-stage or uploaded extras) retire into the context's pool: every call that used them has joined its streams
   // back into ctx->stream before returning, and a reuse is enqueued on that stream
   const bool plain = !c->d.OmN && !c->d.St && !c->sb.G && !c->sb.Gf && !c->back.P && !c->back.Nm && !c->back.Om && !c->back.OmN && !c->back.St &&
@@ -757,6 +766,7 @@ int pwn_hip_cloud_upload(pwn_hip_ctx* ctx, pwn_hip_cloud* c, int n, const float*
                          const float* omega_p, const float* omega_n) {
   if (!ctx || !c || n < 0 || !points || !normals || !curvature || !omega_p || !omega_n) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if (n > c->d.capacity) return fail(ctx, PWN_HIP_ERR_CAPACITY, "cloud capacity too small");
+  cloud_changes(ctx, c);
   // repack on the host into the device layout (upload is not on the hot path)
   std::vector<float> hp((size_t)n * 4), hn((size_t)n * 4), hc(n), hop((size_t)n * 16), hon((size_t)n * 16);
   HIPCHK(ctx, copy_any(hp.data(), points, hp.size() * 4, ctx->stream), PWN_HIP_ERR_COPY);
@@ -853,6 +863,7 @@ int pwn_hip_cloud_transform_in_place(pwn_hip_ctx* ctx, pwn_hip_cloud* c, const f
   if (!ctx || !c || !T) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   const Mat4 m = forced(T);
   if (is_identity(m)) return PWN_HIP_OK;                       // cloud.cpp:176
+  cloud_changes(ctx, c);
   if (!c->d.OmN) {                                             // class matrices transform with the cloud
     for (int k = 0; k < 2; ++k) {
       float* om = c->d.omN[k]; float t1[9], o2[9];
@@ -927,6 +938,7 @@ int pwn_hip_unproject(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const
   if (int rc = check_image(ctx, rows, cols)) return rc;
   const size_t N = (size_t)rows * cols;
   cloud->idx_valid = false;                      // the cloud gets new points
+  cloud_changes(ctx, cloud);
   const ConvertParams cp = make_convert_params(ctx, p, T, rows, cols, 0);
   const float* d = nullptr;
   if (int rc = stage_depth(ctx, depth, N, &d)) return rc;
@@ -1181,7 +1193,10 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
       HIPCHK(ctx, hipMemsetAsync(ctx->z32ref_ws + s0 * ctx->N, 0xFF, (size_t)m * ctx->N * 4, st), PWN_HIP_ERR_COPY);
       HIPCHK(ctx, hipMemsetAsync(ctx->z32cur_ws + s0 * ctx->N, 0xFF, (size_t)m * ctx->N * 4, st), PWN_HIP_ERR_COPY);
     }
-    if (s0 == 0 || kk == 0) { tag0 = subTag0; lastRefTag = subTag0 - (tagsPerSub - 1); ctx->img_pair = base; }     // slot 0: what pwn_hip_align_images / pwn_hip_match_score read
+    if (s0 == 0 || kk == 0) {      // slot 0: what pwn_hip_align_images / pwn_hip_match_score read
+      tag0 = subTag0; lastRefTag = subTag0 - (tagsPerSub - 1); ctx->img_pair = base;
+      ctx->img_ref_cloud = refs[base]; ctx->img_cur_cloud = curs[base];
+    }
     const unsigned subLastRefTag = subTag0 - (tagsPerSub - 1);
     if (!sub_own[kk]) {
       StageTimer t(ctx, "project_cur", st);
@@ -1292,7 +1307,7 @@ int pwn_hip_align_with_priors_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params*
   pd.ref = ref->d; pd.cur = cur->d;
   pd.zref = ctx->z32ref_ws; pd.zcur = ctx->z32cur_ws; pd.curidx = ctx->curidx_ws; pd.partials = ctx->partials_ws; pd.state = ctx->state_ws;
   pd.refidx0 = nullptr;
-  ctx->img_pair = 0;
+  ctx->img_pair = 0; ctx->img_ref_cloud = ref; ctx->img_cur_cloud = cur;
   PairState& hs = ctx->state_host[0];
   std::memset(&hs, 0, sizeof(hs));
   Mat4 T = mat4_from(p->initial_guess); set_last_row(T);

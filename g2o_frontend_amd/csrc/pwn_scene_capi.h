@@ -157,6 +157,7 @@ int pwn_hip_cloud_download_gaussians(pwn_hip_ctx* ctx, const pwn_hip_cloud* c, f
 int pwn_hip_cloud_add(pwn_hip_ctx* ctx, pwn_hip_cloud* dst, const pwn_hip_cloud* src, const float T[16]) {
   if (!ctx || !dst || !src || !T) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if (dst == src) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "cannot add a cloud to itself");
+  cloud_changes(ctx, dst);
   const int k = dst->n_host, n = src->n_host;
   if ((size_t)k + (size_t)n > (size_t)dst->d.capacity) return fail(ctx, PWN_HIP_ERR_CAPACITY, "destination cloud capacity too small for Cloud::add");
   const bool srcGauss = src->sb.G && src->n_gauss > 0;
@@ -188,6 +189,7 @@ int pwn_hip_merge(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud, const float K[9], cons
   if (!ctx || !cloud || !K || !T) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if (int rc = check_image(ctx, rows, cols)) return rc;
   if (min_distance < 0.f) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "min_distance must be >= 0");
+  cloud_changes(ctx, cloud);
   const int n = cloud->n_host;
   if (n > kMaxCloudPoints) return fail(ctx, PWN_HIP_ERR_CAPACITY, "cloud has more points than the z-buffer index field holds (2^21)");
   if (!cloud->sb.G || cloud->n_gauss < n) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "Merger::merge needs the cloud's Gaussians (pwn_hip_cloud_gaussians)");
@@ -230,6 +232,7 @@ int pwn_hip_merge(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud, const float K[9], cons
 // kept (optional, host) receives the original indices of the survivors in output order.
 int pwn_hip_voxelize(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud, float resolution, int* new_size, int* kept) {
   if (!ctx || !cloud || !(resolution > 0.f)) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "bad argument");
+  cloud_changes(ctx, cloud);
   const int n = cloud->n_host;
   if (n == 0) { if (new_size) *new_size = 0; return PWN_HIP_OK; }
   if (int rc = ensure_back(ctx, cloud)) return rc;
@@ -343,6 +346,7 @@ int pwn_hip_cloud_load(pwn_hip_ctx* ctx, pwn_hip_cloud* c, const char* filename,
   if (tag != "PWNCLOUD") return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "not a PWNCLOUD file");
   ls >> numPoints >> binary;
   if (numPoints > (size_t)c->d.capacity) return fail(ctx, PWN_HIP_ERR_CAPACITY, "cloud capacity smaller than the file's point count");
+  cloud_changes(ctx, c);
   is.getline(buf, 1024);
   std::istringstream lst(buf);
   float tv[6] = { 0, 0, 0, 0, 0, 0 };

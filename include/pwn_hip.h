@@ -237,7 +237,9 @@ int pwn_hip_linearize(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, const p
 int pwn_hip_align(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, const pwn_hip_cloud* reference,
                   const pwn_hip_cloud* current, pwn_hip_align_result* result);
 /* CorrespondenceFinder::{reference,current}{Index,Depth}Image() after the last pwn_hip_align
- * (correspondencefinder.h:99-117; read by pwn_tracker/pwn_matcher_base.cpp:153-155). Any may be NULL. */
+ * (correspondencefinder.h:99-117; read by pwn_tracker/pwn_matcher_base.cpp:153-155). Any may be NULL.
+ * The aligner's z-buffers keep point indices only; the depth images are recomputed from the two clouds' points, so this call (and
+ * pwn_hip_match_score) is valid until either cloud of that alignment is destroyed or gets new content (then: INVALID_ARGUMENT). */
 int pwn_hip_align_images(pwn_hip_ctx* ctx, int* reference_index, float* reference_depth, int* current_index, float* current_depth);
 /* n independent alignments (the loop-closure candidate batch, pwn_tracker/pwn_closer.cpp:92-111).
  * p is shared by all pairs; initial_guesses: n*16 floats or NULL (= p->initial_guess for all). */

@@ -155,3 +155,32 @@ def test_matchCloudsBatch_equals_single(ctx, oracle):
     for s, b in zip(single, batch):
         assert np.array_equal(s["transform"], b["transform"]) and s["image_nonZeros"] == b["image_nonZeros"] and s["image_inliers"] == b["image_inliers"]
         assert s["image_reprojectionDistance"] == b["image_reprojectionDistance"]
+
+
+@pytest_gpu
+def test_finder_images_end_with_their_clouds(ctx, oracle):
+    """The aligner's z-buffers keep point indices; depth images and the matchClouds score are recomputed from the clouds' points.  Once a cloud
+    of the last alignment has new content or is gone, pwn_hip_align_images / pwn_hip_match_score refuse instead of reading freed or foreign points."""
+    import ctypes as C
+    from g2o_frontend_amd import api
+    from g2o_frontend_amd._lib import MatchResult, PwnHipError
+    from test_gpu_parity import gpu_objects
+    rows, cols, K, _, _ = case_params("small")
+    ref, cur, _, _, _ = make_depth_pair("small", 4)
+    _, converter, aligner = gpu_objects(ctx, "small")
+    gref, gcur = api.Cloud(ctx, rows * cols), api.Cloud(ctx, rows * cols)
+    converter.compute(gref, ref); converter.compute(gcur, cur)
+    aligner.setReferenceCloud(gref); aligner.setCurrentCloud(gcur)
+    aligner.align(images=True)
+    m = MatchResult()
+    ctx.check(ctx._L.pwn_hip_match_score(ctx.h, 50.0, C.byref(m)))
+    assert m.image_non_zeros > 1000
+    converter.compute(gcur, ref)                                   # the current cloud gets new content
+    with pytest.raises(PwnHipError) as e:
+        ctx.check(ctx._L.pwn_hip_match_score(ctx.h, 50.0, C.byref(m)))
+    assert e.value.code == 1
+    aligner.align()
+    ctx.check(ctx._L.pwn_hip_match_score(ctx.h, 50.0, C.byref(m)))   # valid again after the next alignment
+    ctx.check(ctx._L.pwn_hip_cloud_destroy(ctx.h, gref.h)); gref.h = None
+    with pytest.raises(PwnHipError):
+        aligner.align.__self__.ctx.check(ctx._L.pwn_hip_align_images(ctx.h, None, None, None, None))
