@@ -74,6 +74,12 @@ PROTOTYPES = {
     "pwn_hip_ctx_set_concurrency": (_I, [_VP, _I]),
     "pwn_hip_last_error_string": (C.c_char_p, [_VP]),
     "pwn_hip_device_count": (_I, []),
+    "pwn_hip_host_alloc": (_I, [C.POINTER(C.c_void_p), C.c_size_t]),
+    "pwn_hip_host_free": (_I, [_VP]),
+    "pwn_hip_device_alloc": (_I, [_VP, C.POINTER(C.c_void_p), C.c_size_t]),
+    "pwn_hip_device_free": (_I, [_VP, _VP]),
+    "pwn_hip_copy": (_I, [_VP, _VP, _VP, C.c_size_t]),
+    "pwn_hip_copy_async": (_I, [_VP, _VP, _VP, C.c_size_t]),
     "pwn_hip_default_converter_params": (None, [_VP]),
     "pwn_hip_default_aligner_params": (None, [_VP]),
     "pwn_hip_cloud_create": (_I, [_VP, _I, C.POINTER(_VP)]),

@@ -32,17 +32,100 @@ def _ptr(x):
     raise TypeError(type(x))
 
 
+class DeviceBuffer:
+    """a caller-owned buffer in HBM; accepted wherever a frame / image pointer is (it has data_ptr(), shape, is_contiguous() like a tensor)"""
+
+    def __init__(self, ctx, array):
+        a = np.ascontiguousarray(array)
+        self.ctx, self.shape, self.dtype, self.nbytes = ctx, a.shape, a.dtype, a.nbytes
+        self._p = C.c_void_p()
+        ctx.check(ctx._L.pwn_hip_device_alloc(ctx.h, C.byref(self._p), max(1, a.nbytes)))
+        ctx.check(ctx._L.pwn_hip_copy(ctx.h, self._p, a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def data_ptr(self): return self._p.value
+    def is_contiguous(self): return True
+
+    def frame(self, i):
+        """the i-th image of a [n, rows, cols] buffer as a frame argument"""
+        return _DeviceView(self, i)
+
+    def copy_from_async(self, array):
+        """queue host -> device on the context's copy stream (pwn_hip_copy_async); the next convert call waits for it"""
+        assert array.nbytes == self.nbytes and array.flags["C_CONTIGUOUS"]
+        self.ctx.check(self.ctx._L.pwn_hip_copy_async(self.ctx.h, self._p, array.ctypes.data_as(C.c_void_p), array.nbytes))
+
+    def numpy(self):
+        out = np.empty(self.shape, self.dtype)
+        self.ctx.check(self.ctx._L.pwn_hip_copy(self.ctx.h, out.ctypes.data_as(C.c_void_p), self._p, self.nbytes))
+        return out
+
+    def free(self):
+        if self._p and self.ctx.h:
+            self.ctx._L.pwn_hip_device_free(self.ctx.h, self._p)
+        self._p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class _DeviceView:
+    def __init__(self, buf, i):
+        self.buf, self.shape = buf, tuple(buf.shape[1:])
+        self._off = i * int(np.prod(self.shape)) * buf.dtype.itemsize
+
+    def data_ptr(self): return self.buf.data_ptr() + self._off
+    def is_contiguous(self): return True
+
+
+class _PinnedBlock:
+    """owner of one pwn_hip_host_alloc block (freed when the last array view over it goes away)"""
+
+    def __init__(self, nbytes):
+        self.ptr = C.c_void_p()
+        rc = _lib.lib().pwn_hip_host_alloc(C.byref(self.ptr), nbytes)
+        if rc != 0:
+            raise _lib.PwnHipError(rc, _lib.lib().pwn_hip_last_error_string(None).decode())
+        self.buf = (C.c_char * nbytes).from_address(self.ptr.value)
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                _lib.lib().pwn_hip_host_free(self.ptr); self.ptr = None
+        except Exception:
+            pass
+
+
+def pinned_empty(shape, dtype=np.float32):
+    """numpy array in page-locked host memory (pwn_hip_host_alloc): depth frames handed over from it are copied by asynchronous DMA"""
+    dtype = np.dtype(dtype)
+    n = int(np.prod(shape))
+    blk = _PinnedBlock(max(1, n * dtype.itemsize))
+    a = np.frombuffer(blk.buf, dtype=dtype, count=n).reshape(shape)
+    _PINNED[a.__array_interface__["data"][0]] = blk          # keeps the block alive; release with pinned_free
+    return a
+
+
+_PINNED = {}
+
+
+def pinned_free(a):
+    _PINNED.pop(a.__array_interface__["data"][0], None)
+
+
 def _colmajor(M, n):
     return np.ascontiguousarray(np.asarray(M, dtype=np.float32).reshape(n, n).T.reshape(-1))
 
 
 def _set(field, M, n):
-    for i, v in enumerate(_colmajor(M, n)):
-        field[i] = float(v)
+    a = _colmajor(M, n)
+    C.memmove(field, a.ctypes.data, a.nbytes)            # one copy instead of n*n Python assignments (the tracker sets 3 matrices per frame)
 
 
 def _from_colmajor(a, n):
-    return np.array(list(a), dtype=np.float32).reshape(n, n).T.copy()
+    return np.frombuffer(a, dtype=np.float32, count=n * n).reshape(n, n).T.copy()
 
 
 # numpy view of pwn_hip_align_result (include/pwn_hip.h): zero-copy access to a batch of results
@@ -93,6 +176,10 @@ class Context:
 
     def set_concurrency(self, streams: int):
         self.check(self._L.pwn_hip_ctx_set_concurrency(self.h, streams))
+
+    def upload(self, array):
+        """DeviceBuffer holding a copy of a host array (pwn_hip_device_alloc + pwn_hip_copy): a frame resident in HBM without torch"""
+        return DeviceBuffer(self, array)
 
     def synchronize(self):
         self.check(self._L.pwn_hip_ctx_synchronize(self.h))
@@ -574,8 +661,8 @@ class Aligner:
     def _unpack(r: AlignResult):
         n = r.iterations
         return dict(T=_from_colmajor(r.T, 4), error=r.error, inliers=r.inliers, iterations=n, total_time_ms=r.total_time_ms,
-                    chi2=np.array(r.chi2[:n], np.float32), iter_inliers=np.array(r.iter_inliers[:n], np.int32),
-                    C=np.array(r.iter_correspondences[:n], np.int32), K=np.array(r.iter_candidates[:n], np.int32),
+                    chi2=np.frombuffer(r.chi2, np.float32, n).copy(), iter_inliers=np.frombuffer(r.iter_inliers, np.int32, n).copy(),
+                    C=np.frombuffer(r.iter_correspondences, np.int32, n).copy(), K=np.frombuffer(r.iter_candidates, np.int32, n).copy(),
                     n_reference=r.n_reference, n_current=r.n_current)
 
     def addRelativePrior(self, mean, informationMatrix):

@@ -25,6 +25,7 @@
 #ifndef PWN_HIP_H
 #define PWN_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -151,6 +152,25 @@ int pwn_hip_ctx_set_concurrency(pwn_hip_ctx* ctx, int streams);
 const char* pwn_hip_last_error_string(const pwn_hip_ctx* ctx);
 /* number of HIP devices visible; does not initialise a device */
 int pwn_hip_device_count(void);
+
+/* Page-locked host memory for depth frames handed to the convert calls from the host (a grabber's ring buffer): copies from it are
+ * asynchronous DMA transfers that overlap the kernels of the other stream; from ordinary (pageable) memory every frame goes through the
+ * runtime's bounce buffer and blocks the calling thread.  Does not need a context.  The reference has no counterpart (its images are
+ * cv::Mat on the host, depthimageconverter.h:47); any host pointer is accepted by every entry point, this is the fast kind. */
+int pwn_hip_host_alloc(void** ptr, size_t bytes);
+int pwn_hip_host_free(void* ptr);
+/* Device buffers for callers that do not link the HIP runtime themselves (the binding of INTEGRATION.md is plain C++): frames uploaded ahead
+ * of time with pwn_hip_copy are used in place by the convert calls (no staging copy).  pwn_hip_copy: any direction, ordered after the work
+ * already queued on the context, complete on return. */
+int pwn_hip_device_alloc(pwn_hip_ctx* ctx, void** ptr, size_t bytes);
+int pwn_hip_device_free(pwn_hip_ctx* ctx, void* ptr);
+int pwn_hip_copy(pwn_hip_ctx* ctx, void* dst, const void* src, size_t bytes);
+/* The same copy queued on the context's copy stream; returns at once (for page-locked host memory -- pageable memory makes it wait).  The
+ * next call on the context that reads frames (convert*, unproject, the depth-image helpers, pwn_hip_copy, ctx_synchronize, device_free)
+ * runs after every copy issued so far; aligner calls do not wait.  Pattern: upload the frames of batch k+1 into a second set of device
+ * buffers, align batch k meanwhile, convert batch k+1 -- the transfers disappear behind the alignment.  The caller keeps source and
+ * destination untouched until one of those calls has returned. */
+int pwn_hip_copy_async(pwn_hip_ctx* ctx, void* dst, const void* src, size_t bytes);
 
 void pwn_hip_default_converter_params(pwn_hip_converter_params* p);
 void pwn_hip_default_aligner_params(pwn_hip_aligner_params* p);

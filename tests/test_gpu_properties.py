@@ -74,6 +74,52 @@ def test_converter_is_idempotent_and_batch_invariant(world):
         assert np.array_equal(x[k].view(np.uint32), y[k].view(np.uint32)) and np.array_equal(x[k].view(np.uint32), z[k].view(np.uint32)), k
 
 
+def test_frames_from_pinned_host_memory_and_from_hbm_give_the_same_clouds(world):
+    """pwn_hip_host_alloc: frames handed over from page-locked host memory (asynchronous copies on the sub-batch streams), from pageable
+    memory (the fixture) and from buffers already in HBM are the same input."""
+    from g2o_frontend_amd import api
+    ctx, converter = world["ctx"], world["converter"]
+    rows, cols = world["rows"], world["cols"]
+    frames = [p[0] for p in world["pairs"][:5]]
+    block = api.pinned_empty((3, rows, cols), np.uint16)                                    # three consecutive frames (one transfer) ...
+    pinned = [block[0], block[1], block[2]] + [api.pinned_empty((rows, cols), np.uint16) for _ in frames[3:]]      # ... and two on their own
+    for d, f in zip(pinned, frames):
+        d[...] = f
+    resident = [ctx.upload(f) for f in frames]                                              # pwn_hip_device_alloc + pwn_hip_copy
+    assert np.array_equal(resident[3].numpy(), frames[3])
+    a = [api.Cloud(ctx, rows * cols) for _ in frames]; b = [api.Cloud(ctx, rows * cols) for _ in frames]
+    ctx.set_subbatch(2, 2)                                                                  # three sub-batches over two streams
+    converter.computeBatch(a, pinned, raw_scale=0.001)
+    converter.computeBatch(b, resident, raw_scale=0.001)
+    ctx.set_subbatch(64, 64)
+    c = [api.Cloud(ctx, rows * cols) for _ in frames]
+    converter.computeBatch(c, pinned, raw_scale=0.001)                                      # one sub-batch: the run of three + two single copies
+    for x, y in zip(a, c):
+        xa, ya = x.arrays(), y.arrays()
+        for k in xa:
+            assert np.array_equal(xa[k].view(np.uint32), ya[k].view(np.uint32)), k
+    for x, y, z in zip(a, b, world["refs"]):
+        xa, ya, za = x.arrays(), y.arrays(), z.arrays()
+        for k in xa:
+            assert np.array_equal(xa[k].view(np.uint32), ya[k].view(np.uint32)) and np.array_equal(xa[k].view(np.uint32), za[k].view(np.uint32)), k
+    # pwn_hip_copy_async: the convert call that follows waits for the queued copies; frames addressed inside one device block
+    dev = ctx.upload(np.zeros((3, rows, cols), np.uint16))
+    dev.copy_from_async(block)
+    e = [api.Cloud(ctx, rows * cols) for _ in range(3)]
+    converter.computeBatch(e, [dev.frame(i) for i in range(3)], raw_scale=0.001)
+    assert np.array_equal(dev.numpy(), block)
+    for x, y in zip(a, e):
+        xa, ya = x.arrays(), y.arrays()
+        for k in xa:
+            assert np.array_equal(xa[k].view(np.uint32), ya[k].view(np.uint32)), k
+    dev.free()
+    api.pinned_free(block)
+    for d in pinned[3:]:
+        api.pinned_free(d)
+    for d in resident:
+        d.free()
+
+
 def test_forward_backward_consistency(world):
     """align(ref, cur) and align(cur, ref) are inverse motions (up to the accuracy of the registration itself)."""
     aligner = world["aligner"]
