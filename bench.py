@@ -536,6 +536,57 @@ def run_tracker(device, frames_mm, poses, scale=1):
     return out
 
 
+def run_tracker_replicas(device, frames_mm, replicas=4, scale=1):
+    """the tracker is serial across frames -- more streams, not more GPUs per stream.  `replicas` independent trackers
+    (one context and one host thread each, the same 200 frames) on ONE GPU: a single VGA pair fills 150 of the 256 CUs for a few
+    microseconds at a time, so the launches of different streams interleave."""
+    import threading
+    from g2o_frontend_amd import api, synth
+    rows, cols, K = 480, 640, synth.K_VGA
+    _, conv, alig = conf(rows, cols)
+    Km = np.array([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]], np.float32)
+    I = np.eye(4, dtype=np.float32)
+    ctx0 = api.Context(device, rows, cols, 2)
+    frames = [ctx0.DepthImage_convert_16UC1_to_32FC1(f) for f in frames_mm]
+    ctx0.close()
+    gate = threading.Barrier(replicas + 1)
+    finals, errors = [None] * replicas, []
+
+    def stream(k):
+        try:
+            ctx = api.Context(device, rows, cols, 2)
+            converter, al = build_objects(ctx, rows, cols, K, conv, alig)
+            alproj = api.PinholePointProjector(); alproj.setMinDistance(alig["min_distance"]); alproj.setMaxDistance(alig["max_distance"])
+            al.setProjector(alproj)
+            tracker = api.PwnTracker(al, converter); tracker.setScale(scale)
+            tracker.processFrame(frames[0], I, Km); tracker.processFrame(frames[1], I, Km); tracker.init()
+            gate.wait(); gate.wait()
+            for d in frames:
+                tracker.processFrame(d, I, Km)
+            finals[k] = tracker.globalT().copy()
+            gate.wait()
+            ctx.close()
+        except Exception as e:      # a failing stream must not leave the others waiting at the gate
+            errors.append(repr(e)); gate.abort()
+
+    threads = [threading.Thread(target=stream, args=(k,)) for k in range(replicas)]
+    for t in threads:
+        t.start()
+    try:
+        gate.wait(); t0 = time.perf_counter(); gate.wait()
+        gate.wait(); dt = time.perf_counter() - t0
+    except threading.BrokenBarrierError:
+        dt = None
+    for t in threads:
+        t.join()
+    if dt is None or errors:
+        return {"replicas": replicas, "error": "; ".join(errors) or "barrier broken"}
+    return {"replicas": replicas, "frames_per_s_total": replicas * len(frames) / dt, "frames_per_stream": len(frames), "scale": scale,
+            "ms_per_frame_per_stream": dt / len(frames) * 1e3,
+            "streams_bitwise_equal": bool(all(np.array_equal(finals[0], f) for f in finals[1:])),
+            "note": "independent tracker streams on one GPU, one context + host thread each (Python threads; ctypes releases the GIL during the calls)"}
+
+
 def chi2_match(traces, res, w=None):
     """The chi2 parity gate that travels with the throughput number.  Teacher-forced (the gate, bar 1e-5): every iteration
     of the CPU oracle's trace re-run on the GPU from the oracle's own iterate -- the same inputs on both sides, so K_i, C_i, inliers_i
@@ -733,6 +784,7 @@ def main():
     if extras_on and poses is not None:
         try:
             extra["tracker_config2"] = run_tracker(local, frames_trk, poses)
+            extra["tracker_config2"]["replicas_on_one_gpu"] = run_tracker_replicas(local, frames_trk, replicas=4)
         except Exception as e:
             extra["tracker_error"] = repr(e)[:300]
 
