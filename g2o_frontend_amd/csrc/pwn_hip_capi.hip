@@ -247,6 +247,7 @@ ConvertParams make_convert_params(const pwn_hip_ctx* ctx, const pwn_hip_converte
   cp.offset = forced(p->sensor_offset);
   cp.hasOffset = is_identity(cp.offset) ? 0 : 1;
   cp.keepStats = keep_stats;
+  cp.lean = 0;
   return cp;
 }
 // class matrices of the normal information matrix, after Cloud::transformInPlace (T * Omega * T^t, informationmatrix.h:111-121)
@@ -438,13 +439,17 @@ int sync_and_counts(pwn_hip_ctx* ctx, pwn_hip_cloud* const* clouds, int n) {
 
 template <typename SRC>
 int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const SRC* const* frames, float depth_scale, int n,
-                       int rows, int cols, pwn_hip_cloud* const* clouds, int keep_stats) {
+                       int rows, int cols, pwn_hip_cloud* const* clouds, int keep_stats, bool want_interval = false) {
   if (!ctx || !p || !frames || !clouds || n < 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if (int rc = check_image(ctx, rows, cols)) return rc;
   if (int rc = absorb_copies(ctx)) return rc;
   const size_t N = (size_t)rows * cols;
   ctx->stages.clear();
-  const ConvertParams cp = make_convert_params(ctx, p, nullptr, rows, cols, keep_stats);
+#ifndef PWN_LEAN
+#define PWN_LEAN 1      // 0: the front end always stores points and intervals (A/B experiments)
+#endif
+  ConvertParams cp = make_convert_params(ctx, p, nullptr, rows, cols, keep_stats);
+  cp.lean = (PWN_LEAN && !want_interval) ? 1 : 0;      // the interval image leaves the converter only through pwn_hip_convert(..., interval_image)
   const StreamPlan plan = make_plan(ctx, ctx->sub_frames, n);
   const int sub = plan.sub;
   if (int rc = ensure_desc(ctx, n)) return rc;
@@ -1094,7 +1099,7 @@ int pwn_hip_convert(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const f
                     int* index_image, int* interval_image, int keep_stats) {
   const float* frames[1] = { depth };
   pwn_hip_cloud* clouds[1] = { cloud };
-  if (int rc = convert_batch_impl<float>(ctx, p, frames, 0.f, 1, rows, cols, clouds, keep_stats)) return rc;
+  if (int rc = convert_batch_impl<float>(ctx, p, frames, 0.f, 1, rows, cols, clouds, keep_stats, interval_image != nullptr)) return rc;
   const size_t N = (size_t)rows * cols;
   if (index_image) HIPCHK(ctx, hipMemcpy(index_image, ctx->frames_host[0].index, N * 4, hipMemcpyDefault), PWN_HIP_ERR_COPY);
   if (interval_image) HIPCHK(ctx, hipMemcpy(interval_image, ctx->frames_host[0].interval, N * 4, hipMemcpyDefault), PWN_HIP_ERR_COPY);

@@ -95,6 +95,8 @@ struct ConvertParams {
   int keepStats;
   int spinLimit;             // polls of a strip hand-over word before a waiting lane gives up and raises the fault flag (kSpinLimit)
   int dbgWithhold;           // test hook (pwn_hip_debug_withhold_carry): index of one hand-over word that is NOT written, -1 = none
+  int lean;                  // 1 = the front end (k_unproject_integral*) stores neither the points nor the interval image and k_stats recomputes
+                             // both from the depth (the same expressions, the same bits): 20 bytes per pixel less written and 18 less read back
 };
 
 struct PairState {
@@ -455,17 +457,19 @@ __global__ void __launch_bounds__(256) k_unproject_integral_rows(const FrameDesc
         p.z = dot4seq(cp.iKRt(2,0), a, cp.iKRt(2,1), b, cp.iKRt(2,2), d, cp.iKRt(2,3), 1.0f);
         p.w = 0.f;
         if (idx < f.cloud.capacity) {
-          f.cloud.P[idx] = p;
+          if (!cp.lean) f.cloud.P[idx] = p;
           v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = 1.0f;
           v[4] = p.x * p.x; v[5] = p.x * p.y; v[6] = p.x * p.z;
           v[7] = p.y * p.y; v[8] = p.y * p.z; v[9] = p.z * p.z;
         }
-        const float inv = 1.0f / d;
-        const float px = cp.ivx * inv, py = cp.ivy * inv;
-        itv = (px > py) ? (int)px : (int)py;
+        if (!cp.lean) {
+          const float inv = 1.0f / d;
+          const float px = cp.ivx * inv, py = cp.ivy * inv;
+          itv = (px > py) ? (int)px : (int)py;
+        }
       }
       f.index[(size_t)r * cols + c] = idx;
-      f.interval[(size_t)r * cols + c] = itv;
+      if (!cp.lean) f.interval[(size_t)r * cols + c] = itv;
     }
 #pragma unroll
     for (int k = 0; k < kIntegralChannels; ++k) tile[(k * kIR_Rows + lr) * kIR_Stride + lc] = v[k];
@@ -637,6 +641,7 @@ __global__ void __launch_bounds__(kII_Threads) k_unproject_integral(const FrameD
   const gptr<v4f> gP = as_global((v4f*)f.cloud.P);
   const gptr<unsigned long long> gcarry = as_global(f.carry);
   const int capacity = f.cloud.capacity;
+  const bool lean = cp.lean != 0;
   float vcarry[3] = { 0.f, 0.f, 0.f };
   bool starved = false;
 
@@ -724,18 +729,20 @@ __global__ void __launch_bounds__(kII_Threads) k_unproject_integral(const FrameD
             p.z = dot4seq(cp.iKRt(2,0), a, cp.iKRt(2,1), b, cp.iKRt(2,2), dd, cp.iKRt(2,3), 1.0f);
             p.w = 0.f;
             if (idx < capacity) {
-              if (!(PWN_II_X & 2)) store4(gP + idx, p);
+              if (!(PWN_II_X & 2) && !lean) store4(gP + idx, p);
               v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = 1.0f;
               v[4] = p.x * p.x; v[5] = p.x * p.y; v[6] = p.x * p.z;
               v[7] = p.y * p.y; v[8] = p.y * p.z; v[9] = p.z * p.z;
             }
-            const float inv = 1.0f / dd;
-            const float px = cp.ivx * inv, py = cp.ivy * inv;
-            itv = (px > py) ? (int)px : (int)py;
+            if (!lean) {
+              const float inv = 1.0f / dd;
+              const float px = cp.ivx * inv, py = cp.ivy * inv;
+              itv = (px > py) ? (int)px : (int)py;
+            }
           }
           if (!(PWN_II_X & 2) || idx == -12345) {
-          if (PWN_II_NT & 2) { __builtin_nontemporal_store(idx, gindex + (unsigned)(r * cols + c)); __builtin_nontemporal_store(itv, ginterval + (unsigned)(r * cols + c)); }
-          else { gindex[(unsigned)(r * cols + c)] = idx; ginterval[(unsigned)(r * cols + c)] = itv; } }
+          if (PWN_II_NT & 2) { __builtin_nontemporal_store(idx, gindex + (unsigned)(r * cols + c)); if (!lean) __builtin_nontemporal_store(itv, ginterval + (unsigned)(r * cols + c)); }
+          else { gindex[(unsigned)(r * cols + c)] = idx; if (!lean) ginterval[(unsigned)(r * cols + c)] = itv; } }
         }
 #pragma unroll
         for (int k = 0; k < kIntegralChannels; ++k) tile[(k * kIR_Rows + lr) * kIR_Stride + lane] = v[k];
@@ -872,9 +879,25 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
   const unsigned upix = (unsigned)(r * cols + c);
   const int idx = stream_load(gindex + upix);
   if (idx < 0 || idx >= cap) return;
-  const int itv = stream_load(ginterval + upix);
+  int itv;
   float4 P;
-  { const v4f pv = stream_load((gptr<const v4f>)(gP + 4u * (unsigned)idx)); P.x = pv.x; P.y = pv.y; P.z = pv.z; P.w = 0.f; }      // one 16-byte load
+  if (cp.lean) {
+    // the front end kept the point and the interval to itself: the same expressions on the same depth (pinholepointprojector.h:246-251,264-274)
+    float d;
+    if (f.raw) { const unsigned sv = stream_load(as_global(f.raw) + upix); d = sv ? f.raw_scale * (float)sv : 0.0f; }
+    else d = stream_load(as_global(f.depth) + upix);
+    const float a = (float)c * d, b = (float)r * d;
+    P.x = dot4seq(cp.iKRt(0,0), a, cp.iKRt(0,1), b, cp.iKRt(0,2), d, cp.iKRt(0,3), 1.0f);
+    P.y = dot4seq(cp.iKRt(1,0), a, cp.iKRt(1,1), b, cp.iKRt(1,2), d, cp.iKRt(1,3), 1.0f);
+    P.z = dot4seq(cp.iKRt(2,0), a, cp.iKRt(2,1), b, cp.iKRt(2,2), d, cp.iKRt(2,3), 1.0f);
+    P.w = 0.f;
+    const float inv = 1.0f / d;
+    const float px = cp.ivx * inv, py = cp.ivy * inv;
+    itv = (px > py) ? (int)px : (int)py;
+  } else {
+    itv = stream_load(ginterval + upix);
+    const v4f pv = stream_load((gptr<const v4f>)(gP + 4u * (unsigned)idx)); P.x = pv.x; P.y = pv.y; P.z = pv.z; P.w = 0.f;      // one 16-byte load
+  }
   float nx = 0.f, ny = 0.f, nz = 0.f;
   float curvature = 0.f;          // Stats() default: eigenvalues 0 -> curvature() = 0/(0+1e-9) = 0  (stats.h:21-27,98-103)
   int cls = 0;
