@@ -110,10 +110,10 @@ struct pwn_hip_ctx {
 namespace {
 
 constexpr size_t kCloudPoolBytes = 1ull << 30;
-size_t cloud_core_bytes(const pwn_hip_cloud* c) { return (size_t)c->d.capacity * (2 * sizeof(float4) + 9 * sizeof(float)) + c->idx_cap * sizeof(int); }
+size_t cloud_core_bytes(const pwn_hip_cloud* c) { return (size_t)c->d.capacity * (3 * sizeof(float) + sizeof(float4) + 9 * sizeof(float)) + c->idx_cap * sizeof(int); }
 void cloud_free(pwn_hip_cloud* c) {
-  void* p[] = { c->d.P, c->d.Nm, c->d.Om, c->d.OmN, c->d.St, c->d.count, c->sb.G, c->sb.Gf,
-                c->back.P, c->back.Nm, c->back.Om, c->back.OmN, c->back.St, c->sback.G, c->sback.Gf, c->idximg };
+  void* p[] = { c->d.P3, c->d.Nc, c->d.Om, c->d.OmN, c->d.St, c->d.count, c->sb.G, c->sb.Gf,
+                c->back.P3, c->back.Nc, c->back.Om, c->back.OmN, c->back.St, c->sback.G, c->sback.Gf, c->idximg };
   for (void* q : p) if (q) (void)hipFree(q);
   delete c;
 }
@@ -264,6 +264,35 @@ void make_omega_n_classes(const pwn_hip_converter_params* p, CloudDev& d) {
     }
     for (int k = 0; k < 9; ++k) d.omN[c][k] = om[k];
   }
+  d.clsThr = p->normal_info_curvature_threshold;      // what normal_class() needs to tell flat from non-flat
+}
+// Host staging in the records the rest of the host code was written for: P = (x, y, z, curvature), Nm = (nx, ny, nz, class word), n
+// points each; the device keeps 12-byte points and (normal, curvature) records (pwn_kernels.h).
+int cloud_fetch_records(pwn_hip_ctx* ctx, const CloudDev& d, int n, std::vector<float>& P, std::vector<float>& Nm) {
+  std::vector<float> p3((size_t)n * 3), nc((size_t)n * 4);
+  if (n > 0) {
+    HIPCHK(ctx, hipMemcpy(p3.data(), d.P3, p3.size() * 4, hipMemcpyDeviceToHost), PWN_HIP_ERR_COPY);
+    HIPCHK(ctx, hipMemcpy(nc.data(), d.Nc, nc.size() * 4, hipMemcpyDeviceToHost), PWN_HIP_ERR_COPY);
+  }
+  P.resize((size_t)n * 4); Nm.resize((size_t)n * 4);
+  for (int i = 0; i < n; ++i) {
+    P[4 * i] = p3[3 * i]; P[4 * i + 1] = p3[3 * i + 1]; P[4 * i + 2] = p3[3 * i + 2]; P[4 * i + 3] = nc[4 * i + 3];
+    Nm[4 * i] = nc[4 * i]; Nm[4 * i + 1] = nc[4 * i + 1]; Nm[4 * i + 2] = nc[4 * i + 2];
+    const int cls = normal_class(nc[4 * i], nc[4 * i + 1], nc[4 * i + 2], nc[4 * i + 3], d.clsThr);
+    std::memcpy(&Nm[4 * i + 3], &cls, 4);
+  }
+  return PWN_HIP_OK;
+}
+int cloud_store_records(pwn_hip_ctx* ctx, const CloudDev& d, int n, const std::vector<float>& P, const std::vector<float>& Nm) {
+  if (n <= 0) return PWN_HIP_OK;
+  std::vector<float> p3((size_t)n * 3), nc((size_t)n * 4);
+  for (int i = 0; i < n; ++i) {
+    p3[3 * i] = P[4 * i]; p3[3 * i + 1] = P[4 * i + 1]; p3[3 * i + 2] = P[4 * i + 2];
+    nc[4 * i] = Nm[4 * i]; nc[4 * i + 1] = Nm[4 * i + 1]; nc[4 * i + 2] = Nm[4 * i + 2]; nc[4 * i + 3] = P[4 * i + 3];
+  }
+  HIPCHK(ctx, hipMemcpy(d.P3, p3.data(), p3.size() * 4, hipMemcpyHostToDevice), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipMemcpy(d.Nc, nc.data(), nc.size() * 4, hipMemcpyHostToDevice), PWN_HIP_ERR_COPY);
+  return PWN_HIP_OK;
 }
 AlignParams make_align_params(const pwn_hip_aligner_params* p) {
   AlignParams ap;
@@ -835,8 +864,8 @@ int pwn_hip_cloud_create(pwn_hip_ctx* ctx, int capacity, pwn_hip_cloud** out) {
   std::memset(&c->d, 0, sizeof(c->d));
   c->d.capacity = capacity;
   const size_t cap = (size_t)capacity;
-  hipError_t e = hipMalloc((void**)&c->d.P, cap * sizeof(float4));
-  if (e == hipSuccess) e = hipMalloc((void**)&c->d.Nm, cap * sizeof(float4));
+  hipError_t e = hipMalloc((void**)&c->d.P3, cap * 3 * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d.Nc, cap * sizeof(float4));
   if (e == hipSuccess) e = hipMalloc((void**)&c->d.Om, cap * 9 * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void**)&c->d.count, sizeof(int));
   if (e == hipSuccess) e = hipMemsetAsync(c->d.count, 0, sizeof(int), ctx->stream);
@@ -849,9 +878,9 @@ int pwn_hip_cloud_destroy(pwn_hip_ctx* ctx, pwn_hip_cloud* c) {
   cloud_changes(ctx, c);
   // plain clouds (no scene-stage or uploaded extras) retire into the context's pool: every call that used them has joined its streams
   // back into ctx->stream before returning, and a reuse is enqueued on that stream
-  const bool plain = !c->d.OmN && !c->d.St && !c->sb.G && !c->sb.Gf && !c->back.P && !c->back.Nm && !c->back.Om && !c->back.OmN && !c->back.St &&
+  const bool plain = !c->d.OmN && !c->d.St && !c->sb.G && !c->sb.Gf && !c->back.P3 && !c->back.Nc && !c->back.Om && !c->back.OmN && !c->back.St &&
                      !c->sback.G && !c->sback.Gf;
-  if (ctx && plain && c->d.P && c->d.Nm && c->d.Om && c->d.count && ctx->cloud_pool_bytes + cloud_core_bytes(c) <= kCloudPoolBytes) {
+  if (ctx && plain && c->d.P3 && c->d.Nc && c->d.Om && c->d.count && ctx->cloud_pool_bytes + cloud_core_bytes(c) <= kCloudPoolBytes) {
     c->n_host = 0; c->has_stats = false; c->n_gauss = 0; c->idx_valid = false;
     ctx->cloud_pool.push_back(c);
     ctx->cloud_pool_bytes += cloud_core_bytes(c);
@@ -891,8 +920,7 @@ int pwn_hip_cloud_upload(pwn_hip_ctx* ctx, pwn_hip_cloud* c, int n, const float*
     }
   }
   if (!c->d.OmN) HIPCHK(ctx, hipMalloc((void**)&c->d.OmN, cap * 9 * sizeof(float)), PWN_HIP_ERR_ALLOCATION);
-  HIPCHK(ctx, hipMemcpy(c->d.P, P.data(), P.size() * 4, hipMemcpyHostToDevice), PWN_HIP_ERR_COPY);
-  HIPCHK(ctx, hipMemcpy(c->d.Nm, Nm.data(), Nm.size() * 4, hipMemcpyHostToDevice), PWN_HIP_ERR_COPY);
+  if (int rc = cloud_store_records(ctx, c->d, n, P, Nm)) return rc;
   HIPCHK(ctx, hipMemcpy(c->d.Om, Om.data(), Om.size() * 4, hipMemcpyHostToDevice), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipMemcpy(c->d.OmN, OmN.data(), OmN.size() * 4, hipMemcpyHostToDevice), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipMemcpy(c->d.count, &n, sizeof(int), hipMemcpyHostToDevice), PWN_HIP_ERR_COPY);
@@ -903,9 +931,8 @@ int pwn_hip_cloud_download(pwn_hip_ctx* ctx, const pwn_hip_cloud* c, float* poin
   if (!ctx || !c) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   const int n = c->n_host; const size_t cap = (size_t)c->d.capacity;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
-  std::vector<float> P((size_t)n * 4), Nm((size_t)n * 4);
-  HIPCHK(ctx, hipMemcpy(P.data(), c->d.P, P.size() * 4, hipMemcpyDeviceToHost), PWN_HIP_ERR_COPY);
-  HIPCHK(ctx, hipMemcpy(Nm.data(), c->d.Nm, Nm.size() * 4, hipMemcpyDeviceToHost), PWN_HIP_ERR_COPY);
+  std::vector<float> P, Nm;
+  if (int rc = cloud_fetch_records(ctx, c->d, n, P, Nm)) return rc;
   std::vector<float> hp, hn, hc, hop, hon;
   if (points) { hp.resize((size_t)n * 4); for (int i = 0; i < n; ++i) { hp[4*i] = P[4*i]; hp[4*i+1] = P[4*i+1]; hp[4*i+2] = P[4*i+2]; hp[4*i+3] = 1.0f; } }
   if (normals) { hn.resize((size_t)n * 4); for (int i = 0; i < n; ++i) { hn[4*i] = Nm[4*i]; hn[4*i+1] = Nm[4*i+1]; hn[4*i+2] = Nm[4*i+2]; hn[4*i+3] = 0.0f; } }
@@ -1050,7 +1077,7 @@ int pwn_hip_unproject(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const
   const ConvertParams cp = make_convert_params(ctx, p, T, rows, cols, 0);
   const float* d = nullptr;
   if (int rc = stage_depth(ctx, depth, N, &d)) return rc;
-  HIPCHK(ctx, hipMemsetAsync(cloud->d.Nm, 0, sizeof(float4) * (size_t)cloud->d.capacity, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipMemsetAsync(cloud->d.Nc, 0, sizeof(float4) * (size_t)cloud->d.capacity, ctx->stream), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipMemsetAsync(cloud->d.Om, 0, sizeof(float) * 9 * (size_t)cloud->d.capacity, ctx->stream), PWN_HIP_ERR_COPY);
   fill_frame(ctx, 0, 0, d, cloud->d, rows);
   HIPCHK(ctx, hipMemcpyAsync(ctx->frames_dev, ctx->frames_host, sizeof(FrameDesc), hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);

@@ -3,9 +3,13 @@
 // One kernel per stage of the reference's CPU path (g2o_frontend/pwn_core/, cited per kernel).
 // All kernels are batched: blockIdx.y selects the frame / pair, whose buffers are described by a
 // FrameDesc / PairDesc record in device memory.  Layout in HBM is SoA:
-//   cloud:  P[i]  = float4(x, y, z, curvature)            (Point + Stats::curvature())
-//           Nm[i] = float4(nx, ny, nz, bits(omegaN class)) (Normal; class 0 = zero, 1 = flat, 2 = non-flat)
+//   cloud:  P3[3*i .. 3*i+2] = x, y, z                     (Point: 12 bytes -- the projection reads nothing else)
+//           Nc[i] = float4(nx, ny, nz, curvature)          (Normal + Stats::curvature(); the class of the normal information matrix --
+//                   0 = zero, 1 = flat, 2 = non-flat -- is not stored: normal_class() derives it from this record and the threshold the
+//                   cloud was converted with)
 //           Om[k*cap + i], k = 3*r + c                     (point information matrix, 9 planes)
+//           64 bytes per point; until round 2 the point carried the curvature and the normal a class word (68 bytes): the fused pass
+//           fetches 8 bytes less per candidate (-7.5 % of its time), the projection 4 of 16 bytes less per point
 //   images: row-major int32 / float32, lanes along image x (row-coalesced loads)
 //   integral image: 10 planes [ch][rows][cols] (x y z n xx xy xz yy yz zz)
 //   z-buffer of the aligner: uint32 per pixel = epoch tag (11 b) | point index (21 b), empty = ~0 (kZ32Tag0);
@@ -57,18 +61,25 @@ constexpr unsigned kZ32IndexMask = (1u << kZIndexBits) - 1u;
 __host__ __device__ __forceinline__ unsigned z32key(unsigned tag, int i) { return (tag << kZIndexBits) | (unsigned)i; }
 __host__ __device__ __forceinline__ int z32_index(unsigned w, unsigned tag) { return ((w >> kZIndexBits) == tag) ? (int)(w & kZ32IndexMask) : -1; }
 
-constexpr int kClsMask = 3;      // Nm[i].w: class of the normal information matrix (0 zero, 1 flat, 2 non-flat)
+constexpr int kClsMask = 3;      // class of the normal information matrix (0 zero, 1 flat, 2 non-flat) as a word in the old-format view (cloud_get)
 
 struct CloudDev {
-  float4* P;
-  float4* Nm;
+  float*  P3;        // [capacity][3] x y z
+  float4* Nc;        // [capacity] (nx, ny, nz, curvature)
   float*  Om;        // [9][capacity]
   float*  OmN;       // optional [9][capacity] full normal information matrices (uploaded clouds), else nullptr
   float*  St;        // optional [capacity][16] stats: U(9, column-major) eigenvalues(3) mean(3) n(1)
   int*    count;
   int     capacity;
   float   omN[2][9]; // class matrices (row-major 3x3): [0] flat, [1] non-flat
+  float   clsThr;    // NormalInformationMatrixCalculator::_curvatureThreshold the cloud was converted with (informationmatrixcalculator.cpp:47-52)
 };
+// NormalInformationMatrixCalculator::compute (informationmatrixcalculator.cpp:38-58): zero normal -> zero matrix, else flat / non-flat by
+// the curvature.  The converter decides on the normal before the sensor offset is applied; a rotation does not turn a non-zero normal
+// into the zero vector, and a candidate with a zero normal is rejected before its class is looked at (correspondencefinder.cpp:69).
+__host__ __device__ __forceinline__ int normal_class(float nx, float ny, float nz, float curvature, float thr) {
+  return (nx != 0.f || ny != 0.f || nz != 0.f) ? ((curvature < thr) ? 1 : 2) : 0;
+}
 
 struct FrameDesc {
   const float* depth;        // float32 metres, or nullptr when `raw` is used
@@ -170,6 +181,23 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 load4(gptr<const v4f> p) { const v4f v = *p; return make_float4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ void store4(gptr<v4f> p, const float4 v) { v4f t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *p = t; }
+typedef float v3f __attribute__((ext_vector_type(3)));
+// point i of a packed xyz array as (x, y, z, 0): one 12-byte load
+__device__ __forceinline__ float4 load_xyz(gptr<const float> p3, unsigned i) { const v3f v = *(gptr<const v3f>)(p3 + 3u * i); return make_float4(v.x, v.y, v.z, 0.f); }
+__device__ __forceinline__ float4 load_xyz(const float* p3, int i) { return load_xyz(as_global(p3), (unsigned)i); }
+__device__ __forceinline__ void store_xyz(float* p3, int i, float x, float y, float z) { v3f v; v.x = x; v.y = y; v.z = z; *(gptr<v3f>)(as_global(p3) + 3u * (unsigned)i) = v; }
+// Old-format view of point i for the code that is not hot (scene stage, stand-alone stages): P = (x, y, z, curvature),
+// Nm = (nx, ny, nz, class word); cloud_put stores the same view back (the class word is derived data and is dropped).
+__device__ __forceinline__ void cloud_get(const CloudDev& c, int i, float4& P, float4& Nm) {
+  P = load_xyz(c.P3, i);
+  const float4 nc = c.Nc[i];
+  P.w = nc.w;
+  Nm = make_float4(nc.x, nc.y, nc.z, __int_as_float(normal_class(nc.x, nc.y, nc.z, nc.w, c.clsThr)));
+}
+__device__ __forceinline__ void cloud_put(const CloudDev& c, int i, const float4 P, const float4 Nm) {
+  store_xyz(c.P3, i, P.x, P.y, P.z);
+  c.Nc[i] = make_float4(Nm.x, Nm.y, Nm.z, P.w);
+}
 // force a wave-uniform value into a scalar register
 __device__ __forceinline__ float uniform(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 __device__ __forceinline__ Mat4 uniform_iso(const Mat4& T) {
@@ -319,7 +347,7 @@ __global__ void __launch_bounds__(256) k_unproject(const FrameDesc* __restrict__
         p.y = dot4seq(cp.iKRt(1,0), a, cp.iKRt(1,1), b, cp.iKRt(1,2), d, cp.iKRt(1,3), 1.0f);
         p.z = dot4seq(cp.iKRt(2,0), a, cp.iKRt(2,1), b, cp.iKRt(2,2), d, cp.iKRt(2,3), 1.0f);
         p.w = 0.f;
-        if (f.cloud.P && idx < f.cloud.capacity) f.cloud.P[idx] = p;
+        if (f.cloud.P3 && idx < f.cloud.capacity) store_xyz(f.cloud.P3, idx, p.x, p.y, p.z);
         // _projectInterval: int(max(fx*R/d, fy*R/d))
         const float inv = 1.0f / d;
         const float px = cp.ivx * inv, py = cp.ivy * inv;
@@ -367,7 +395,7 @@ __global__ void __launch_bounds__(256) k_integral_rows(const FrameDesc* __restri
       if (r < rows && c < cols) {
         const int idx = f.index[(size_t)r * cols + c];
         if (idx >= 0 && idx < f.cloud.capacity) {
-          const float4 p = f.cloud.P[idx];
+          const float4 p = load_xyz(f.cloud.P3, idx);
           v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = 1.0f;
           v[4] = p.x * p.x; v[5] = p.x * p.y; v[6] = p.x * p.z;
           v[7] = p.y * p.y; v[8] = p.y * p.z; v[9] = p.z * p.z;
@@ -457,7 +485,7 @@ __global__ void __launch_bounds__(256) k_unproject_integral_rows(const FrameDesc
         p.z = dot4seq(cp.iKRt(2,0), a, cp.iKRt(2,1), b, cp.iKRt(2,2), d, cp.iKRt(2,3), 1.0f);
         p.w = 0.f;
         if (idx < f.cloud.capacity) {
-          if (!cp.lean) f.cloud.P[idx] = p;
+          if (!cp.lean) store_xyz(f.cloud.P3, idx, p.x, p.y, p.z);
           v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = 1.0f;
           v[4] = p.x * p.x; v[5] = p.x * p.y; v[6] = p.x * p.z;
           v[7] = p.y * p.y; v[8] = p.y * p.z; v[9] = p.z * p.z;
@@ -638,7 +666,7 @@ __global__ void __launch_bounds__(kII_Threads) k_unproject_integral(const FrameD
   const gptr<const int> growoff = as_global((const int*)f.rowoff);
   const gptr<int> gindex = as_global(f.index), ginterval = as_global(f.interval);
   const gptr<float> gintegral = as_global(f.integral);
-  const gptr<v4f> gP = as_global((v4f*)f.cloud.P);
+  float* const gP3 = f.cloud.P3;
   const gptr<unsigned long long> gcarry = as_global(f.carry);
   const int capacity = f.cloud.capacity;
   const bool lean = cp.lean != 0;
@@ -729,7 +757,7 @@ __global__ void __launch_bounds__(kII_Threads) k_unproject_integral(const FrameD
             p.z = dot4seq(cp.iKRt(2,0), a, cp.iKRt(2,1), b, cp.iKRt(2,2), dd, cp.iKRt(2,3), 1.0f);
             p.w = 0.f;
             if (idx < capacity) {
-              if (!(PWN_II_X & 2) && !lean) store4(gP + idx, p);
+              if (!(PWN_II_X & 2) && !lean) store_xyz(gP3, idx, p.x, p.y, p.z);
               v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = 1.0f;
               v[4] = p.x * p.x; v[5] = p.x * p.y; v[6] = p.x * p.z;
               v[7] = p.y * p.y; v[8] = p.y * p.z; v[9] = p.z * p.z;
@@ -874,7 +902,7 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
   // base and a 32-bit lane offset instead of flat_* with 64-bit VALU address arithmetic (the kernel is VALU-bound)
   const gptr<const int> gindex = as_global((const int*)f.index), ginterval = as_global((const int*)f.interval);
   const gptr<const float> gintegral = as_global((const float*)f.integral);
-  const gptr<float> gP = as_global((float*)f.cloud.P), gN = as_global((float*)f.cloud.Nm), gOm = as_global(f.cloud.Om);
+  const gptr<float> gP = as_global(f.cloud.P3), gN = as_global((float*)f.cloud.Nc), gOm = as_global(f.cloud.Om);
   const int cap = f.cloud.capacity;
   const unsigned upix = (unsigned)(r * cols + c);
   const int idx = stream_load(gindex + upix);
@@ -896,7 +924,7 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
     itv = (px > py) ? (int)px : (int)py;
   } else {
     itv = stream_load(ginterval + upix);
-    const v4f pv = stream_load((gptr<const v4f>)(gP + 4u * (unsigned)idx)); P.x = pv.x; P.y = pv.y; P.z = pv.z; P.w = 0.f;      // one 16-byte load
+    const v3f pv = stream_load((gptr<const v3f>)(gP + 3u * (unsigned)idx)); P.x = pv.x; P.y = pv.y; P.z = pv.z; P.w = 0.f;      // one 12-byte load
   }
   float nx = 0.f, ny = 0.f, nz = 0.f;
   float curvature = 0.f;          // Stats() default: eigenvalues 0 -> curvature() = 0/(0+1e-9) = 0  (stats.h:21-27,98-103)
@@ -1011,12 +1039,12 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
 #pragma unroll
       for (int j = 0; j < 3; ++j) om[3 * i + j] = dot3seq(t1[3 * i], m(j,0), t1[3 * i + 1], m(j,1), t1[3 * i + 2], m(j,2));
   }
-  P.w = curvature;
+  (void)cls;      // not stored: normal_class(normal, curvature, normalInfoCurvThr) gives it back
   {
-    // one 16-byte store each (four dword stores per lane would write every 1 KiB segment of the wave four times at quarter density)
-    v4f pv; pv.x = P.x; pv.y = P.y; pv.z = P.z; pv.w = P.w;
-    v4f nv; nv.x = nx; nv.y = ny; nv.z = nz; nv.w = __int_as_float(cls);
-    stream_store((gptr<v4f>)(gP + 4u * (unsigned)idx), pv);
+    // one 12-byte and one 16-byte store (dword stores per lane would write every 1 KiB segment of the wave several times at a fraction of the density)
+    v3f pv; pv.x = P.x; pv.y = P.y; pv.z = P.z;
+    v4f nv; nv.x = nx; nv.y = ny; nv.z = nz; nv.w = curvature;
+    stream_store((gptr<v3f>)(gP + 3u * (unsigned)idx), pv);
     stream_store((gptr<v4f>)(gN + 4u * (unsigned)idx), nv);
   }
 #pragma unroll
@@ -1027,7 +1055,8 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
 __global__ void __launch_bounds__(256) k_cloud_transform(CloudDev cl, Mat4 m) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= *cl.count || i >= cl.capacity) return;
-  float4 P = cl.P[i]; float4 Nm = cl.Nm[i];
+  float4 P, Nm;
+  cloud_get(cl, i, P, Nm);
   const float px = dot4seq(m(0,0), P.x, m(0,1), P.y, m(0,2), P.z, m(0,3), 1.0f);
   const float py = dot4seq(m(1,0), P.x, m(1,1), P.y, m(1,2), P.z, m(1,3), 1.0f);
   const float pz = dot4seq(m(2,0), P.x, m(2,1), P.y, m(2,2), P.z, m(2,3), 1.0f);
@@ -1036,7 +1065,6 @@ __global__ void __launch_bounds__(256) k_cloud_transform(CloudDev cl, Mat4 m) {
   const float ty = dot4seq(m(1,0), Nm.x, m(1,1), Nm.y, m(1,2), Nm.z, m(1,3), 0.0f);
   const float tz = dot4seq(m(2,0), Nm.x, m(2,1), Nm.y, m(2,2), Nm.z, m(2,3), 0.0f);
   Nm.x = tx; Nm.y = ty; Nm.z = tz;
-  int word = __float_as_int(Nm.w) & kClsMask;
   for (int pass = 0; pass < 2; ++pass) {
     float* base = pass == 0 ? cl.Om : cl.OmN;
     if (!base) continue;
@@ -1046,8 +1074,7 @@ __global__ void __launch_bounds__(256) k_cloud_transform(CloudDev cl, Mat4 m) {
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) om[3 * a + b] = dot3seq(t1[3 * a], m(b,0), t1[3 * a + 1], m(b,1), t1[3 * a + 2], m(b,2));
     for (int k = 0; k < 9; ++k) base[(size_t)k * cl.capacity + i] = om[k];
   }
-  Nm.w = __int_as_float(word);
-  cl.P[i] = P; cl.Nm[i] = Nm;
+  cloud_put(cl, i, P, Nm);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1096,7 +1123,7 @@ __device__ __forceinline__ Z32Pending z32_insert(const Mat4& KRt, float minD, fl
 // z32_settle: nothing to do for the first point of this projection in its pixel (older tags and the empty word are larger than any key of
 // the current tag); otherwise make sure the word ends up with the nearest of every point this thread gets to see, ties to the lower index.
 // P: the cloud's points (to evaluate the depth of a point met in the pixel).
-__device__ __forceinline__ void z32_settle(const Z32Pending& q, const Mat4& KRt, const float4* __restrict__ P, unsigned tag) {
+__device__ __forceinline__ void z32_settle(const Z32Pending& q, const Mat4& KRt, const float* __restrict__ P3, unsigned tag) {
   if (!q.w || (q.old >> kZIndexBits) != tag) return;
   int best = (int)(q.key & kZ32IndexMask); float dbest = q.d;
   unsigned cur = q.old < q.key ? q.old : q.key;       // what the word holds after the atomicMin, unless someone changed it since
@@ -1104,7 +1131,7 @@ __device__ __forceinline__ void z32_settle(const Z32Pending& q, const Mat4& KRt,
   for (int guard = 0; guard < 1024; ++guard) {
     const int j = (int)(seen & kZ32IndexMask);
     if (j != best) {
-      const float dj = point_depth(KRt, P[j]);
+      const float dj = point_depth(KRt, load_xyz(P3, j));
       if (dj < dbest || (dj == dbest && j < best)) { best = j; dbest = dj; }
     }
     const unsigned want = z32key(tag, best);
@@ -1130,7 +1157,7 @@ __global__ void __launch_bounds__(256) k_project(const PairDesc* __restrict__ pa
   unsigned* z = which ? pd.zcur : pd.zref;
   float4 p[kProjectPointsPerThread];
 #pragma unroll
-  for (int j = 0; j < kProjectPointsPerThread; ++j) { const int i = i0 + 256 * j; if (i < n) p[j] = cl.P[i]; }      // loads first
+  for (int j = 0; j < kProjectPointsPerThread; ++j) { const int i = i0 + 256 * j; if (i < n) p[j] = load_xyz(cl.P3, i); }      // loads first (12 bytes per point)
   Z32Pending q[kProjectPointsPerThread];
 #pragma unroll
   for (int j = 0; j < kProjectPointsPerThread; ++j) {
@@ -1138,7 +1165,7 @@ __global__ void __launch_bounds__(256) k_project(const PairDesc* __restrict__ pa
     if (i < n) q[j] = z32_insert(KRt, ap.minD, ap.maxD, ap.rows, ap.cols, p[j], i, z, tag); else q[j].w = nullptr;
   }
 #pragma unroll
-  for (int j = 0; j < kProjectPointsPerThread; ++j) z32_settle(q[j], KRt, cl.P, tag);
+  for (int j = 0; j < kProjectPointsPerThread; ++j) z32_settle(q[j], KRt, cl.P3, tag);
 }
 // current-cloud z-buffer -> int index image, once per alignment.  grid = (blocks, pairs)
 __global__ void k_resolve_cur(const PairDesc* __restrict__ pairs, int n, unsigned tag) {
@@ -1157,7 +1184,7 @@ __global__ void k_pair_images(const PairDesc* __restrict__ pairs, int which, uns
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     const int k = z32_index(z[i], tag);
     if (index) index[i] = k;
-    if (depth) depth[i] = (k >= 0 && k < np) ? point_depth(KRt, cl.P[k]) : FLT_MAX;
+    if (depth) depth[i] = (k >= 0 && k < np) ? point_depth(KRt, load_xyz(cl.P3, k)) : FLT_MAX;
   }
 }
 // stand-alone projection with an explicit matrix (pwn_hip_project)
@@ -1166,7 +1193,7 @@ __global__ void __launch_bounds__(256) k_project_single(CloudDev cl, Mat4 KRt, f
   const int i = blockIdx.x * 256 + threadIdx.x;
   const int n = min(*cl.count, cl.capacity);
   if (i >= n) return;
-  project_point(KRt, minD, maxD, rows, cols, cl.P[i], i, z, tag);
+  project_point(KRt, minD, maxD, rows, cols, load_xyz(cl.P3, i), i, z, tag);
 }
 // z-buffer -> (index image, depth image): empty pixels -1 / FLT_MAX (pinholepointprojector.cpp:41-42)
 __global__ void k_zbuf_resolve(const unsigned long long* __restrict__ z, int n, int* __restrict__ index, float* __restrict__ depth, unsigned tag) {
@@ -1398,7 +1425,8 @@ struct Candidate {
 // every wait for an LDS accumulator update would also wait for the gathers of the next pixel that are meant to stay in flight.
 // They all point to hipMalloc'ed memory: as_global() -> global_* loads (vmcnt only).
 struct PairPtrs {
-  gptr<const v4f> refP, refN, curP, curN;
+  gptr<const float> refP, curP;      // packed xyz
+  gptr<const v4f> refN, curN;        // (normal, curvature)
   gptr<const float> curOm, curOmN;
   gptr<const unsigned> zref;
   gptr<const int> curidx, refidx0;
@@ -1406,8 +1434,8 @@ struct PairPtrs {
 };
 __device__ __forceinline__ PairPtrs pair_ptrs(const PairDesc& pd) {
   PairPtrs q;
-  q.refP = as_global((const v4f*)pd.ref.P); q.refN = as_global((const v4f*)pd.ref.Nm);
-  q.curP = as_global((const v4f*)pd.cur.P); q.curN = as_global((const v4f*)pd.cur.Nm);
+  q.refP = as_global((const float*)pd.ref.P3); q.refN = as_global((const v4f*)pd.ref.Nc);
+  q.curP = as_global((const float*)pd.cur.P3); q.curN = as_global((const v4f*)pd.cur.Nc);
   q.curOm = as_global((const float*)pd.cur.Om); q.curOmN = as_global((const float*)pd.cur.OmN);
   q.zref = as_global((const unsigned*)pd.zref); q.curidx = as_global((const int*)pd.curidx);
   q.refidx0 = as_global(pd.refidx0);
@@ -1418,12 +1446,14 @@ __device__ __forceinline__ void candidate_load(const PairPtrs& q, int ri, int ci
   c.valid = !(ri < 0 || ci < 0 || ri >= nref || ci >= ncur);
   c.ci = ci;
   if (c.valid) {
-    c.rP = load4(q.refP + (unsigned)ri); c.cP = load4(q.curP + (unsigned)ci); c.cN = load4(q.curN + (unsigned)ci);
+    // 12 + 16 bytes per side; the rest of the pass keeps the (point, curvature) / (normal, -) records it was written for
+    c.rP = load_xyz(q.refP, (unsigned)ri); c.cP = load_xyz(q.curP, (unsigned)ci); c.cN = load4(q.curN + (unsigned)ci);
 #if PWN_CL_X & 2
     c.rN = c.cN;
 #else
     c.rN = load4(q.refN + (unsigned)ri);
 #endif
+    c.rP.w = c.rN.w; c.cP.w = c.cN.w;
 #if PWN_OMEGA_PREFETCH
 #pragma unroll
     for (int k = 0; k < 9; ++k) c.oP[k] = q.curOm[(size_t)k * q.cap + (unsigned)ci];
@@ -1439,8 +1469,7 @@ __device__ __forceinline__ void candidate_consume(const PairDesc& pd, const Pair
   if (!correspondence_test(ap, Tc, c.rP, c.rN, c.cP, c.cN, rp, rn)) return;
   cnt[1] += 1.f;
   float oN[9];
-  const int word = __float_as_int(c.cN.w);
-  const int cls = word & kClsMask;
+  const int cls = (c.cP.w < pd.cur.clsThr) ? 1 : 2;      // normal_class(): the normal is not zero here (correspondence_test)
   if (pd.cur.OmN) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) oN[k] = q.curOmN[(size_t)k * q.cap + (unsigned)c.ci];
@@ -1645,7 +1674,9 @@ __global__ void __launch_bounds__(256) k_correspondence_image(CloudDev ref, Clou
   if (ri >= 0 && ci >= 0 && ri < nref && ci < ncur) {
     atomicAdd(&counters[0], 1);
     float3 rp, rn;
-    if (correspondence_test(ap, Tc, ref.P[ri], ref.Nm[ri], cur.P[ci], cur.Nm[ci], rp, rn)) res = make_int2(ri, ci);
+    float4 rP, rN, cP, cN;
+    cloud_get(ref, ri, rP, rN); cloud_get(cur, ci, cP, cN);
+    if (correspondence_test(ap, Tc, rP, rN, cP, cN, rp, rn)) res = make_int2(ri, ci);
   }
   out[pix] = res;
 }
@@ -1663,7 +1694,8 @@ __global__ void __launch_bounds__(kAlignBlock) k_linearize_list(CloudDev ref, Cl
     const int2 c = corr[i];
     if (c.x < 0 || c.y < 0 || c.x >= nref || c.y >= ncur) continue;
     acc[35] += 1.f;
-    const float4 rP = ref.P[c.x], rN = ref.Nm[c.x], cP = cur.P[c.y], cN = cur.Nm[c.y];
+    float4 rP, rN, cP, cN;
+    cloud_get(ref, c.x, rP, rN); cloud_get(cur, c.y, cP, cN);
     float oP[9], oN[9];
     load_omegas(cur, c.y, __float_as_int(cN.w) & kClsMask, oP, oN);
     const float3 rp = iso_point(Tl, rP), rn = iso_normal(Tl, rN);
@@ -1691,9 +1723,9 @@ __global__ void __launch_bounds__(256) k_match_score(const PairDesc* __restrict_
   const Mat4 KRtRef = uniform_iso(pd.state->KRtLast), KRtCur = uniform_iso(pd.state->KRtCur);
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
     float dc = FLT_MAX, dr = FLT_MAX;
-    if (curOwn) { const int ci = pd.curidx[i]; if (ci >= 0 && ci < ncur) dc = pd.cur.P[ci].z; }
-    else { const int ci = z32_index(pd.zcur[i], curTag); if (ci >= 0 && ci < ncur) dc = point_depth(KRtCur, pd.cur.P[ci]); }
-    { const int ri = z32_index(pd.zref[i], refTag); if (ri >= 0 && ri < nref) dr = point_depth(KRtRef, pd.ref.P[ri]); }
+    if (curOwn) { const int ci = pd.curidx[i]; if (ci >= 0 && ci < ncur) dc = load_xyz(pd.cur.P3, ci).z; }
+    else { const int ci = z32_index(pd.zcur[i], curTag); if (ci >= 0 && ci < ncur) dc = point_depth(KRtCur, load_xyz(pd.cur.P3, ci)); }
+    { const int ri = z32_index(pd.zref[i], refTag); if (ri >= 0 && ri < nref) dr = point_depth(KRtRef, load_xyz(pd.ref.P3, ri)); }
     const unsigned short c = depth_to_u16(dc, scale);
     const unsigned short r = depth_to_u16(dr, scale);
     if (c > 0 && r > 0) {

@@ -52,9 +52,9 @@ int ensure_scene(pwn_hip_ctx* ctx, pwn_hip_cloud* c, bool with_gauss) {
 int ensure_back(pwn_hip_ctx* ctx, pwn_hip_cloud* c) {
   const size_t cap = (size_t)c->d.capacity;
   c->back.capacity = c->d.capacity; c->back.count = c->d.count;
-  std::memcpy(c->back.omN, c->d.omN, sizeof(c->d.omN));
-  if (int rc = scene_alloc(ctx, (void**)&c->back.P, cap * sizeof(float4))) return rc;
-  if (int rc = scene_alloc(ctx, (void**)&c->back.Nm, cap * sizeof(float4))) return rc;
+  std::memcpy(c->back.omN, c->d.omN, sizeof(c->d.omN)); c->back.clsThr = c->d.clsThr;
+  if (int rc = scene_alloc(ctx, (void**)&c->back.P3, cap * 3 * sizeof(float))) return rc;
+  if (int rc = scene_alloc(ctx, (void**)&c->back.Nc, cap * sizeof(float4))) return rc;
   if (int rc = scene_alloc(ctx, (void**)&c->back.Om, cap * 9 * sizeof(float))) return rc;
   if (c->d.OmN) { if (int rc = scene_alloc(ctx, (void**)&c->back.OmN, cap * 9 * sizeof(float))) return rc; }
   if (c->d.St) { if (int rc = scene_alloc(ctx, (void**)&c->back.St, cap * 16 * sizeof(float))) return rc; }
@@ -65,7 +65,7 @@ int ensure_back(pwn_hip_ctx* ctx, pwn_hip_cloud* c) {
   return PWN_HIP_OK;
 }
 void swap_back(pwn_hip_cloud* c) {
-  std::swap(c->d.P, c->back.P); std::swap(c->d.Nm, c->back.Nm); std::swap(c->d.Om, c->back.Om);
+  std::swap(c->d.P3, c->back.P3); std::swap(c->d.Nc, c->back.Nc); std::swap(c->d.Om, c->back.Om);
   if (c->d.OmN && c->back.OmN) std::swap(c->d.OmN, c->back.OmN);
   if (c->d.St && c->back.St) std::swap(c->d.St, c->back.St);
   if (c->sb.G && c->sback.G) { std::swap(c->sb.G, c->sback.G); std::swap(c->sb.Gf, c->sback.Gf); }
@@ -286,11 +286,10 @@ int pwn_hip_voxelize(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud, float resolution, i
 int pwn_hip_cloud_save(pwn_hip_ctx* ctx, const pwn_hip_cloud* c, const char* filename, const float T[16], int step, int binary) {
   if (!ctx || !c || !filename || !T || step <= 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "bad argument");
   const int n = c->n_host;
-  std::vector<float> P((size_t)n * 4), Nm((size_t)n * 4), St;
+  std::vector<float> P, Nm, St;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+  if (int rc = cloud_fetch_records(ctx, c->d, n, P, Nm)) return rc;
   if (n > 0) {
-    HIPCHK(ctx, hipMemcpy(P.data(), c->d.P, P.size() * 4, hipMemcpyDeviceToHost), PWN_HIP_ERR_COPY);
-    HIPCHK(ctx, hipMemcpy(Nm.data(), c->d.Nm, Nm.size() * 4, hipMemcpyDeviceToHost), PWN_HIP_ERR_COPY);
     if (c->has_stats && c->d.St) { St.resize((size_t)n * 16); HIPCHK(ctx, hipMemcpy(St.data(), c->d.St, St.size() * 4, hipMemcpyDeviceToHost), PWN_HIP_ERR_COPY); }
   }
   std::ofstream os(filename);
@@ -387,12 +386,15 @@ int pwn_hip_cloud_load(pwn_hip_ctx* ctx, pwn_hip_cloud* c, const char* filename,
   const bool ok = is.good();
   if (int rc = scene_alloc(ctx, (void**)&c->d.St, (size_t)c->d.capacity * 16 * sizeof(float))) return rc;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+  // Cloud::load leaves both information-matrix vectors empty (cloud.cpp:25-82): zero matrices for every point.  The class of the normal
+  // information matrix is derived from normal and curvature on the device, so a loaded cloud says "zero" with explicit planes.
+  if (int rc = scene_alloc(ctx, (void**)&c->d.OmN, (size_t)c->d.capacity * 9 * sizeof(float))) return rc;
   if (n > 0) {
-    HIPCHK(ctx, hipMemcpy(c->d.P, P.data(), P.size() * 4, hipMemcpyHostToDevice), PWN_HIP_ERR_COPY);
-    HIPCHK(ctx, hipMemcpy(c->d.Nm, Nm.data(), Nm.size() * 4, hipMemcpyHostToDevice), PWN_HIP_ERR_COPY);
+    if (int rc = cloud_store_records(ctx, c->d, n, P, Nm)) return rc;
     HIPCHK(ctx, hipMemcpy(c->d.St, St.data(), St.size() * 4, hipMemcpyHostToDevice), PWN_HIP_ERR_COPY);
     HIPCHK(ctx, hipMemset(c->d.Om, 0, (size_t)c->d.capacity * 9 * sizeof(float)), PWN_HIP_ERR_COPY);
   }
+  HIPCHK(ctx, hipMemset(c->d.OmN, 0, (size_t)c->d.capacity * 9 * sizeof(float)), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipMemcpy(c->d.count, &n, sizeof(int), hipMemcpyHostToDevice), PWN_HIP_ERR_COPY);
   c->n_host = n; c->has_stats = true; c->n_gauss = 0; c->idx_valid = false;
   if (!ok) return fail(ctx, PWN_HIP_ERR_COPY, "read error / truncated PWNCLOUD file");

@@ -131,7 +131,8 @@ __global__ void __launch_bounds__(256) k_cloud_append(CloudDev dst, SceneBuffers
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n || k + i >= dst.capacity) return;
   const int o = k + i;
-  float4 P = src.P[i]; float4 Nm = src.Nm[i];
+  float4 P, Nm;                    // old-format view: (x, y, z, curvature), (normal, class word)
+  cloud_get(src, i, P, Nm);
   float omP[9], omN[9];
   const int cls = __float_as_int(Nm.w) & kClsMask;
 #pragma unroll
@@ -155,7 +156,7 @@ __global__ void __launch_bounds__(256) k_cloud_append(CloudDev dst, SceneBuffers
     omega_transform(m, omP);
     omega_transform(m, omN);
   }
-  dst.P[o] = P; dst.Nm[o] = Nm;
+  cloud_put(dst, o, P, Nm);
 #pragma unroll
   for (int q = 0; q < 9; ++q) { dst.Om[(size_t)q * dst.capacity + o] = omP[q]; dst.OmN[(size_t)q * dst.capacity + o] = omN[q]; }
   if (dst.St) {
@@ -203,7 +204,8 @@ __global__ void __launch_bounds__(256) k_scene_transform(CloudDev cl, SceneBuffe
 __global__ void __launch_bounds__(256) k_expand_omega_n(CloudDev cl, float* __restrict__ out, int n) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const int cls = __float_as_int(cl.Nm[i].w) & kClsMask;
+  const float4 nc = cl.Nc[i];
+  const int cls = normal_class(nc.x, nc.y, nc.z, nc.w, cl.clsThr);
 #pragma unroll
   for (int q = 0; q < 9; ++q) out[(size_t)q * cl.capacity + i] = (cls == 1) ? cl.omN[0][q] : ((cls == 2) ? cl.omN[1][q] : 0.f);
 }
@@ -221,7 +223,7 @@ __global__ void __launch_bounds__(256) k_merge_classify(CloudDev cl, int n, Mat4
                                                         float normalThreshold, int* __restrict__ collapsed, int* __restrict__ head, int* __restrict__ next) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const float4 p = cl.P[i];
+  const float4 p = load_xyz(cl.P3, i);
   int res = -1;
   // PinholePointProjector::_project (pinholepointprojector.h:224-233): x, y stay -1 when the depth is out of the projector's range
   const float ix = dot4seq(KRt(0,0), p.x, KRt(0,1), p.y, KRt(0,2), p.z, KRt(0,3), 1.0f);
@@ -239,7 +241,7 @@ __global__ void __launch_bounds__(256) k_merge_classify(CloudDev cl, int n, Mat4
       if (targetIndex == i) res = i;
       else {
         const float targetZ = zkey_depth(key, tag);
-        const float4 cn = cl.Nm[i], tn = cl.Nm[targetIndex];
+        const float4 cn = cl.Nc[i], tn = cl.Nc[targetIndex];
         if (fabsf(d - targetZ) < distanceThreshold && dot4seq(cn.x, tn.x, cn.y, tn.y, cn.z, tn.z, 0.f, 0.f) > normalThreshold) {
           res = targetIndex;
           next[i] = atomicExch(&head[targetIndex], i);
@@ -275,9 +277,7 @@ __global__ void __launch_bounds__(256) k_merge_accumulate(CloudDev cl, SceneBuff
   }
   gauss_update_moments(g, flags);                 // gaussians()[i].mean()  (merger.cpp:92)
   sb.G[t] = g; sb.Gf[t] = flags;
-  float4 P = cl.P[t];
-  P.x = g.mean[0]; P.y = g.mean[1]; P.z = g.mean[2];
-  cl.P[t] = P;
+  store_xyz(cl.P3, t, g.mean[0], g.mean[1], g.mean[2]);
 }
 __global__ void __launch_bounds__(256) k_merge_keep_flags(const int* __restrict__ collapsed, int n, int* __restrict__ keep) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(256) k_merge_compact(CloudDev src, SceneBuffer
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n || !keep[i]) return;
   const int o = offs[i];
-  dst.P[o] = src.P[i]; dst.Nm[o] = src.Nm[i];
+  { const float4 p = load_xyz(src.P3, i); store_xyz(dst.P3, o, p.x, p.y, p.z); dst.Nc[o] = src.Nc[i]; }
 #pragma unroll
   for (int q = 0; q < 9; ++q) {
     dst.Om[(size_t)q * dst.capacity + o] = src.Om[(size_t)q * src.capacity + i];
@@ -378,7 +378,7 @@ __global__ void __launch_bounds__(256) k_voxel_insert(CloudDev cl, int n, float 
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   unsigned long long key;
-  if (!voxel_key(cl.P[i], inverseResolution, key)) { atomicExch(fault, 1); slotOf[i] = -1; return; }
+  if (!voxel_key(load_xyz(cl.P3, i), inverseResolution, key)) { atomicExch(fault, 1); slotOf[i] = -1; return; }
   unsigned slot = (unsigned)voxel_hash(key) & tableMask;
   for (unsigned probe = 0; probe <= tableMask; ++probe) {
     const unsigned long long prev = atomicCAS(&keys[slot], ~0ull, key);
@@ -396,7 +396,7 @@ __global__ void __launch_bounds__(256) k_voxel_records(CloudDev cl, int n, float
                                                        unsigned long long* __restrict__ rkeys, int* __restrict__ ridx) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n || !keep[i]) return;
-  unsigned long long key = 0; (void)voxel_key(cl.P[i], inverseResolution, key);
+  unsigned long long key = 0; (void)voxel_key(load_xyz(cl.P3, i), inverseResolution, key);
   rkeys[offs[i]] = key; ridx[offs[i]] = i;
 }
 // LSD radix sort, 8 bits per pass, of m (key, index) records: histogram per block -> scan -> stable scatter.
@@ -442,7 +442,7 @@ __global__ void __launch_bounds__(256) k_voxel_gather(CloudDev src, SceneBuffers
   const int o = blockIdx.x * 256 + threadIdx.x;
   if (o >= m) return;
   const int i = order[o];
-  dst.P[o] = src.P[i]; dst.Nm[o] = src.Nm[i];
+  { const float4 p = load_xyz(src.P3, i); store_xyz(dst.P3, o, p.x, p.y, p.z); dst.Nc[o] = src.Nc[i]; }
 #pragma unroll
   for (int q = 0; q < 9; ++q) {
     dst.Om[(size_t)q * dst.capacity + o] = src.Om[(size_t)q * src.capacity + i];
