@@ -129,7 +129,10 @@ void launch_corr_linearize(const pwn_hip_ctx* ctx, int nb, int m, hipStream_t st
 
 // projection of one cloud of each of the m pairs (which: 0 = reference, 1 = current): four points per thread when the launch is large
 void launch_project(int capacity, int m, hipStream_t st, const PairDesc* pr, const AlignParams& ap, int which, unsigned tag) {
-  if (m >= 8) hipLaunchKernelGGL((k_project<4>), dim3((capacity + 1023) / 1024, m), dim3(256), 0, st, pr, ap, which, tag);
+#ifndef PWN_PROJECT_PPT
+#define PWN_PROJECT_PPT 4
+#endif
+  if (m >= 8) hipLaunchKernelGGL((k_project<PWN_PROJECT_PPT>), dim3((capacity + 256 * PWN_PROJECT_PPT - 1) / (256 * PWN_PROJECT_PPT), m), dim3(256), 0, st, pr, ap, which, tag);
   else hipLaunchKernelGGL((k_project<1>), dim3((capacity + 255) / 256, m), dim3(256), 0, st, pr, ap, which, tag);
 }
 
