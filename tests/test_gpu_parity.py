@@ -445,6 +445,41 @@ def test_align_with_sensor_offset_and_guess(ctx, oracle):
     _check_alignment(o, g)
 
 
+def test_distinct_information_thresholds(ctx, oracle):
+    """Three different curvature thresholds in the converter (stats 0.2, point information 0.03, normal information 0.07) and a fourth in
+    the finder (flat 0.02): the class of the normal information matrix is not stored with the cloud but derived from normal, curvature and the
+    normal-information threshold the cloud was converted with (informationmatrixcalculator.cpp:38-58) -- which must not be mistaken for any of
+    the other three.  Converter arrays bit for bit (the downloaded omega_n included), every iteration teacher-forced, batch == single."""
+    from g2o_frontend_amd import api
+    name = "small"
+    rows, cols, K, conv, alig = case_params(name)
+    conv = dict(conv, stats_curvature_threshold=0.2, point_info_curvature_threshold=0.03, normal_info_curvature_threshold=0.07)
+    ref, cur, _, ref_mm, cur_mm = make_depth_pair(name, 6)
+    cp = oracle.converter_params(K=K, **conv)
+    ap = oracle.aligner_params(rows, cols, K=K, accumulate_fp64=1, **alig)
+    oref, _, _ = oracle.convert(cp, ref); ocur, _, _ = oracle.convert(cp, cur)
+    oa = ocur.arrays()
+    curv = oa["curvature"]; has_n = np.abs(oa["normals"][:, :3]).sum(1) > 0
+    assert (has_n & (curv >= 0.03) & (curv < 0.07)).sum() > 50 and (has_n & (curv >= 0.07)).sum() > 50, "degenerate input: no point between the thresholds"
+    _, converter, aligner = gpu_objects(ctx, name)
+    converter._stats.setCurvatureThreshold(0.2); converter._pinfo.setCurvatureThreshold(0.03); converter._ninfo.setCurvatureThreshold(0.07)
+    gref, gcur = api.Cloud(ctx, rows * cols), api.Cloud(ctx, rows * cols)
+    converter.compute(gref, ref); converter.compute(gcur, cur)
+    _compare_clouds(oref.arrays(), gref.arrays(), name); _compare_clouds(oa, gcur.arrays(), name)
+    o = oracle.align(ap, oref, ocur)
+    aligner.setReferenceCloud(gref); aligner.setCurrentCloud(gcur)
+    g = aligner.align()
+    _check_alignment(o, g)
+    _check_teacher_forced(aligner, o)
+    # the batch path (raw uint16 frames, lean hand-over inside the converter) gives the same clouds and the same alignment
+    bref, bcur = api.Cloud(ctx, rows * cols), api.Cloud(ctx, rows * cols)
+    converter.computeBatch([bref, bcur], [ref_mm, cur_mm], raw_scale=0.001)
+    _compare_clouds(oa, bcur.arrays(), name)
+    b = aligner.alignBatch([bref, gref], [bcur, gcur])
+    for r in b:
+        assert np.array_equal(r["T"], g["T"]) and np.array_equal(r["chi2"], g["chi2"])
+
+
 def test_inner_iterations_and_nonrobust(ctx, oracle, aligned_inputs):
     d = aligned_inputs["small"]
     _, ap = oracle_params(oracle, "small", accumulate_fp64=1, inner_iterations=2, outer_iterations=4, robust_kernel=0, inlier_max_chi2=50.0)
