@@ -717,6 +717,7 @@ int pwn_hip_ctx_create(pwn_hip_ctx** out, int device, int max_rows, int max_cols
 int pwn_hip_ctx_destroy(pwn_hip_ctx* ctx) {
   if (!ctx) return PWN_HIP_OK;
   (void)hipSetDevice(ctx->device);
+  if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);      // pwn_hip_copy_async transfers still in flight
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void* dev[] = { ctx->depth_ws, ctx->raw_ws, ctx->index_ws, ctx->interval_ws, ctx->integral_ws, ctx->rowoff_ws, ctx->carry_ws, ctx->fault_dev, ctx->zref_ws, ctx->z32ref_ws, ctx->z32cur_ws, ctx->curidx_ws,
                   ctx->partials_ws, ctx->state_ws, ctx->frames_dev, ctx->pairs_dev, ctx->raw_dev, ctx->counts_dev, ctx->solve_dev, ctx->counters_dev,
