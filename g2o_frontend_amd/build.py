@@ -51,15 +51,13 @@ def build_tools(force: bool = False) -> str:
     if force or (not os.path.exists(out3)) or any(os.path.getmtime(d) > os.path.getmtime(out3) for d in deps3):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", root, src3, "-o", out3, "-L", _HERE, "-lpwn_hip",
                                "-Wl,-rpath,$ORIGIN/../g2o_frontend_amd"])
-    # bench.py's workload driven from C++ (device-resident raw frames: needs the HIP runtime API for hipMalloc / hipMemcpy)
+    # bench.py's workload driven from C++ (device and page-locked memory through the C-ABI: no HIP headers, no HIP runtime on the link line)
     src4 = os.path.join(root, "tools", "pwn_hip_bench.cpp")
     out4 = os.path.join(root, "tools", "pwn_hip_bench")
     deps4 = [src4] + deps[1:]
     if force or (not os.path.exists(out4)) or any(os.path.getmtime(d) > os.path.getmtime(out4) for d in deps4):
-        rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", root, "-I", os.path.join(rocm, "include"), src4, "-o", out4,
-                               "-L", _HERE, "-lpwn_hip", "-L", os.path.join(rocm, "lib"), "-lamdhip64",
-                               "-Wl,-rpath,$ORIGIN/../g2o_frontend_amd", "-Wl,-rpath," + os.path.join(rocm, "lib")])
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", root, src4, "-o", out4, "-L", _HERE, "-lpwn_hip",
+                               "-Wl,-rpath,$ORIGIN/../g2o_frontend_amd"])
     return out
 
 

@@ -1,15 +1,18 @@
 // pwn_hip_bench -- the headline workload of bench.py driven from C++ through the host mirror: P depth pairs per step, every step converts
-// the 2P raw uint16 frames (resident in HBM) and aligns the P pairs (10 Gauss-Newton iterations) in batched calls.  Frames come from a list
-// of 16-bit PGM files; pair i is (frame 2i mod F, frame 2i+1 mod F).  Prints one line: pairs, steps, ms per step, alignments per second,
-// then one line per distinct pair with the pose and the chi2 trace (for cross-checking against the Python mirror).
+// the 2P raw uint16 frames and aligns the P pairs (10 Gauss-Newton iterations) in batched calls.  Frames come from a list of 16-bit PGM
+// files; pair i is (frame 2i mod F, frame 2i+1 mod F).  Prints one line: pairs, steps, ms per step, alignments per second, then one line
+// per distinct pair with the pose and the chi2 trace (for cross-checking against the Python mirror).
+//   mode 0 (default): frames resident in HBM (bench.py's `value`)
+//   mode 1: frames in one page-locked host block, handed to the convert call as host pointers (copied one sub-batch ahead of the kernels)
+//   mode 2: the same host block, uploaded by the caller into one of two device blocks with pwn_hip_copy_async while the previous batch is
+//           being aligned (the PCIe-inclusive rate of a caller that double-buffers)
+// No HIP headers, no HIP runtime on the link line: device and page-locked memory come from the C-ABI (pwn_hip_device_alloc / _host_alloc).
 //
 // build (g2o_frontend_amd/build.py: build_tools):
-//   g++ -O2 -std=c++17 -D__HIP_PLATFORM_AMD__ -I. -I/opt/rocm/include tools/pwn_hip_bench.cpp -o tools/pwn_hip_bench
-//       -Lg2o_frontend_amd -lpwn_hip -L/opt/rocm/lib -lamdhip64 -Wl,-rpath,$ORIGIN/../g2o_frontend_amd
-#include <hip/hip_runtime_api.h>
-
+//   g++ -O2 -std=c++17 -I. tools/pwn_hip_bench.cpp -o tools/pwn_hip_bench -Lg2o_frontend_amd -lpwn_hip -Wl,-rpath,$ORIGIN/../g2o_frontend_amd
 #include <chrono>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <sstream>
@@ -35,8 +38,9 @@ static bool readPGM16(const std::string& fn, RawDepthImage& img) {
 }
 
 int main(int argc, char** argv) {
-  if (argc < 2) { std::cout << "USAGE: pwn_hip_bench depthImageList.txt [pairs=128] [steps=5] [warmup=1] [device=0]" << std::endl; return 0; }
+  if (argc < 2) { std::cout << "USAGE: pwn_hip_bench depthImageList.txt [pairs=128] [steps=5] [warmup=1] [device=0] [mode=0]" << std::endl; return 0; }
   const int P = argc > 2 ? atoi(argv[2]) : 128, steps = argc > 3 ? atoi(argv[3]) : 5, warmup = argc > 4 ? atoi(argv[4]) : 1, device = argc > 5 ? atoi(argv[5]) : 0;
+  const int mode = argc > 6 ? atoi(argv[6]) : 0;
   std::vector<RawDepthImage> frames;
   {
     std::ifstream is(argv[1]);
@@ -66,20 +70,27 @@ int main(int argc, char** argv) {
     Aligner aligner(&ctx); aligner.setProjector(&projector); aligner.setCorrespondenceFinder(&finder); aligner.setLinearizer(&linearizer);
     aligner.setOuterIterations(10); aligner.setInnerIterations(1);
 
-    // the raw frames live in HBM, as in bench.py: the timed region starts with the inputs resident
-    if (hipSetDevice(device) != hipSuccess) { std::cerr << "hipSetDevice failed" << std::endl; return 1; }
-    std::vector<uint16_t*> dev(frames.size(), nullptr);
-    for (size_t i = 0; i < frames.size(); ++i) {
-      if (hipMalloc((void**)&dev[i], frames[i].data.size() * 2) != hipSuccess ||
-          hipMemcpy(dev[i], frames[i].data.data(), frames[i].data.size() * 2, hipMemcpyHostToDevice) != hipSuccess) { std::cerr << "device upload failed" << std::endl; return 1; }
-    }
-    std::vector<Cloud*> clouds(2 * (size_t)P), refs(P), curs(P);
-    std::vector<const uint16_t*> raw(2 * (size_t)P);
-    for (int i = 0; i < 2 * P; ++i) { clouds[i] = new Cloud(ctx, rows * cols); raw[i] = dev[i % frames.size()]; }
+    const size_t fpix = (size_t)rows * cols, fbytes = fpix * 2, nfr = 2 * (size_t)P;
+    auto check = [&](int rc, const char* what) { if (rc != PWN_HIP_OK) throw Error(rc, std::string(what) + ": " + pwn_hip_last_error_string(ctx.handle())); };
+    // one page-locked host block with the 2P frames of a step (modes 1, 2), up to two device blocks (mode 0: one, filled once)
+    uint16_t* host = nullptr;
+    check(pwn_hip_host_alloc((void**)&host, nfr * fbytes), "pwn_hip_host_alloc");
+    for (size_t i = 0; i < nfr; ++i) std::memcpy(host + i * fpix, frames[i % frames.size()].data.data(), fbytes);
+    uint16_t* dev[2] = { nullptr, nullptr };
+    for (int b = 0; b < (mode == 2 ? 2 : (mode == 0 ? 1 : 0)); ++b) check(pwn_hip_device_alloc(ctx.handle(), (void**)&dev[b], nfr * fbytes), "pwn_hip_device_alloc");
+    if (mode == 0) check(pwn_hip_copy(ctx.handle(), dev[0], host, nfr * fbytes), "pwn_hip_copy");
+    std::vector<Cloud*> clouds(nfr), refs(P), curs(P);
+    std::vector<const uint16_t*> raw(nfr);
+    for (size_t i = 0; i < nfr; ++i) clouds[i] = new Cloud(ctx, rows * cols);
     for (int i = 0; i < P; ++i) { refs[i] = clouds[2 * i]; curs[i] = clouds[2 * i + 1]; }
     std::vector<pwn_hip_align_result> results;
+    int flip = 0;
+    if (mode == 2) check(pwn_hip_copy_async(ctx.handle(), dev[0], host, nfr * fbytes), "pwn_hip_copy_async");      // prime the first block
     auto step = [&]() {
-      converter.computeBatchRaw(clouds, raw, 0.001f, rows, cols);
+      const uint16_t* base = mode == 1 ? host : dev[mode == 2 ? flip : 0];
+      for (size_t i = 0; i < nfr; ++i) raw[i] = base + i * fpix;
+      converter.computeBatchRaw(clouds, raw, 0.001f, rows, cols);                       // waits for the copies queued into `base`
+      if (mode == 2) { flip ^= 1; check(pwn_hip_copy_async(ctx.handle(), dev[flip], host, nfr * fbytes), "pwn_hip_copy_async"); }   // the next step's frames travel during the alignment
       projector.setImageSize(rows, cols);
       results = aligner.alignBatch(refs, curs);
     };
@@ -89,7 +100,7 @@ int main(int argc, char** argv) {
     for (int i = 0; i < steps; ++i) step();
     ctx.synchronize();
     const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    std::printf("pairs %d steps %d ms_per_step %.4f alignments_per_s %.1f\n", P, steps, dt / steps * 1e3, (double)P * steps / dt);
+    std::printf("pairs %d steps %d ms_per_step %.4f alignments_per_s %.1f mode %d\n", P, steps, dt / steps * 1e3, (double)P * steps / dt, mode);
     const size_t distinct = std::min((size_t)P, frames.size() / 2);
     for (size_t i = 0; i < distinct; ++i) {
       const pwn_hip_align_result& r = results[i];
@@ -99,7 +110,8 @@ int main(int argc, char** argv) {
       std::printf("\n");
     }
     for (Cloud* c : clouds) delete c;
-    for (uint16_t* d : dev) (void)hipFree(d);
+    for (uint16_t* d : dev) check(pwn_hip_device_free(ctx.handle(), d), "pwn_hip_device_free");
+    check(pwn_hip_host_free(host), "pwn_hip_host_free");
   } catch (const Error& e) {
     std::cerr << e.what() << std::endl;
     return 2;

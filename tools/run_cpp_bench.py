@@ -27,8 +27,9 @@ def main():
             names.append(fn)
     lst = os.path.join(d, "list.txt")
     open(lst, "w").write("\n".join(names) + "\n")
-    out = subprocess.check_output([os.path.join(ROOT, "tools", "pwn_hip_bench"), lst, str(P), str(steps), "2"]).decode()
-    print(out.splitlines()[0])
+    for mode in (0, 1, 2):      # resident frames / host frames in one page-locked block / double-buffered upload by the caller
+        out = subprocess.check_output([os.path.join(ROOT, "tools", "pwn_hip_bench"), lst, str(P), str(steps), "2", "0", str(mode)]).decode()
+        print(out.splitlines()[0])
 
 
 if __name__ == "__main__":
