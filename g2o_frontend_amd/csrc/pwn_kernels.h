@@ -1765,16 +1765,19 @@ __device__ __forceinline__ void reduce_partials(const double* partials, int nblo
   if (c < kAccN) {
     double acc = 0.0;
     int b = s;
-    // 32 independent loads in flight, then the 32 adds in block order (one pair at VGA: 150 records, 38 per wave: two round trips instead of ten)
-    for (; b + 4 * 31 < nblocks; b += 4 * 32) {
-      double v[32];
+    // up to kRW independent loads in flight, then the adds in block order (one pair at VGA: 150 records, 38 per wave: ONE memory round trip;
+    // with 32 + a remainder loop it was three).  Records past the end are neither loaded nor added: the sum is the same chain as before.
+#ifndef PWN_REDUCE_WIDTH
+#define PWN_REDUCE_WIDTH 40
+#endif
+    constexpr int kRW = PWN_REDUCE_WIDTH;
+    for (; b < nblocks; b += 4 * kRW) {
+      double v[kRW];
 #pragma unroll
-      for (int i = 0; i < 32; ++i) v[i] = partials[(size_t)(b + 4 * i) * kAccN + c];
+      for (int i = 0; i < kRW; ++i) { const int bb = b + 4 * i; v[i] = (bb < nblocks) ? partials[(size_t)bb * kAccN + c] : 0.0; }
 #pragma unroll
-      for (int i = 0; i < 32; ++i) acc += v[i];
+      for (int i = 0; i < kRW; ++i) if (b + 4 * i < nblocks) acc += v[i];
     }
-#pragma unroll 4
-    for (; b < nblocks; b += 4) acc += partials[(size_t)b * kAccN + c];
     part[s][c] = acc;
   }
   __syncthreads();
