@@ -1,0 +1,40 @@
+// How long does a kernel boundary take on this machine?  Chains of dependent launches in one stream:
+//   (a) empty kernel, 1 block;  (b) empty kernel, 300 blocks x 256;  (c) 1 block that spins ~8 us of dependent arithmetic (a stand-in for
+//   k_solve_update) followed by (b) -- against one launch of 300 blocks in which block 0 does the arithmetic first.
+// hipcc --offload-arch=gfx950 -O3 tools/micro/launch_chain.hip -o /tmp/launch_chain && /tmp/launch_chain
+#include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+__global__ void k_empty(int* p) { if (p && threadIdx.x == 12345) *p = 1; }
+__global__ void k_serial(float* out, int n) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  float x = out[0];
+  for (int i = 0; i < n; ++i) x = x * 1.0000001f + 0.5f;      // dependent chain
+  out[0] = x;
+}
+__global__ void k_serial_then_wide(float* out, int n) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) { float x = out[0]; for (int i = 0; i < n; ++i) x = x * 1.0000001f + 0.5f; out[0] = x; }
+}
+int main() {
+  hipStream_t s; hipStreamCreate(&s);
+  float* d; hipMalloc(&d, 64); hipMemset(d, 0, 64);
+  auto run = [&](const char* name, int reps, auto body) {
+    for (int i = 0; i < 20; ++i) body();
+    hipStreamSynchronize(s);
+    auto t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < reps; ++i) body();
+    hipStreamSynchronize(s);
+    double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+    std::printf("%-62s %8.2f us per iteration\n", name, us);
+  };
+  run("empty kernel, 1 block", 2000, [&] { hipLaunchKernelGGL(k_empty, dim3(1), dim3(256), 0, s, (int*)nullptr); });
+  run("empty kernel, 300 blocks", 2000, [&] { hipLaunchKernelGGL(k_empty, dim3(300), dim3(256), 0, s, (int*)nullptr); });
+  for (int n : { 500, 1000, 2000 }) {
+    char nm[128];
+    std::snprintf(nm, sizeof nm, "serial(%d) in its own launch + empty 300 blocks", n);
+    run(nm, 1000, [&] { hipLaunchKernelGGL(k_serial, dim3(1), dim3(256), 0, s, d, n); hipLaunchKernelGGL(k_empty, dim3(300), dim3(256), 0, s, (int*)nullptr); });
+    std::snprintf(nm, sizeof nm, "serial(%d) inside block 0 of the 300-block launch", n);
+    run(nm, 1000, [&] { hipLaunchKernelGGL(k_serial_then_wide, dim3(300), dim3(256), 0, s, d, n); });
+  }
+  return 0;
+}
