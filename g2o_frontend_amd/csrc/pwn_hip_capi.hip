@@ -919,8 +919,8 @@ int pwn_hip_cloud_upload(pwn_hip_ctx* ctx, pwn_hip_cloud* c, int n, const float*
     Nm[4 * i] = hn[4 * i]; Nm[4 * i + 1] = hn[4 * i + 1]; Nm[4 * i + 2] = hn[4 * i + 2];
     const int one = 1; std::memcpy(&Nm[4 * i + 3], &one, 4);
     for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) {
-      Om[(size_t)(3 * r + q) * cap + i] = hop[(size_t)16 * i + r + 4 * q];      // column-major 4x4 -> plane (r,q)
-      OmN[(size_t)(3 * r + q) * cap + i] = hon[(size_t)16 * i + r + 4 * q];
+      Om[om_at(cap, i, 3 * r + q)] = hop[(size_t)16 * i + r + 4 * q];      // column-major 4x4 -> entry (r,q)
+      OmN[om_at(cap, i, 3 * r + q)] = hon[(size_t)16 * i + r + 4 * q];
     }
   }
   if (!c->d.OmN) HIPCHK(ctx, hipMalloc((void**)&c->d.OmN, cap * 9 * sizeof(float)), PWN_HIP_ERR_ALLOCATION);
@@ -950,10 +950,10 @@ int pwn_hip_cloud_download(pwn_hip_ctx* ctx, const pwn_hip_cloud* c, float* poin
     for (int i = 0; i < n; ++i) {
       int cls; std::memcpy(&cls, &Nm[4 * i + 3], 4); cls &= kClsMask;
       for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) {
-        if (omega_p) hop[(size_t)16 * i + r + 4 * q] = Om[(size_t)(3 * r + q) * cap + i];
+        if (omega_p) hop[(size_t)16 * i + r + 4 * q] = Om[om_at(cap, i, 3 * r + q)];
         if (omega_n) {
           float v = 0.f;
-          if (c->d.OmN) v = OmN[(size_t)(3 * r + q) * cap + i];
+          if (c->d.OmN) v = OmN[om_at(cap, i, 3 * r + q)];
           else if (cls == 1) v = c->d.omN[0][3 * r + q];
           else if (cls == 2) v = c->d.omN[1][3 * r + q];
           hon[(size_t)16 * i + r + 4 * q] = v;

@@ -7,7 +7,8 @@
 //           Nc[i] = float4(nx, ny, nz, curvature)          (Normal + Stats::curvature(); the class of the normal information matrix --
 //                   0 = zero, 1 = flat, 2 = non-flat -- is not stored: normal_class() derives it from this record and the threshold the
 //                   cloud was converted with)
-//           Om[k*cap + i], k = 3*r + c                     (point information matrix, 9 planes)
+//           Om[((r*cap + i)*3 + c]                         (point information matrix: three planes of 12-byte rows, om_at(); nine dword
+//                   planes until round 2: k_stats stores three 12-byte rows per point instead of nine dwords, -9 % of its time)
 //           64 bytes per point; until round 2 the point carried the curvature and the normal a class word (68 bytes): the fused pass
 //           fetches 8 bytes less per candidate (-7.5 % of its time), the projection 4 of 16 bytes less per point
 //   images: row-major int32 / float32, lanes along image x (row-coalesced loads)
@@ -66,8 +67,8 @@ constexpr int kClsMask = 3;      // class of the normal information matrix (0 ze
 struct CloudDev {
   float*  P3;        // [capacity][3] x y z
   float4* Nc;        // [capacity] (nx, ny, nz, curvature)
-  float*  Om;        // [9][capacity]
-  float*  OmN;       // optional [9][capacity] full normal information matrices (uploaded clouds), else nullptr
+  float*  Om;        // [3][capacity][3]: row r of point i at (r * capacity + i) * 3 (om_at)
+  float*  OmN;       // optional, same layout: full normal information matrices (uploaded clouds, scenes), else nullptr
   float*  St;        // optional [capacity][16] stats: U(9, column-major) eigenvalues(3) mean(3) n(1)
   int*    count;
   int     capacity;
@@ -77,6 +78,8 @@ struct CloudDev {
 // NormalInformationMatrixCalculator::compute (informationmatrixcalculator.cpp:38-58): zero normal -> zero matrix, else flat / non-flat by
 // the curvature.  The converter decides on the normal before the sensor offset is applied; a rotation does not turn a non-zero normal
 // into the zero vector, and a candidate with a zero normal is rejected before its class is looked at (correspondencefinder.cpp:69).
+// information matrices (Om, OmN): entry k = 3 r + c of point i
+__host__ __device__ __forceinline__ size_t om_at(size_t cap, size_t i, int k) { return ((size_t)(k / 3) * cap + i) * 3 + (size_t)(k % 3); }
 __host__ __device__ __forceinline__ int normal_class(float nx, float ny, float nz, float curvature, float thr) {
   return (nx != 0.f || ny != 0.f || nz != 0.f) ? ((curvature < thr) ? 1 : 2) : 0;
 }
@@ -1048,7 +1051,10 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
     stream_store((gptr<v4f>)(gN + 4u * (unsigned)idx), nv);
   }
 #pragma unroll
-  for (int k = 0; k < 9; ++k) stream_store((gptr<float>)((gptr<char>)(gOm + (size_t)k * (size_t)cap) + 4u * (unsigned)idx), om[k]);
+  for (int r3 = 0; r3 < 3; ++r3) {      // three 12-byte rows (nine dword stores per point cost k_stats 9 % more time)
+    v3f rw; rw.x = om[3 * r3]; rw.y = om[3 * r3 + 1]; rw.z = om[3 * r3 + 2];
+    stream_store((gptr<v3f>)(gOm + (size_t)r3 * 3u * (size_t)cap + 3u * (unsigned)idx), rw);
+  }
 }
 
 // Cloud::transformInPlace on an existing device cloud (cloud.cpp:173-186); grid = ceil(cap/256)
@@ -1069,10 +1075,10 @@ __global__ void __launch_bounds__(256) k_cloud_transform(CloudDev cl, Mat4 m) {
     float* base = pass == 0 ? cl.Om : cl.OmN;
     if (!base) continue;
     float om[9], t1[9];
-    for (int k = 0; k < 9; ++k) om[k] = base[(size_t)k * cl.capacity + i];
+    for (int k = 0; k < 9; ++k) om[k] = base[om_at(cl.capacity, i, k)];
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) t1[3 * a + b] = dot3seq(m(a,0), om[0 + b], m(a,1), om[3 + b], m(a,2), om[6 + b]);
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) om[3 * a + b] = dot3seq(t1[3 * a], m(b,0), t1[3 * a + 1], m(b,1), t1[3 * a + 2], m(b,2));
-    for (int k = 0; k < 9; ++k) base[(size_t)k * cl.capacity + i] = om[k];
+    for (int k = 0; k < 9; ++k) base[om_at(cl.capacity, i, k)] = om[k];
   }
   cloud_put(cl, i, P, Nm);
 }
@@ -1324,10 +1330,10 @@ __device__ __forceinline__ bool linearize_term(const float3 rp, const float3 rn,
 __device__ __forceinline__ void load_omegas(const CloudDev& cur, int ci, int cls, float* oP, float* oN) {
   const size_t cap = (size_t)cur.capacity;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) oP[k] = cur.Om[k * cap + ci];
+  for (int k = 0; k < 9; ++k) oP[k] = cur.Om[om_at(cap, ci, k)];
   if (cur.OmN) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) oN[k] = cur.OmN[k * cap + ci];
+    for (int k = 0; k < 9; ++k) oN[k] = cur.OmN[om_at(cap, ci, k)];
   } else {
 #pragma unroll
     for (int k = 0; k < 9; ++k) oN[k] = (cls == 1) ? cur.omN[0][k] : ((cls == 2) ? cur.omN[1][k] : 0.f);
@@ -1456,7 +1462,7 @@ __device__ __forceinline__ void candidate_load(const PairPtrs& q, int ri, int ci
     c.rP.w = c.rN.w; c.cP.w = c.cN.w;
 #if PWN_OMEGA_PREFETCH
 #pragma unroll
-    for (int k = 0; k < 9; ++k) c.oP[k] = q.curOm[(size_t)k * q.cap + (unsigned)ci];
+    for (int k = 0; k < 9; ++k) c.oP[k] = q.curOm[om_at(q.cap, (unsigned)ci, k)];
 #endif
   }
 }
@@ -1472,7 +1478,7 @@ __device__ __forceinline__ void candidate_consume(const PairDesc& pd, const Pair
   const int cls = (c.cP.w < pd.cur.clsThr) ? 1 : 2;      // normal_class(): the normal is not zero here (correspondence_test)
   if (pd.cur.OmN) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k) oN[k] = q.curOmN[(size_t)k * q.cap + (unsigned)c.ci];
+    for (int k = 0; k < 9; ++k) oN[k] = q.curOmN[om_at(q.cap, (unsigned)c.ci, k)];
   } else {
     // class -> matrix through a 27-float LDS table (row 0 = zero matrix): one broadcast read per entry.  Selecting from the descriptor
     // compiled into a tree of exec-masked branches with a scalar load and a wait inside each, 18 of them per correspondence.
@@ -1495,7 +1501,10 @@ __device__ __forceinline__ void candidate_consume(const PairDesc& pd, const Pair
     for (int k = 0; k < 9; ++k) oP[k] = oN[k] * 10.f;
 #else
 #pragma unroll
-    for (int k = 0; k < 9; ++k) oP[k] = q.curOm[k * cap + ci];
+    for (int r3 = 0; r3 < 3; ++r3) {      // three 12-byte loads
+      const v3f rw = *(gptr<const v3f>)(q.curOm + (size_t)r3 * 3u * cap + 3u * ci);
+      oP[3 * r3] = rw.x; oP[3 * r3 + 1] = rw.y; oP[3 * r3 + 2] = rw.z;
+    }
 #endif
   }
 #endif

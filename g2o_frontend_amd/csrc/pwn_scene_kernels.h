@@ -136,10 +136,10 @@ __global__ void __launch_bounds__(256) k_cloud_append(CloudDev dst, SceneBuffers
   float omP[9], omN[9];
   const int cls = __float_as_int(Nm.w) & kClsMask;
 #pragma unroll
-  for (int q = 0; q < 9; ++q) omP[q] = src.Om[(size_t)q * src.capacity + i];
+  for (int q = 0; q < 9; ++q) omP[q] = src.Om[om_at(src.capacity, i, q)];
   if (src.OmN) {
 #pragma unroll
-    for (int q = 0; q < 9; ++q) omN[q] = src.OmN[(size_t)q * src.capacity + i];
+    for (int q = 0; q < 9; ++q) omN[q] = src.OmN[om_at(src.capacity, i, q)];
   } else {
 #pragma unroll
     for (int q = 0; q < 9; ++q) omN[q] = (cls == 1) ? src.omN[0][q] : ((cls == 2) ? src.omN[1][q] : 0.f);
@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256) k_cloud_append(CloudDev dst, SceneBuffers
   }
   cloud_put(dst, o, P, Nm);
 #pragma unroll
-  for (int q = 0; q < 9; ++q) { dst.Om[(size_t)q * dst.capacity + o] = omP[q]; dst.OmN[(size_t)q * dst.capacity + o] = omN[q]; }
+  for (int q = 0; q < 9; ++q) { dst.Om[om_at(dst.capacity, o, q)] = omP[q]; dst.OmN[om_at(dst.capacity, o, q)] = omN[q]; }
   if (dst.St) {
     float st[16];
     if (src.St) {
@@ -207,7 +207,7 @@ __global__ void __launch_bounds__(256) k_expand_omega_n(CloudDev cl, float* __re
   const float4 nc = cl.Nc[i];
   const int cls = normal_class(nc.x, nc.y, nc.z, nc.w, cl.clsThr);
 #pragma unroll
-  for (int q = 0; q < 9; ++q) out[(size_t)q * cl.capacity + i] = (cls == 1) ? cl.omN[0][q] : ((cls == 2) ? cl.omN[1][q] : 0.f);
+  for (int q = 0; q < 9; ++q) out[om_at(cl.capacity, i, q)] = (cls == 1) ? cl.omN[0][q] : ((cls == 2) ? cl.omN[1][q] : 0.f);
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -292,8 +292,8 @@ __global__ void __launch_bounds__(256) k_merge_compact(CloudDev src, SceneBuffer
   { const float4 p = load_xyz(src.P3, i); store_xyz(dst.P3, o, p.x, p.y, p.z); dst.Nc[o] = src.Nc[i]; }
 #pragma unroll
   for (int q = 0; q < 9; ++q) {
-    dst.Om[(size_t)q * dst.capacity + o] = src.Om[(size_t)q * src.capacity + i];
-    if (src.OmN && dst.OmN) dst.OmN[(size_t)q * dst.capacity + o] = src.OmN[(size_t)q * src.capacity + i];
+    dst.Om[om_at(dst.capacity, o, q)] = src.Om[om_at(src.capacity, i, q)];
+    if (src.OmN && dst.OmN) dst.OmN[om_at(dst.capacity, o, q)] = src.OmN[om_at(src.capacity, i, q)];
   }
   if (src.St && dst.St) {
 #pragma unroll
@@ -445,8 +445,8 @@ __global__ void __launch_bounds__(256) k_voxel_gather(CloudDev src, SceneBuffers
   { const float4 p = load_xyz(src.P3, i); store_xyz(dst.P3, o, p.x, p.y, p.z); dst.Nc[o] = src.Nc[i]; }
 #pragma unroll
   for (int q = 0; q < 9; ++q) {
-    dst.Om[(size_t)q * dst.capacity + o] = src.Om[(size_t)q * src.capacity + i];
-    if (src.OmN && dst.OmN) dst.OmN[(size_t)q * dst.capacity + o] = src.OmN[(size_t)q * src.capacity + i];
+    dst.Om[om_at(dst.capacity, o, q)] = src.Om[om_at(src.capacity, i, q)];
+    if (src.OmN && dst.OmN) dst.OmN[om_at(dst.capacity, o, q)] = src.OmN[om_at(src.capacity, i, q)];
   }
   if (src.St && dst.St) {
 #pragma unroll
