@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+FREE_RUNNING_CHI2_BAR = 1e-4   # free-running chi2 trace vs the fp64-accumulating oracle at VGA (tests/test_gpu_parity.py: FREE_CHI2_RTOL_VGA); 1e-5 holds teacher-forced
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6 TB/s is what a bare streaming read gets on these boxes
 
 
@@ -58,6 +59,11 @@ def parse(argv=None):
     ap.add_argument("--render-workers", type=int, default=0,
                     help="processes that render the synthetic frames (0 = automatic; 1 = in this process: required under rocprofv3, whose preloaded "
                          "library has initialised the GPU before Python starts -- no child process may be started from such a process)")
+    ap.add_argument("--total-pairs", type=int, default=0,
+                    help="strong-scaling mode: shard the SAME list of this many pairs (BASELINE configs[3]: 1024) over the N ranks, instead of --pairs per rank")
+    ap.add_argument("--write-records-crc", action="store_true",
+                    help="N = 1 only: write profiles/records_crc.json (per-pair CRC32 of the result records) -- multi-GPU runs check their assembled records against it")
+    ap.add_argument("--check-gather", action="store_true", help="kept for scripts: the `gather` object (backend, records, equality with the local records) is always in the line")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="launcher / sharding / gather plumbing only, on the CPU with the gloo backend (no GPU, no kernels): used by tests")
     return ap.parse_args(argv)
@@ -65,14 +71,14 @@ def parse(argv=None):
 
 def conf(rows, cols):
     from g2o_frontend_amd import synth
-    from oracle import oracle as O   # parameter tables only (the oracle is the checker / cpu_baseline, never the product path)
+    from g2o_frontend_amd import conf as C      # the reference's configuration files as tables (the oracle is not imported by the GPU-driving process)
     if (rows, cols) == (960, 1280):
         K = synth.K_1280
-        conv = dict(O.VGA_CONF_CONVERTER, min_image_radius=20, max_image_radius=60, min_points=200)
+        conv = dict(C.K2_CONF_CONVERTER)
     else:
         K = synth.K_VGA if (rows, cols) == (480, 640) else synth.scaled_K(synth.K_VGA, 640 // cols)
-        conv = dict(O.VGA_CONF_CONVERTER)
-    return K, conv, dict(O.VGA_CONF_ALIGNER)
+        conv = dict(C.VGA_CONF_CONVERTER)
+    return K, conv, dict(C.VGA_CONF_ALIGNER)
 
 
 def build_objects(ctx, rows, cols, K, conv, alig):
@@ -268,6 +274,8 @@ class BatchWorkload:
         import torch
         from g2o_frontend_amd import api, shard
         self.args, self.rows, self.cols, self.P, self.seeds, self.use_dist, self.world = args, rows, cols, P, list(seeds), use_dist, world
+        self.Pmax = P                     # rows every rank contributes to the all-gather (the largest shard; set by main() in strong-scaling mode)
+        self.total = world * P            # pairs of the whole job
         self.N = rows * cols
         self.K, self.conv, self.alig = conf(rows, cols)
         self.n_it = self.alig["outer_iterations"] * self.alig["inner_iterations"]
@@ -299,7 +307,7 @@ class BatchWorkload:
                 ms, n = self.ctx.stage_ms(k); self.stage_ms[k] += ms; self.stage_n[k] += n
         self.records_host.numpy()[:] = shard.pack_results_raw(res, self.seeds)
         self.records.copy_(self.records_host, non_blocking=False)
-        self.last["gathered"] = shard.gather_records(self.records, self.world, self.P, force=self.use_dist)      # the only collective of the path
+        self.last["gathered"] = shard.gather_records(self.records, self.world, self.Pmax, force=self.use_dist)      # the only collective of the path
         self.last["res"] = res
 
     def barrier(self):
@@ -360,17 +368,56 @@ class BatchWorkload:
         achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
         conv_ms = sum(self.stage_ms[k] for k in STAGES[:6]) / max(steps, 1)
         conv_GBps = float(b["convert"].sum()) / (conv_ms * 1e-3) / 1e9 if conv_ms > 0 else 0.0
-        traffic = None
+        # HBM traffic per launch from the PMC passes committed under profiles/ (tools/summarize_pmc.py writes profiles/traffic.json from the newest
+        # summary; its `version` travels with the line).  Every term of every kernel's traffic is per pixel / per point, so other frame sizes and
+        # launch sizes scale with pixels x items per launch.
+        traffic = None; tj = {}
         tfile = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tfile):
-            try:      # measured per pair-iteration by the PMC passes (profiles/), scaled to what one launch of this run covers; every
-                tj = json.load(open(tfile))      # term of the kernel's traffic is per pixel / per point, so other frame sizes scale with N
-                traffic = tj.get("k_corr_linearize_bytes_per_pair_iteration") * (self.N / tj.get("pixels_per_frame", 307200)) * (P * self.n_it * steps / launches)
+            try:
+                tj = json.load(open(tfile))
             except Exception:
-                traffic = None
+                tj = {}
+
+        def pmc_bytes(kernel, items_per_launch):
+            e = tj.get("kernels", {}).get(kernel)
+            if not e:
+                return None
+            return e["bytes_per_launch"] / tj.get("items_per_launch", 64) * (self.N / tj.get("pixels_per_frame", 307200)) * items_per_launch
+        traffic = pmc_bytes("k_corr_linearize", P * self.n_it * steps / launches)
+        # the other kernels of the step, each against the same peak: algorithmic bytes of its share of SURVEY.md 8(d)'s formulas / its own
+        # average launch time (hipEvent pairs of the serial profiled pass), PMC traffic beside it
+        F = 2 * P                                                      # frames per step
+        Msum = float(b["Mr"].sum() + b["Mc"].sum())
+        per_kernel = {}
+
+        def kernel_entry(name, stage, alg_bytes_per_step, items_per_step, note):
+            n = self.stage_n[stage]
+            if not n or self.stage_ms[stage] <= 0:
+                return
+            ms = self.stage_ms[stage] / n
+            alg = alg_bytes_per_step * steps / n
+            tr = pmc_bytes(name, items_per_step * steps / n)
+            ach = alg / (ms * 1e-3) / 1e9
+            per_kernel[name] = {"achieved": ach, "frac": ach / HBM_PEAK_GBS, "unit": "GB/s", "avg_launch_ms": ms, "launches": n,
+                                "bytes_per_launch_algorithmic": alg, "traffic": tr,
+                                "traffic_over_algorithmic": (tr / alg) if tr else None,
+                                "traffic_GBps": (tr / (ms * 1e-3) / 1e9) if tr else None, "algorithmic_bytes": note}
+        fused_conv = self.stage_n.get("convert_fused", 0) > 0
+        if fused_conv:
+            kernel_entry("k_convert_fused", "convert_fused", 8.0 * self.N * F + 64.0 * Msum, F, "8N + 64M per frame (the whole converter: SURVEY.md 8(d))")
+        else:
+            kernel_entry("k_stats", "stats", 6.0 * self.N * F + 64.0 * Msum, F, "2N depth + 4N index in, 64M cloud out per frame (the 40N integral planes are a temporary)")
+            kernel_entry("k_unproject_integral", "integral", 6.0 * self.N * F, F, "2N depth in, 4N index out per frame (the 40N integral planes are a temporary)")
+        npj = self.stage_n["project_cur"] + self.stage_n["project_ref"]
+        if npj:
+            self.stage_ms["project"] = self.stage_ms["project_cur"] + self.stage_ms["project_ref"]; self.stage_n["project"] = npj
+            kernel_entry("k_project", "project", float(b["project"].sum()), P * (pc + pr), "16M + 4N per executed projection")
         dom = max(STAGES, key=lambda k: self.stage_ms[k])
         roofline = {"bound": "hbm", "kernel": "k_corr_linearize", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                    "traffic_over_algorithmic": (traffic / k_bytes) if (traffic and k_bytes) else None,
+                    "traffic_source": {"file": "profiles/traffic.json", "version": tj.get("version"), "pmc_summary": tj.get("source")},
                     "bytes_per_launch_algorithmic": k_bytes, "avg_launch_ms": k_ms, "launches": self.stage_n["corr_linearize"],
                     "dominant_by_time": dom,
                     "traffic_GBps": (traffic / (k_ms * 1e-3) / 1e9) if (traffic and k_ms > 0) else None,
@@ -378,10 +425,11 @@ class BatchWorkload:
                     "path_achieved_GBps": total_step * steps / dt / 1e9, "path_frac": total_step * steps / dt / 1e9 / HBM_PEAK_GBS,
                     "converter_ms_per_step": conv_ms, "converter_achieved_GBps": conv_GBps, "converter_frac": conv_GBps / HBM_PEAK_GBS,
                     "projections_per_pair": pc + pr,
+                    "other_kernels": per_kernel,
                     "measured_in": "serial profiled pass of the same K steps (one stream, hipEvent pair per kernel stage); "
                                    "the timed region runs the streams without instrumentation",
-                    "serial_pass_alignments_per_s": (world * P * steps / dt_serial) if dt_serial else None}
-        return dict(value=world * P * steps / dt, ms_per_step=dt / steps * 1e3, roofline=roofline,
+                    "serial_pass_alignments_per_s": (self.total * steps / dt_serial) if dt_serial else None}
+        return dict(value=self.total * steps / dt, ms_per_step=dt / steps * 1e3, roofline=roofline,
                     path_roofline={"algorithmic_bytes_per_pair": total_step / P, "achieved_GBps": total_step * steps / dt / 1e9,
                                    "frac_of_peak": total_step * steps / dt / 1e9 / HBM_PEAK_GBS,
                                    "projections_counted_per_pair": pc + pr},
@@ -601,8 +649,11 @@ def chi2_match(traces, res, w=None):
             worst64 = max(worst64, abs(float(g["chi2"][k]) - t["chi2_fp64"][k]) / max(t["chi2_fp64"][k], 1e-30))
             worst32 = max(worst32, abs(float(g["chi2"][k]) - t["chi2_fp32_serial"][k]) / max(t["chi2_fp32_serial"][k], 1e-30))
         worstT = max(worstT, float(np.abs(g["T"].reshape(4, 4).T - np.asarray(t["T"])).max()))
-    out = {"pairs": len(traces), "bar": 1e-5,
-           "free_running_max_rel_diff_vs_fp64_accumulated_oracle": worst64,
+    out = {"pairs": len(traces), "bar": 1e-5, "bar_applies_to": "teacher-forced comparison (max_rel_diff): same iterate on both sides",
+           "free_running_bar": FREE_RUNNING_CHI2_BAR,
+           "free_running_note": "seed-dependent: one correspondence entering or leaving the set moves chi2 by its own term (~1/C = 5e-6 of chi2 at VGA, "
+                                "more for a boundary term); worst over 16 VGA seeds in tests/test_gpu_parity.py::test_free_running_chi2_many_seeds",
+           "free_running_max_rel_diff_vs_fp64_accumulated_oracle": worst64, "free_running_ok": bool(worst64 <= FREE_RUNNING_CHI2_BAR),
            "free_running_max_rel_diff_vs_reference_fp32_serial_sums": worst32, "free_running_max_abs_pose_diff": worstT,
            "note": "fp32-serial = the reference's own summation order: the distance between two orders of the same fp32 terms (tests allow 1e-4 / 5e-3)"}
     if w is not None and traces and "T_before" in traces[0]:
@@ -632,8 +683,51 @@ def chi2_match(traces, res, w=None):
                    projector_index_images_bit_exact=bool(index_equal), ok=bool(worst_tf <= 1e-5 and counters_equal and index_equal),
                    canonical_choices="single-thread semantics of the finder / linearizer; eigensolver trig by the shared double-precision algorithm (DESIGN.md section 2)")
     else:
-        out.update(mode="free-running only", max_rel_diff=worst64, ok=bool(worst64 <= 1e-5))
+        out.update(mode="free-running only", max_rel_diff=worst64, ok=bool(worst64 <= FREE_RUNNING_CHI2_BAR))
     return out
+
+
+# ------------------------------------------------------------------------------------------------ record digests (determinism gate)
+RECORDS_CRC_FILE = os.path.join(ROOT, "profiles", "records_crc.json")
+
+
+def records_crc(allrec):
+    """CRC32 of every assembled 80-byte result record (pose, chi2, inliers, iterations, pair id), in global pair order"""
+    import zlib
+    a = np.ascontiguousarray(allrec, np.float32)
+    return [int(zlib.crc32(a[i].tobytes())) for i in range(a.shape[0])]
+
+
+def kernel_source_digest():
+    """identifies the kernels a records_crc.json belongs to: a change of summation order changes the last bits of H, b and so the records"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "g2o_frontend_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def check_records_crc(allrec, rows, cols, write=False):
+    crc = records_crc(allrec)
+    src = kernel_source_digest()
+    if write:
+        with open(RECORDS_CRC_FILE, "w") as f:
+            json.dump({"made_by": "bench.py --gpus 1 --total-pairs %d --write-records-crc (one MI355X)" % len(crc), "rows": rows, "cols": cols,
+                       "kernel_source_digest": src, "pairs": len(crc), "crc32": crc}, f)
+    if not os.path.exists(RECORDS_CRC_FILE):
+        return {"checked": 0, "note": "no profiles/records_crc.json"}
+    try:
+        g = json.load(open(RECORDS_CRC_FILE))
+    except Exception as e:
+        return {"checked": 0, "note": "unreadable: %r" % (e,)}
+    if (g.get("rows"), g.get("cols")) != (rows, cols):
+        return {"checked": 0, "note": "file is for another frame size"}
+    n = min(len(crc), g["pairs"])
+    bad = [i for i in range(n) if crc[i] != g["crc32"][i]]
+    return {"checked": n, "equal": not bad, "first_mismatch": bad[0] if bad else None, "mismatches": len(bad),
+            "file_is_for_these_kernels": g.get("kernel_source_digest") == src, "file": "profiles/records_crc.json",
+            "note": "records of pair p are the same bits whatever GPU / rank / sub-batch aligned it; a mismatch with a stale file (other kernel sources) means nothing"}
 
 
 # ------------------------------------------------------------------------------------------------ CPU dry run of the N-rank plumbing
@@ -646,23 +740,26 @@ def dry_run_cpu(args, rank, world):
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     P = args.pairs
-    seeds = list(shard.shard_range(world * P, rank, world))
+    total = args.total_pairs if args.total_pairs > 0 else world * P
+    seeds = list(shard.shard_range(total, rank, world))
+    P = len(seeds); Pmax = (total + world - 1) // world
     res = np.zeros(P, ALIGN_RESULT_DTYPE)
     for i, s in enumerate(seeds):      # what pwn_hip_align_batch would have filled in for pair s
         T = np.eye(4, dtype=np.float32); T[:3, 3] = (s, 2 * s, -s)
         res["T"][i] = T.T.reshape(-1); res["error"][i] = 0.5 * s; res["inliers"][i] = 1000 + s; res["iterations"][i] = 10
     rec = torch.from_numpy(shard.pack_results_raw(res, seeds))
-    g = shard.gather_records(rec, world, P)
+    g = shard.gather_records(rec, world, Pmax)
     t = torch.tensor([float(rank)], dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.barrier()
     if rank == 0:
-        allrec = shard.assemble(g.numpy(), world * P)
+        allrec = shard.assemble(g.numpy(), total)
         ok = all(allrec[p, 12] == p and allrec[p, 13] == 2 * p and allrec[p, 14] == -p and allrec[p, 17] == 1000 + p and allrec[p, 19] == p
-                 for p in range(world * P))
+                 for p in range(total))
         print(json.dumps({"dry_run": True, "n_gpus": world, "records": int(allrec.shape[0]), "records_ok": bool(ok), "max_rank_seen": int(t.item()),
-                          "pairs_per_gpu": P}))
+                          "pairs_per_gpu": P, "scaling": "strong" if args.total_pairs > 0 else "weak", "total_pairs": total,
+                          "records_crc": records_crc(allrec)[:4]}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -700,7 +797,9 @@ def main():
 
     # synthetic inputs of this rank's shard (and of the extra lines), rendered on the CPU before the GPU is initialised
     from g2o_frontend_amd import shard, synth
-    seeds = list(shard.shard_range(world * P, rank, world))          # contiguous shard of the global pair list
+    total = args.total_pairs if args.total_pairs > 0 else world * P      # strong scaling: the same pair list whatever N is; weak: --pairs per rank
+    seeds = list(shard.shard_range(total, rank, world))                  # contiguous shard of the global pair list
+    P = len(seeds)
     jobs = [("pair", s, rows, cols, K) for s in seeds]
     n5 = 0; poses = None
     if extras_on and not args.no_config5 and (rows, cols) == (480, 640):
@@ -734,15 +833,24 @@ def main():
     n_seen = dist.get_world_size() if use_dist else 1                            # the ranks the process group actually holds
 
     w = BatchWorkload(args, local, rows, cols, P, frames_mm, seeds, use_dist, world)
+    w.total = total; w.Pmax = (total + world - 1) // world
     dt, dt_serial = w.run(args.steps, args.warmup, profile=not args.no_profile)
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     rep = w.report(args.steps, dt, dt_serial, world)
+    gather_info = None
     if rank == 0:
-        allrec = shard.assemble(w.last["gathered"].cpu().numpy(), world * P)      # every pair of every rank arrived exactly once
-        assert allrec.shape[0] == world * P
+        allrec = shard.assemble(w.last["gathered"].cpu().numpy(), total)          # every pair of every rank arrived exactly once
+        assert allrec.shape[0] == total
+        mine = shard.pack_results_raw(w.last["res"], seeds)                        # this rank's own records as they left the C-ABI
+        gather_info = {"backend": "nccl (RCCL), all_gather_into_tensor on device tensors" if use_dist else "none (one rank: the local records)",
+                       "forced": bool(use_dist and world == 1), "world": n_seen, "records": int(allrec.shape[0]), "record_bytes": int(4 * allrec.shape[1]),
+                       "records_equal_local": bool(np.array_equal(allrec[np.asarray(seeds)].view(np.uint32), mine.view(np.uint32)))}
+        # determinism gate of the multi-GPU leg: a pair's record does not depend on which GPU aligned it, in which sub-batch or next to which
+        # other pairs (tests/test_gpu_properties.py), so the records any N assembles must equal, bit for bit, those of the one-GPU run
+        gather_info["records_vs_single_gpu_run"] = check_records_crc(allrec, rows, cols, write=args.write_records_crc and world == 1)
 
     extra = {}
     if not args.no_latency and rank == 0:
@@ -796,11 +904,11 @@ def main():
         out = {
             "metric": "depth-pair alignments/sec (640x480, 10 GN iters)", "value": rep["value"], "unit": "alignments/s",
             "n_gpus": n_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": rep["ms_per_step"],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "strong" if args.total_pairs > 0 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"loop-closure batch: {P} independent {cols}x{rows} depth pairs per GPU "
                                    f"(u16 mm frames resident in HBM; per pair: convert 2 frames + Aligner::align, "
                                    f"{alig['outer_iterations']}x{alig['inner_iterations']} GN iterations); BASELINE configs[3] shard",
-                       "pairs_per_gpu": P, "rows": rows, "cols": cols, "sub_frames": args.sub_frames, "sub_pairs": args.sub_pairs,
+                       "pairs_per_gpu": P, "total_pairs": total, "rows": rows, "cols": cols, "sub_frames": args.sub_frames, "sub_pairs": args.sub_pairs,
                        "streams": args.streams,
                        "parallelism": f"independent pairs sharded over {n_seen} GPU(s), RCCL all-gather of result records only"},
             "roofline": rep["roofline"],
@@ -809,6 +917,7 @@ def main():
             "stage_ms_per_step": rep["stage_ms_per_step"],
             "stage_launches_per_step": rep["stage_launches_per_step"],
             "counters_mean": rep["counters_mean"],
+            "gather": gather_info,
         }
         out.update(extra)
         print(json.dumps(out))

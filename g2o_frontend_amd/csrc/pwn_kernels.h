@@ -882,6 +882,10 @@ template <typename PTR, typename T> __device__ __forceinline__ void stream_store
 #endif
 }
 
+#ifndef PWN_ST_X
+#define PWN_ST_X 0   // timing experiments only (results wrong): 1 = no cloud stores, 2 = no arithmetic between the corner loads and the stores
+                     // (memory traffic alone), 4 = no integral-plane loads (the corner sums come from registers: arithmetic + stores alone)
+#endif
 __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ frames, ConvertParams cp, int nframes) {
   const int nxb = (cp.cols + 255) / 256;
   const int perFrame = nxb * cp.rows;
@@ -949,6 +953,15 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
     const unsigned oA = (unsigned)(ymax * cols + xmax), oB = (unsigned)(ymin * cols + xmin);
     const unsigned oC = (unsigned)(ymax * cols + xmin), oD = (unsigned)(ymin * cols + xmax);
     float a[kIntegralChannels];
+#if PWN_ST_X & 4
+    {   // timing experiment: a plausible window (a few thousand points around the pixel's own point) without touching the planes
+      const float cnt = (float)(2000 + ((oA ^ oB ^ oC ^ oD) & 1023));
+      const float jx = 0.01f * (float)(c & 31), jy = 0.01f * (float)(r & 31);
+      a[0] = cnt * P.x; a[1] = cnt * P.y; a[2] = cnt * P.z; a[3] = cnt;
+      a[4] = cnt * (P.x * P.x + 0.0100f + jx); a[5] = cnt * (P.x * P.y + 0.0010f); a[6] = cnt * (P.x * P.z + 0.0005f);
+      a[7] = cnt * (P.y * P.y + 0.0200f + jy); a[8] = cnt * (P.y * P.z + 0.0007f); a[9] = cnt * (P.z * P.z + 0.0001f);
+    }
+#else
 #pragma unroll
     for (int k = 0; k < kIntegralChannels; ++k) {
       const gptr<const char> pl = (gptr<const char>)(gintegral + (size_t)k * N);      // plane base: scalar; lane offsets: 32-bit bytes
@@ -958,8 +971,17 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
       v = v - *(gptr<const float>)(pl + 4u * oD);
       a[k] = v;
     }
+#endif
     const int n = (int)a[3];
+#if PWN_ST_X & 2
+    if (n >= cp.minPoints) {   // timing experiment: the loaded sums go straight to the stores
+      npts = n; nx = a[0]; ny = a[1]; nz = a[2]; curvature = a[4];
+      om[0] = a[5]; om[1] = a[6]; om[2] = a[7]; om[3] = a[8]; om[4] = a[9]; om[5] = a[0] + a[9]; om[6] = a[1] + a[8]; om[7] = a[2] + a[7]; om[8] = a[4] + a[6];
+    }
+    if (false) {
+#else
     if (n >= cp.minPoints) {
+#endif
       npts = n;
       // PointAccumulator::mean / covariance (pointaccumulator.h:66-86)
       float d = a[3];
@@ -990,7 +1012,7 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
   }
   // information matrices
   const float sq = dot4seq(nx, nx, ny, ny, nz, nz, 0.f, 0.f);
-  if (sq > 0) {
+  if (sq > 0 && !(PWN_ST_X & 2)) {
     float dg[3];
     if (curvature < cp.pointInfoCurvThr) { dg[0] = cp.pFlat[0]; dg[1] = cp.pFlat[1]; dg[2] = cp.pFlat[2]; }
     else { dg[0] = 1.0f / ev[0]; dg[1] = 1.0f / ev[1]; dg[2] = 1.0f / ev[2]; }
@@ -1043,6 +1065,12 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
       for (int j = 0; j < 3; ++j) om[3 * i + j] = dot3seq(t1[3 * i], m(j,0), t1[3 * i + 1], m(j,1), t1[3 * i + 2], m(j,2));
   }
   (void)cls;      // not stored: normal_class(normal, curvature, normalInfoCurvThr) gives it back
+#if PWN_ST_X & 1
+  {   // timing experiment: no stores; the test depends on every output so that none of the arithmetic can be sunk behind it
+    const float chk = ((((P.x + P.y) + (P.z + nx)) + ((ny + nz) + (curvature + om[0]))) + (((om[1] + om[2]) + (om[3] + om[4])) + ((om[5] + om[6]) + (om[7] + om[8]))));
+    if (chk != 12345.678f) return;
+  }
+#endif
   {
     // one 12-byte and one 16-byte store (dword stores per lane would write every 1 KiB segment of the wave several times at a fraction of the density)
     v3f pv; pv.x = P.x; pv.y = P.y; pv.z = P.z;

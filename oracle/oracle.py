@@ -132,6 +132,7 @@ def lib():
         L.orc_align_statistics.argtypes = [C.c_void_p] * 9
         L.orc_iso_inverse.argtypes = [C.c_void_p] * 2
         L.orc_iso_mul.argtypes = [C.c_void_p] * 3
+        L.orc_reorthonormalize.argtypes = [C.c_void_p] * 2
         L.orc_match_score.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_float] + [C.c_void_p] * 4
         L.orc_set_gaussians.argtypes = [C.c_int, C.c_float, C.c_float]
         L.orc_cloud_num_gaussians.argtypes = [C.c_void_p]; L.orc_cloud_num_gaussians.restype = C.c_int
@@ -462,6 +463,13 @@ def iso_inverse(T):
 def iso_mul(A, B):
     a = _f32(np.asarray(A, np.float32).T.reshape(-1)); b = _f32(np.asarray(B, np.float32).T.reshape(-1)); o = np.empty(16, np.float32)
     lib().orc_iso_mul(_p(a), _p(b), _p(o))
+    return o.reshape(4, 4).T.copy()
+
+
+def reorthonormalize(T):
+    """pwn_tracker/pwn_tracker.cpp:154-159"""
+    a = _f32(np.asarray(T, np.float32).T.reshape(-1)); o = np.empty(16, np.float32)
+    lib().orc_reorthonormalize(_p(a), _p(o))
     return o.reshape(4, 4).T.copy()
 
 

@@ -1261,6 +1261,20 @@ void orc_compute_statistics(const float Hin[36], const float T[16], float mean[6
 
 void orc_iso_inverse(const float T[16], float out[16]) { const M4 r = iso_inverse(m4_load(T)); std::memcpy(out, r.m, sizeof(r.m)); }
 void orc_iso_mul(const float A[16], const float B[16], float out[16]) { const M4 r = iso_mul(m4_load(A), m4_load(B)); std::memcpy(out, r.m, sizeof(r.m)); }
+/* PwnTracker::processFrame's periodic clean-up of the accumulated rotation (pwn_tracker/pwn_tracker.cpp:154-159):
+ *   R = globalT.linear(); E = R^T R; E.diagonal() -= 1; globalT.linear() -= 0.5 * R * E
+ * (0.5 * R is exact in fp32, so (0.5 R) E and 0.5 (R E) are the same bits whichever way Eigen groups the expression). */
+void orc_reorthonormalize(const float T[16], float out[16]) {
+  M4 t = m4_load(T);
+  const M3 R = iso_linear(t);
+  M3 Rt; for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) Rt(i,j) = R(j,i);
+  M3 E = m3_mul(Rt, R);
+  E(0,0) -= 1.0f; E(1,1) -= 1.0f; E(2,2) -= 1.0f;
+  M3 hR; for (int k = 0; k < 9; ++k) hR.m[k] = 0.5f * R.m[k];
+  const M3 D = m3_mul(hR, E);
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) t(i,j) = R(i,j) - D(i,j);
+  std::memcpy(out, t.m, sizeof(t.m));
+}
 void orc_v2t(const float v[6], float T[16]) { const M4 t = v2t(v); std::memcpy(T, t.m, sizeof(t.m)); }
 void orc_t2v(const float T[16], float v[6]) { t2v(m4_load(T), v); }
 void orc_eigen3(const float A[9], float evals[3], float evecs[9]) {

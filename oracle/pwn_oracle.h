@@ -154,6 +154,8 @@ void orc_align_statistics(const orc_aligner_params* p, const orc_cloud* ref, con
 /* Isometry3f::inverse / product (used by the tracker harness of the tests) */
 void orc_iso_inverse(const float T[16], float out[16]);
 void orc_iso_mul(const float A[16], const float B[16], float out[16]);
+/* pwn_tracker/pwn_tracker.cpp:154-159: globalT.linear() -= 0.5 * R * (R^T R - I) (every 50th frame of PwnTracker::processFrame) */
+void orc_reorthonormalize(const float T[16], float out[16]);
 /* bm_se3.h:9-52 exposed for unit tests */
 void orc_v2t(const float v[6], float T[16]);
 void orc_t2v(const float T[16], float v[6]);

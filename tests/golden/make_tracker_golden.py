@@ -2,7 +2,7 @@
 """Generates tests/golden/tracker_vga_sweep.json: BASELINE configs[2] at its stated size -- the 200-frame synthetic VGA stream
 synth.trajectory_sweep(9, 200) through PwnTracker::processFrame semantics (pwn_tracker/pwn_tracker.cpp:106-215), matcher scale 1,
 reference configuration pwn_aligner_1_1.conf -- run through the CPU oracle (tests/oracle_tracker.py).  Per frame: key-frame decision,
-inliers, chi2, globalT.  About 90 s on 8 cores.  The GPU test (tests/test_tracker.py) compares all 200 frames with this file and re-runs the
+inliers, chi2, globalT (after the re-orthonormalisation of every 50th frame, pwn_tracker.cpp:154-159), the aligner's T.  About 90 s on 8 cores.  The GPU test (tests/test_tracker.py) compares all 200 frames with this file and re-runs the
 oracle live on a prefix to show the file is what the oracle gives."""
 import json
 import os
@@ -31,7 +31,8 @@ def main():
         depth = O.convert_16u_to_32f(synth.render_depth_mm(SEED, poses[k], rows, cols, K, hole_stream=k))
         o = otr.processFrame(depth, I, Km)
         rec.append(dict(newFrame=bool(o["newFrame"]), inliers=int(o.get("inliers", 0)), error=float(o.get("error", 0.0)),
-                        globalT=[float(np.float32(v)) for v in o["globalT"].reshape(-1)]))
+                        globalT=[float(np.float32(v)) for v in o["globalT"].reshape(-1)],
+                        T=[float(np.float32(v)) for v in o["T"].reshape(-1)] if "T" in o else None))
         if k % 20 == 0:
             print(k, rec[-1]["newFrame"], rec[-1]["inliers"], file=sys.stderr, flush=True)
     out = dict(seed=SEED, frames=FRAMES, scale=SCALE, newFrameInliersFraction=FRACTION, rows=rows, cols=cols,

@@ -31,8 +31,10 @@ class OracleTracker:
                                   accumulate_fp64=1, **self.alig)
             res = O.align(ap, self.prev, cur)
             self.globalT = O.iso_mul(self.prevT, res["T"]) if res["inliers"] > 0 else O.iso_mul(self.globalT, guess)
+            if not (self.counter % 50):                       # pwn_tracker.cpp:154-159: every 50th frame R <- R - 0.5 R (R^T R - I)
+                self.globalT = O.reorthonormalize(self.globalT)
             self.globalT[3] = (0, 0, 0, 1)
-            out.update(inliers=res["inliers"], error=res["error"])
+            out.update(T=res["T"].copy(), inliers=res["inliers"], error=res["error"])
             if np.float32(res["inliers"]) / np.float32(r * c) < self.fraction:
                 out["newFrame"] = True; self.keyframes += 1
                 self.prev, self.prevT = cur, self.globalT.copy()

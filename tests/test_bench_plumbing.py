@@ -82,3 +82,32 @@ def test_render_pool_keeps_job_order():
         ref, cur, _ = synth.make_pair(s, 60, 80, K)
         assert np.array_equal(got[s][0], ref) and np.array_equal(got[s][1], cur)
     assert np.array_equal(got[5], synth.render_depth_mm(9, np.eye(4), 60, 80, K, hole_stream=3))
+
+
+def test_strong_scaling_mode_shards_one_pair_list_and_assembles_the_same_records():
+    """`--total-pairs T` (BASELINE configs[3] literally: the SAME 1024-pair list over N GPUs): the records rank 0 assembles at N = 2 --
+    uneven shards included -- are the records of the N = 1 run (CRC per record), and the line says "strong"."""
+    runs = {}
+    for n in (1, 2):
+        out = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--dry-run-cpu", "--total-pairs", "13"], capture_output=True, text=True,
+                             timeout=300, env=_clean_env())
+        assert out.returncode == 0, out.stderr[-2000:]
+        runs[n] = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+        assert runs[n]["records"] == 13 and runs[n]["records_ok"] and runs[n]["scaling"] == "strong" and runs[n]["total_pairs"] == 13
+    assert runs[1]["pairs_per_gpu"] == 13 and runs[2]["pairs_per_gpu"] in (6, 7)
+    assert runs[1]["records_crc"] == runs[2]["records_crc"]
+
+
+def test_records_crc_gate(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import bench
+    rec = np.arange(5 * 20, dtype=np.float32).reshape(5, 20)
+    monkeypatch.setattr(bench, "RECORDS_CRC_FILE", str(tmp_path / "records_crc.json"))
+    assert bench.check_records_crc(rec, 480, 640)["checked"] == 0                     # no file yet
+    w = bench.check_records_crc(rec, 480, 640, write=True)
+    assert w["checked"] == 5 and w["equal"] and w["file_is_for_these_kernels"]
+    assert bench.check_records_crc(rec[:3], 480, 640)["checked"] == 3                 # a shorter pair list checks its prefix
+    bad = rec.copy(); bad[2, 7] += 1
+    r = bench.check_records_crc(bad, 480, 640)
+    assert not r["equal"] and r["first_mismatch"] == 2 and r["mismatches"] == 1
+    assert bench.check_records_crc(rec, 960, 1280)["checked"] == 0                    # another frame size: not comparable

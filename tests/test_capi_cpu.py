@@ -168,3 +168,21 @@ def test_product_does_not_import_the_oracle():
                 if f.endswith((".py", ".h", ".hip", ".cpp", ".hpp")):
                     txt = open(os.path.join(dirpath, f)).read()
                     assert not pat.search(txt), os.path.join(dirpath, f)
+
+
+def test_bench_imports_the_oracle_only_in_the_cpu_baseline_leg():
+    """bench.py's GPU-driving process never imports the checker: `from oracle import ...` may appear only inside the two functions of the
+    cpu_baseline child process (round-2 review: the parameter tables now live in g2o_frontend_amd/conf.py)."""
+    import ast
+    tree = ast.parse(open(os.path.join(ROOT, "bench.py")).read())
+    allowed = {"_cpu_worker", "cpu_baseline_child"}
+
+    def visit(node, fn):
+        for ch in ast.iter_child_nodes(node):
+            name = ch.name if isinstance(ch, (ast.FunctionDef, ast.AsyncFunctionDef)) else fn
+            if isinstance(ch, ast.ImportFrom) and (ch.module or "").split(".")[0] == "oracle":
+                assert fn in allowed, (fn, ch.lineno)
+            if isinstance(ch, ast.Import):
+                assert not any(a.name.split(".")[0] == "oracle" for a in ch.names) or fn in allowed, (fn, ch.lineno)
+            visit(ch, name)
+    visit(tree, None)

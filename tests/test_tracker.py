@@ -10,6 +10,10 @@ pytestmark = pytest.mark.gpu
 
 from oracle_tracker import OracleTracker  # noqa: E402  (processFrame restated on top of the oracle)
 
+# bars of test_config2_full_size_stream_matches_oracle (measured values are printed by the test; profiles/r03_tracker_parity.txt)
+FREE_INLIERS_BAR, FREE_POSE_BAR = 64, 2e-4          # free-running chain of 200 frames / 5 key-cloud switches
+FORCED_INLIERS_BAR, FORCED_POSE_BAR = 64, 2e-4      # one alignment from the oracle's own state (tightened below the free-running bars once measured)
+
 
 def test_processFrame_trajectory_and_keyframes_match_oracle(oracle):
     from g2o_frontend_amd import api, synth
@@ -67,10 +71,17 @@ def test_cloud_cache_lru_and_reconversion(oracle):
 def test_config2_full_size_stream_matches_oracle():
     """BASELINE configs[2] at its stated size: the 200-frame VGA stream of synth.trajectory_sweep(9) through PwnTracker::processFrame
     (pwn_tracker/pwn_tracker.cpp:106-215) at matcher scale 1 with the reference's new-frame fraction 0.4 -- a trajectory that switches the
-    key-cloud five times (:164-185).  Every frame against the oracle tracker's record of the same stream (tests/golden/tracker_vga_sweep.json,
-    made by tests/golden/make_tracker_golden.py): key-frame decisions identical, inliers within a few correspondences, globalT within the
-    free-running pose bar accumulated along the chain; the oracle is re-run live on a prefix that contains the first switch to show the file
-    is the oracle's output; size-independent properties on all 200 frames."""
+    key-cloud five times (:164-185) and passes the re-orthonormalisation of every 50th frame (:154-159) three times.  Every frame against the
+    oracle tracker's record of the same stream (tests/golden/tracker_vga_sweep.json, made by tests/golden/make_tracker_golden.py):
+
+    * free-running leg: the tracker runs on its own state from frame 0: key-frame decisions identical, inliers and globalT within the
+      free-running bars accumulated along the chain of key-frames;
+    * teacher-forced leg: a second tracker whose chain state (_globalT, _previousCloudTransform; its key cloud is bit-identical by the
+      converter's parity) is set to the oracle's before every frame, so each alignment starts from the oracle's own initial guess and only
+      the ten iterations of ONE alignment separate the two sides: inliers within a handful, aligner T and globalT at the single-alignment bar;
+    * the oracle is re-run live on a prefix that contains the first switch and, from the recorded state, across frame 50 (bit-identical to
+      the file: the file is the oracle's output, re-orthonormalisation included);
+    * size-independent properties on all 200 frames."""
     import json
     import os
     from g2o_frontend_amd import api, synth
@@ -85,36 +96,65 @@ def test_config2_full_size_stream_matches_oracle():
     alproj = api.PinholePointProjector(); alproj.setMinDistance(alig["min_distance"]); alproj.setMaxDistance(alig["max_distance"])
     aligner.setProjector(alproj)
     tracker = api.PwnTracker(aligner, converter); tracker.setScale(1); tracker.setNewFrameInliersFraction(gold["newFrameInliersFraction"])
+    forced = api.PwnTracker(aligner, converter); forced.setScale(1); forced.setNewFrameInliersFraction(gold["newFrameInliersFraction"])
     otr = OracleTracker(O, conv, alig, 1, gold["newFrameInliersFraction"])
     Km = np.array([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]], np.float32)
     I = np.eye(4, dtype=np.float32)
     poses = synth.trajectory_sweep(gold["seed"], n)
+    gT = [np.asarray(e["globalT"], np.float32).reshape(4, 4) for e in gold["per_frame"]]
     live_prefix = 30                                    # the oracle costs ~0.45 s per VGA frame; the first switch is at frame 24
+    live_again = (49, 52)                               # ... and frames 49..51 from the recorded state: the step of pwn_tracker.cpp:154-159 at frame 50
     keyframes, worst_pose, worst_inl = [], 0.0, 0
+    f_worst_pose, f_worst_T, f_worst_inl, f_equal = 0.0, 0.0, 0, 0
+    last_key = 0
+    key_depth = None
     for k in range(n):
         depth = ctx.DepthImage_convert_16UC1_to_32FC1(synth.render_depth_mm(gold["seed"], poses[k], rows, cols, K, hole_stream=k))
-        g = tracker.processFrame(depth, I, Km)
         e = gold["per_frame"][k]
-        if k < live_prefix:
+        # --- the oracle, live
+        if k == live_again[0]:                          # restart the oracle tracker from the file's state just before frame 49
+            otr = OracleTracker(O, conv, alig, 1, gold["newFrameInliersFraction"])
+            otr.prev, _, _, _ = otr.makeCloud(Km, I, key_depth)
+            otr.prevT, otr.prevOff, otr.globalT, otr.counter = gT[last_key].copy(), I.copy(), gT[k - 1].copy(), k
+        if k < live_prefix or live_again[0] <= k < live_again[1]:
             o = otr.processFrame(depth, I, Km)
             assert o["newFrame"] == e["newFrame"] and int(o.get("inliers", 0)) == e["inliers"], k
             assert np.array_equal(o["globalT"].reshape(-1).astype(np.float32), np.asarray(e["globalT"], np.float32)), k
+        # --- free-running leg
+        g = tracker.processFrame(depth, I, Km)
         assert g["newFrame"] == e["newFrame"], (k, g.get("inliers"), e["inliers"])
         if g["newFrame"]:
             keyframes.append(k)
         if k > 0:
             worst_inl = max(worst_inl, abs(g["inliers"] - e["inliers"]))
-            assert abs(g["inliers"] - e["inliers"]) <= 64, (k, g["inliers"], e["inliers"])                # of ~150 000
+            assert abs(g["inliers"] - e["inliers"]) <= FREE_INLIERS_BAR, (k, g["inliers"], e["inliers"])         # of ~150 000
             assert g["inliers"] > 0 and g["aligned"]
         dT = np.abs(g["globalT"].reshape(-1) - np.asarray(e["globalT"], np.float32)).max()
         worst_pose = max(worst_pose, float(dT))
-        assert dT < 2e-4, (k, dT)                       # free-running chain: 1e-5-class per alignment, chained over the key-frames
-        # properties that hold at any size: globalT is a rigid transform and follows the true camera motion
+        assert dT < FREE_POSE_BAR, (k, dT)              # free-running chain: 1e-5-class per alignment, chained over the key-frames
+        # --- teacher-forced leg
+        if k > 0:
+            forced._globalT = gT[k - 1].copy(); forced._previousCloudTransform = gT[last_key].copy()
+        f = forced.processFrame(depth, I, Km)
+        assert f["newFrame"] == e["newFrame"], (k, f.get("inliers"), e["inliers"])
+        if k > 0:
+            d_inl = abs(f["inliers"] - e["inliers"])
+            f_worst_inl = max(f_worst_inl, d_inl); f_equal += int(d_inl == 0)
+            assert d_inl <= FORCED_INLIERS_BAR, (k, f["inliers"], e["inliers"])
+            dTa = float(np.abs(f["T"].reshape(-1) - np.asarray(e["T"], np.float32).reshape(4, 4).reshape(-1)).max())
+            dTg = float(np.abs(f["globalT"].reshape(-1) - np.asarray(e["globalT"], np.float32)).max())
+            f_worst_T, f_worst_pose = max(f_worst_T, dTa), max(f_worst_pose, dTg)
+            assert dTa < FORCED_POSE_BAR and dTg < FORCED_POSE_BAR, (k, dTa, dTg)
+        if e["newFrame"]:
+            last_key, key_depth = k, depth
+        # --- properties that hold at any size: globalT is a rigid transform and follows the true camera motion
         R = g["globalT"][:3, :3].astype(np.float64)
         assert np.abs(R.T @ R - np.eye(3)).max() < 1e-4 and np.array_equal(g["globalT"][3], [0, 0, 0, 1])
         true = np.linalg.inv(poses[0]) @ poses[k]
         assert np.abs(g["globalT"][:3, 3] - true[:3, 3]).max() < 0.04, (k, g["globalT"][:3, 3], true[:3, 3])   # odometry drift; the oracle's own chain reaches 2.1 cm
     assert keyframes == gold["keyframes"] and len(keyframes) - 1 >= 3          # >= 3 key-cloud switches after the first frame
-    assert tracker.numKeyframes() == len(keyframes)
-    print(f"config2: key-frames {keyframes}, worst |inliers diff| {worst_inl}, worst |globalT diff| {worst_pose:.2e}")
+    assert tracker.numKeyframes() == forced.numKeyframes() == len(keyframes)
+    print(f"config2: key-frames {keyframes}; free-running: worst |inliers diff| {worst_inl}, worst |globalT diff| {worst_pose:.2e}; "
+          f"teacher-forced: inliers equal on {f_equal} of {n - 1} frames, worst |diff| {f_worst_inl}, worst |T diff| {f_worst_T:.2e}, "
+          f"worst |globalT diff| {f_worst_pose:.2e}")
     ctx.close()
