@@ -60,8 +60,8 @@ class DeviceBuffer:
         return out
 
     def free(self):
-        if self._p and self.ctx.h:
-            self.ctx._L.pwn_hip_device_free(self.ctx.h, self._p)
+        if self._p:      # a context that is already closed took its streams along: the buffer is freed without it (plain hipFree)
+            self.ctx._L.pwn_hip_device_free(self.ctx.h if self.ctx.h else None, self._p)
         self._p = C.c_void_p()
 
     def __del__(self):
@@ -81,14 +81,14 @@ class _DeviceView:
 
 
 class _PinnedBlock:
-    """owner of one pwn_hip_host_alloc block (freed when the last array view over it goes away)"""
+    """owner of one pwn_hip_host_alloc block; freed when the last array view over it is gone (every numpy view reaches it through its
+    base chain: view -> memoryview -> the ctypes buffer below, which holds the only reference to this owner)"""
 
     def __init__(self, nbytes):
         self.ptr = C.c_void_p()
         rc = _lib.lib().pwn_hip_host_alloc(C.byref(self.ptr), nbytes)
         if rc != 0:
             raise _lib.PwnHipError(rc, _lib.lib().pwn_hip_last_error_string(None).decode())
-        self.buf = (C.c_char * nbytes).from_address(self.ptr.value)
 
     def __del__(self):
         try:
@@ -99,20 +99,21 @@ class _PinnedBlock:
 
 
 def pinned_empty(shape, dtype=np.float32):
-    """numpy array in page-locked host memory (pwn_hip_host_alloc): depth frames handed over from it are copied by asynchronous DMA"""
+    """numpy array in page-locked host memory (pwn_hip_host_alloc): depth frames handed over from it are copied by asynchronous DMA.
+    The memory lives as long as any view of the array does.  Before the last view goes away, make sure no pwn_hip_copy_async from it is
+    still in flight (a convert call on that context, or Context.synchronize(), has returned)."""
     dtype = np.dtype(dtype)
     n = int(np.prod(shape))
-    blk = _PinnedBlock(max(1, n * dtype.itemsize))
-    a = np.frombuffer(blk.buf, dtype=dtype, count=n).reshape(shape)
-    _PINNED[a.__array_interface__["data"][0]] = blk          # keeps the block alive; release with pinned_free
-    return a
-
-
-_PINNED = {}
+    nbytes = max(1, n * dtype.itemsize)
+    blk = _PinnedBlock(nbytes)
+    buf = (C.c_char * nbytes).from_address(blk.ptr.value)
+    buf._pwn_owner = blk                                       # the buffer object keeps the block alive, the arrays keep the buffer alive
+    return np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
 
 
 def pinned_free(a):
-    _PINNED.pop(a.__array_interface__["data"][0], None)
+    """kept for callers of the earlier interface: the block is released with its last view, nothing to do here"""
+    return None
 
 
 def _colmajor(M, n):

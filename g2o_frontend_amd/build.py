@@ -8,6 +8,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SOURCES = [os.path.join(_HERE, "csrc", f) for f in ("pwn_hip_capi.hip", "pwn_kernels.h", "pwn_math.h", "pwn_scene_kernels.h", "pwn_scene_capi.h", "pwn_stats.h")]
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "pwn_hip.h")
+TEST_HEADER = os.path.join(os.path.dirname(_HERE), "include", "pwn_hip_testing.h")
 OUT = os.path.join(_HERE, "libpwn_hip.so")
 # -ffp-contract=off: the kernels reproduce the CPU path's evaluation order; a fused multiply-add would change bits.
 # -fno-slp-vectorize: the SLP vectoriser pairs scalar fp32 ops into v_pk_*_f32 and pays for it in v_mov shuffles and registers
@@ -17,7 +18,7 @@ FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fn
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
-    deps = SOURCES + [HEADER, __file__]
+    deps = SOURCES + [HEADER, TEST_HEADER, __file__]
     stale = (not os.path.exists(OUT)) or any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps)
     if force or stale:
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")

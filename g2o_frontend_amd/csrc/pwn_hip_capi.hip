@@ -6,7 +6,9 @@
 // in a kernel of pwn_kernels.h, and the Gauss-Newton loop runs without host round trips (the 6x6 solve and
 // the SE(3) update are a one-wave kernel).  There is no CPU fallback: without a HIP device every entry point
 // returns PWN_HIP_ERR_NO_DEVICE.
+#include <cstdlib>
 #include "../../include/pwn_hip.h"
+#include "../../include/pwn_hip_testing.h"
 #include "pwn_kernels.h"
 #include "pwn_scene_kernels.h"
 #include "pwn_stats.h"
@@ -56,6 +58,8 @@ struct pwn_hip_ctx {
   hipEvent_t fork_ev = nullptr, join_ev = nullptr, join_extra[2] = { nullptr, nullptr };
   hipStream_t copy_stream = nullptr;       // host frames of a batch call are copied on their own stream, one sub-batch ahead of the kernels
   std::vector<hipEvent_t> sync_events;     // ordering events of that hand-over (copied[k], converted[k]); grown on demand
+  std::vector<hipEvent_t> stagger_events;  // front_done[k] of a converter batch call: sub-batch k+1's front end starts when sub-batch k's has finished (convert_batch_impl)
+  int convert_stagger = 1;                 // PWN_CONVERT_STAGGER=0 switches the staggered schedule off (A/B)
   hipEvent_t copy_ev = nullptr;            // pwn_hip_copy_async: the next call that reads frames waits for the copies issued so far
   bool copy_pending = false;
   int max_rows = 0, max_cols = 0, max_batch = 0;
@@ -385,7 +389,10 @@ int ensure_desc(pwn_hip_ctx* ctx, int n) {
 }
 
 // launch sequence of the converter for the frames [base, base+n) of the uploaded descriptor array
-int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, hipStream_t st) {
+// front_wait / front_done (optional): the front end (strip counts + k_unproject_integral) starts after `front_wait` and records `front_done`
+// when it has finished -- the staggered schedule of convert_batch_impl
+int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, hipStream_t st, hipEvent_t front_wait = nullptr, hipEvent_t front_done = nullptr) {
+  if (front_wait) HIPCHK(ctx, hipStreamWaitEvent(st, front_wait, 0), PWN_HIP_ERR_LAUNCH);
   const FrameDesc* fr = ctx->frames_dev + base;
 #ifndef PWN_SINGLE_PASS_MIN_FRAMES
 #define PWN_SINGLE_PASS_MIN_FRAMES 16     // measured on MI355X at VGA (tools/ab_convert_n.py), three kernels vs single pass: 8 frames 0.20 vs 0.27 ms, 16 frames 0.38 vs 0.35, 32 frames 0.74 vs 0.58
@@ -423,6 +430,7 @@ int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, h
     { StageTimer t(ctx, "integral_cols", st);
       hipLaunchKernelGGL(k_integral_cols, dim3((cp.cols + kIC_Block - 1) / kIC_Block, kIntegralChannels, n), dim3(kIC_Block), 0, st, fr, cp.rows, cp.cols); }
   }
+  if (front_done) HIPCHK(ctx, hipEventRecord(front_done, st), PWN_HIP_ERR_LAUNCH);
   { StageTimer t(ctx, "stats", st);
     const unsigned perFrame = (unsigned)cp.rows * (unsigned)((cp.cols + 255) / 256);
     const unsigned nblk = (n >= 8 ? 8u * (unsigned)((n + 7) / 8) : (unsigned)n) * perFrame;      // see k_stats: XCD-aware placement from 8 frames on
@@ -540,6 +548,13 @@ int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, cons
     }
     HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->fork_ev, 0), PWN_HIP_ERR_LAUNCH);      // after everything queued before this call
   }
+  const bool stagger = plan.dual() && ctx->convert_stagger && nsub > 1 && !ctx->profiling;
+  if (stagger)
+    while ((int)ctx->stagger_events.size() < nsub) {
+      hipEvent_t e = nullptr;
+      HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming), PWN_HIP_ERR_ALLOCATION);
+      ctx->stagger_events.push_back(e);
+    }
   for (int base = 0, k = 0; base < n; base += sub, ++k) {
     const int m = std::min(sub, n - base);
     hipStream_t st = plan.stream(k);
@@ -563,7 +578,13 @@ int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, cons
         HIPCHK(ctx, hipStreamWaitEvent(st, ctx->sync_events[2 * k], 0), PWN_HIP_ERR_LAUNCH);
       }
     }
-    if (int rc = launch_convert(ctx, cp, base, m, st)) return rc;
+    // Staggered schedule (two or more streams): the front end of sub-batch k+1 starts when the front end of sub-batch k has finished, so it
+    // runs NEXT TO k_stats of sub-batch k instead of next to the other stream's front end.  The two kernels want different things from a CU
+    // -- the front end is a chain of dependent LDS steps and hand-over waits that leaves the vector ALUs and most of the memory system idle,
+    // k_stats is gathers + arithmetic + streamed stores -- and overlap far better with each other than each does with itself.
+    hipEvent_t fw = nullptr, fd = nullptr;
+    if (stagger) { fw = k > 0 ? ctx->stagger_events[k - 1] : nullptr; fd = ctx->stagger_events[k]; }
+    if (int rc = launch_convert(ctx, cp, base, m, st, fw, fd)) return rc;
     if (ahead) HIPCHK(ctx, hipEventRecord(ctx->sync_events[2 * k + 1], st), PWN_HIP_ERR_LAUNCH);
   }
   if (int rc = plan_join(ctx, plan)) return rc;
@@ -605,8 +626,12 @@ int pwn_hip_device_alloc(pwn_hip_ctx* ctx, void** ptr, size_t bytes) {
   return PWN_HIP_OK;
 }
 int pwn_hip_device_free(pwn_hip_ctx* ctx, void* ptr) {
-  if (!ctx) return fail(nullptr, PWN_HIP_ERR_INVALID_ARGUMENT, "null context");
   if (!ptr) return PWN_HIP_OK;
+  if (!ctx) {      // the context that allocated it is gone (and with it everything that could still use the buffer): plain hipFree, which
+    hipError_t e = hipFree(ptr);      // waits for the device by itself
+    if (e != hipSuccess) { (void)hipGetLastError(); return fail(nullptr, PWN_HIP_ERR_INVALID_ARGUMENT, std::string("hipFree: ") + hipGetErrorString(e)); }
+    return PWN_HIP_OK;
+  }
   HIPCHK(ctx, hipSetDevice(ctx->device), PWN_HIP_ERR_NO_DEVICE);
   if (int rc = absorb_copies(ctx)) return rc;
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);       // nothing queued may still read or write it
@@ -670,6 +695,7 @@ int pwn_hip_ctx_create(pwn_hip_ctx** out, int device, int max_rows, int max_cols
   pwn_hip_ctx* ctx = new pwn_hip_ctx();
   ctx->device = device; ctx->max_rows = max_rows; ctx->max_cols = max_cols; ctx->max_batch = max_batch;
   ctx->N = (size_t)max_rows * max_cols;
+  if (const char* e = std::getenv("PWN_CONVERT_STAGGER")) ctx->convert_stagger = std::atoi(e);      // A/B switch of the converter's staggered schedule
   { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->num_cus = cus; }
   const size_t N = ctx->N, B = (size_t)max_batch;
   ctx->nblocks_max = align_nblocks((int)N);
@@ -744,6 +770,8 @@ int pwn_hip_ctx_destroy(pwn_hip_ctx* ctx) {
   if (ctx->copy_ev) (void)hipEventDestroy(ctx->copy_ev);
   for (hipEvent_t e : ctx->sync_events) (void)hipEventDestroy(e);
   ctx->sync_events.clear();
+  for (hipEvent_t e : ctx->stagger_events) (void)hipEventDestroy(e);
+  ctx->stagger_events.clear();
   if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
   if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
   delete ctx;
@@ -904,6 +932,7 @@ int pwn_hip_cloud_upload(pwn_hip_ctx* ctx, pwn_hip_cloud* c, int n, const float*
   if (!ctx || !c || n < 0 || !points || !normals || !curvature || !omega_p || !omega_n) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if (n > c->d.capacity) return fail(ctx, PWN_HIP_ERR_CAPACITY, "cloud capacity too small");
   cloud_changes(ctx, c);
+  if (int rc = absorb_copies(ctx)) return rc;      // caller pointers may be the destination of a queued pwn_hip_copy_async
   // repack on the host into the device layout (upload is not on the hot path)
   std::vector<float> hp((size_t)n * 4), hn((size_t)n * 4), hc(n), hop((size_t)n * 16), hon((size_t)n * 16);
   HIPCHK(ctx, copy_any(hp.data(), points, hp.size() * 4, ctx->stream), PWN_HIP_ERR_COPY);
@@ -1115,6 +1144,7 @@ int pwn_hip_project_intervals(pwn_hip_ctx* ctx, const pwn_hip_converter_params* 
 int pwn_hip_integral_image(pwn_hip_ctx* ctx, const int* index_image, const pwn_hip_cloud* cloud, int rows, int cols, float* out) {
   if (!ctx || !index_image || !cloud || !out) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if (int rc = check_image(ctx, rows, cols)) return rc;
+  if (int rc = absorb_copies(ctx)) return rc;      // caller pointers may be the destination of a queued pwn_hip_copy_async
   const size_t N = (size_t)rows * cols;
   fill_frame(ctx, 0, 0, nullptr, cloud->d, rows);
   HIPCHK(ctx, copy_any(ctx->frames_host[0].index, index_image, N * 4, ctx->stream), PWN_HIP_ERR_COPY);
@@ -1192,6 +1222,7 @@ int pwn_hip_correspondences(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, c
   const size_t N = (size_t)p->rows * p->cols;
   const AlignParams ap = make_align_params(p);
   int* ri = ctx->index_ws; int* ci = ctx->interval_ws;
+  if (int rc = absorb_copies(ctx)) return rc;      // caller pointers may be the destination of a queued pwn_hip_copy_async
   HIPCHK(ctx, copy_any(ri, ref_index, N * 4, ctx->stream), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, copy_any(ci, cur_index, N * 4, ctx->stream), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipMemsetAsync(ctx->counters_dev, 0, 16 * sizeof(int), ctx->stream), PWN_HIP_ERR_COPY);
@@ -1214,6 +1245,7 @@ int pwn_hip_linearize(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, const p
   if (!ctx || !p || !ref || !cur || (!corr && C > 0) || !T || C < 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if ((size_t)C > ctx->N) return fail(ctx, PWN_HIP_ERR_CAPACITY, "more correspondences than pixels");
   const AlignParams ap = make_align_params(p);
+  if (int rc = absorb_copies(ctx)) return rc;      // caller pointers may be the destination of a queued pwn_hip_copy_async
   if (C > 0) HIPCHK(ctx, copy_any(ctx->corr_ws, corr, (size_t)C * sizeof(int2), ctx->stream), PWN_HIP_ERR_COPY);
   const int nb = std::max(1, align_nblocks(C));
   { StageTimer t(ctx, "corr_linearize");

@@ -184,11 +184,16 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float4 load4(gptr<const v4f> p) { const v4f v = *p; return make_float4(v.x, v.y, v.z, v.w); }
 __device__ __forceinline__ void store4(gptr<v4f> p, const float4 v) { v4f t; t.x = v.x; t.y = v.y; t.z = v.z; t.w = v.w; *p = t; }
-typedef float v3f __attribute__((ext_vector_type(3)));
+// three packed floats: a clang ext_vector_type(3) has sizeof = alignof = 16, but the xyz records and the information-matrix rows sit at
+// 12-byte strides -- the access type therefore carries alignment 4 (still one global_load/store_dwordx3; an `align 16` access at a 4-byte
+// aligned address would be undefined behaviour and licenses the compiler to widen it to 16 bytes, over the next record;
+// tests/test_capi_cpu.py disassembles the library and checks that k_stats / k_unproject_integral contain no dwordx4 store)
+typedef float v3f_raw __attribute__((ext_vector_type(3)));
+typedef v3f_raw v3f __attribute__((aligned(4)));
 // point i of a packed xyz array as (x, y, z, 0): one 12-byte load
-__device__ __forceinline__ float4 load_xyz(gptr<const float> p3, unsigned i) { const v3f v = *(gptr<const v3f>)(p3 + 3u * i); return make_float4(v.x, v.y, v.z, 0.f); }
+__device__ __forceinline__ float4 load_xyz(gptr<const float> p3, unsigned i) { const v3f_raw v = *(gptr<const v3f>)(p3 + 3u * i); return make_float4(v.x, v.y, v.z, 0.f); }
 __device__ __forceinline__ float4 load_xyz(const float* p3, int i) { return load_xyz(as_global(p3), (unsigned)i); }
-__device__ __forceinline__ void store_xyz(float* p3, int i, float x, float y, float z) { v3f v; v.x = x; v.y = y; v.z = z; *(gptr<v3f>)(as_global(p3) + 3u * (unsigned)i) = v; }
+__device__ __forceinline__ void store_xyz(float* p3, int i, float x, float y, float z) { v3f_raw v; v.x = x; v.y = y; v.z = z; *(gptr<v3f>)(as_global(p3) + 3u * (unsigned)i) = v; }
 // Old-format view of point i for the code that is not hot (scene stage, stand-alone stages): P = (x, y, z, curvature),
 // Nm = (nx, ny, nz, class word); cloud_put stores the same view back (the class word is derived data and is dropped).
 __device__ __forceinline__ void cloud_get(const CloudDev& c, int i, float4& P, float4& Nm) {
@@ -568,7 +573,7 @@ __global__ void __launch_bounds__(256) k_unproject_integral_rows(const FrameDesc
 // bounded (kSpinLimit), a starved chain raises *fault and finishes with garbage instead of hanging the device.
 // Workgroup -> (frame, strip) puts all strips of a frame on one XCD (ids are dealt round-robin over the 8 XCDs), so the
 // hand-over words stay in that XCD's L2.  grid = 8 * ceil(frames/8) * strips, block = 256.
-constexpr int kII_Chains = kIntegralChannels * kIR_Rows;     // 160
+constexpr int kII_Chains = kII_ChainsRows;                   // 10 planes x band rows: the same hand-over word layout in both kernels that hand over
 constexpr int kSpinLimit = 1 << 20;      // polls of >= 64 cycles + one L2 round trip each: ~1 s, against hand-over waits of microseconds
 __host__ __device__ __forceinline__ int strips_of(int cols) { return (cols + kIR_Cols - 1) / kIR_Cols; }
 __host__ __device__ __forceinline__ int bands_of(int rows) { return (rows + kIR_Rows - 1) / kIR_Rows; }
@@ -881,6 +886,22 @@ template <typename PTR, typename T> __device__ __forceinline__ void stream_store
   *p = v;
 #endif
 }
+// the 12-byte records: not through the templates above (template argument deduction drops the typedef's alignment attribute and the access
+// would be emitted with the vector type's natural `align 16`)
+__device__ __forceinline__ v3f_raw stream_load3(gptr<const float> p) {
+#if PWN_STATS_NT
+  return __builtin_nontemporal_load((gptr<const v3f>)p);
+#else
+  return *(gptr<const v3f>)p;
+#endif
+}
+__device__ __forceinline__ void stream_store3(gptr<float> p, v3f_raw v) {
+#if PWN_STATS_NT
+  __builtin_nontemporal_store(v, (gptr<v3f>)p);
+#else
+  *(gptr<v3f>)p = v;
+#endif
+}
 
 #ifndef PWN_ST_X
 #define PWN_ST_X 0   // timing experiments only (results wrong): 1 = no cloud stores, 2 = no arithmetic between the corner loads and the stores
@@ -931,7 +952,7 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
     itv = (px > py) ? (int)px : (int)py;
   } else {
     itv = stream_load(ginterval + upix);
-    const v3f pv = stream_load((gptr<const v3f>)(gP + 3u * (unsigned)idx)); P.x = pv.x; P.y = pv.y; P.z = pv.z; P.w = 0.f;      // one 12-byte load
+    const v3f_raw pv = stream_load3((gptr<const float>)gP + 3u * (unsigned)idx); P.x = pv.x; P.y = pv.y; P.z = pv.z; P.w = 0.f;      // one 12-byte load
   }
   float nx = 0.f, ny = 0.f, nz = 0.f;
   float curvature = 0.f;          // Stats() default: eigenvalues 0 -> curvature() = 0/(0+1e-9) = 0  (stats.h:21-27,98-103)
@@ -1073,15 +1094,15 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
 #endif
   {
     // one 12-byte and one 16-byte store (dword stores per lane would write every 1 KiB segment of the wave several times at a fraction of the density)
-    v3f pv; pv.x = P.x; pv.y = P.y; pv.z = P.z;
+    v3f_raw pv; pv.x = P.x; pv.y = P.y; pv.z = P.z;
     v4f nv; nv.x = nx; nv.y = ny; nv.z = nz; nv.w = curvature;
-    stream_store((gptr<v3f>)(gP + 3u * (unsigned)idx), pv);
+    stream_store3(gP + 3u * (unsigned)idx, pv);
     stream_store((gptr<v4f>)(gN + 4u * (unsigned)idx), nv);
   }
 #pragma unroll
   for (int r3 = 0; r3 < 3; ++r3) {      // three 12-byte rows (nine dword stores per point cost k_stats 9 % more time)
-    v3f rw; rw.x = om[3 * r3]; rw.y = om[3 * r3 + 1]; rw.z = om[3 * r3 + 2];
-    stream_store((gptr<v3f>)(gOm + (size_t)r3 * 3u * (size_t)cap + 3u * (unsigned)idx), rw);
+    v3f_raw rw; rw.x = om[3 * r3]; rw.y = om[3 * r3 + 1]; rw.z = om[3 * r3 + 2];
+    stream_store3(gOm + (size_t)r3 * 3u * (size_t)cap + 3u * (unsigned)idx, rw);
   }
 }
 
@@ -1530,7 +1551,7 @@ __device__ __forceinline__ void candidate_consume(const PairDesc& pd, const Pair
 #else
 #pragma unroll
     for (int r3 = 0; r3 < 3; ++r3) {      // three 12-byte loads
-      const v3f rw = *(gptr<const v3f>)(q.curOm + (size_t)r3 * 3u * cap + 3u * ci);
+      const v3f_raw rw = *(gptr<const v3f>)(q.curOm + (size_t)r3 * 3u * cap + 3u * ci);
       oP[3 * r3] = rw.x; oP[3 * r3 + 1] = rw.y; oP[3 * r3 + 2] = rw.z;
     }
 #endif

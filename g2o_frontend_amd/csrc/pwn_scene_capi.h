@@ -112,6 +112,7 @@ int pwn_hip_cloud_gaussians(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p,
   if (int rc = check_image(ctx, rows, cols)) return rc;
   if (int rc = ensure_gauss(ctx, cloud)) return rc;
   if (int rc = ensure_desc(ctx, 1)) return rc;
+  if (int rc = absorb_copies(ctx)) return rc;      // caller pointers may be the destination of a queued pwn_hip_copy_async
   const size_t N = (size_t)rows * cols;
   const ConvertParams cp = make_convert_params(ctx, p, nullptr, rows, cols, 0);
   Mat4 KRt, iKRt; Mat3 iK;

@@ -163,11 +163,14 @@ int pwn_hip_host_free(void* ptr);
  * of time with pwn_hip_copy are used in place by the convert calls (no staging copy).  pwn_hip_copy: any direction, ordered after the work
  * already queued on the context, complete on return. */
 int pwn_hip_device_alloc(pwn_hip_ctx* ctx, void** ptr, size_t bytes);
-int pwn_hip_device_free(pwn_hip_ctx* ctx, void* ptr);
+int pwn_hip_device_free(pwn_hip_ctx* ctx, void* ptr);      /* waits for the context's queued work first; ctx may be NULL once the context that
+                                                             * allocated the buffer has been destroyed (the buffer is then simply released) */
 int pwn_hip_copy(pwn_hip_ctx* ctx, void* dst, const void* src, size_t bytes);
 /* The same copy queued on the context's copy stream; returns at once (for page-locked host memory -- pageable memory makes it wait).  The
- * next call on the context that reads frames (convert*, unproject, the depth-image helpers, pwn_hip_copy, ctx_synchronize, device_free)
- * runs after every copy issued so far; aligner calls do not wait.  Pattern: upload the frames of batch k+1 into a second set of device
+ * next call on the context that reads data through a caller-supplied pointer -- convert*, unproject, project_intervals, the depth-image
+ * helpers, cloud_gaussians, cloud_upload, integral_image, correspondences, linearize -- and pwn_hip_copy, ctx_synchronize, device_free
+ * run after every copy issued so far.  The calls that take cloud handles only (align*, match*, project, merge, voxelize, cloud_add,
+ * cloud_download*) do NOT wait: that is what lets a transfer overlap an alignment.  Pattern: upload the frames of batch k+1 into a second set of device
  * buffers, align batch k meanwhile, convert batch k+1 -- the transfers disappear behind the alignment.  The caller keeps source and
  * destination untouched until one of those calls has returned. */
 int pwn_hip_copy_async(pwn_hip_ctx* ctx, void* dst, const void* src, size_t bytes);
@@ -348,11 +351,6 @@ int pwn_hip_last_stage_ms(pwn_hip_ctx* ctx, const char* stage, float* ms, int* l
  * float4 streaming read and device-to-device copy of `bytes` (use >= 1 GiB: the Infinity Cache holds 256 MiB), best of 5,
  * GB/s; the copy counts bytes read + written.  Allocates and frees 2 x bytes. */
 int pwn_hip_measure_hbm(pwn_hip_ctx* ctx, size_t bytes, float* read_gbps, float* copy_gbps);
-/* TEST HOOK.  The converter's integral-image kernels hand the running sums of a strip to the strip on its right through tagged words,
- * polled with a bound: a word that never arrives raises a fault flag and the convert call returns PWN_HIP_ERR_LAUNCH ("strip hand-over
- * timed out") instead of hanging the device.  This call makes that happen on purpose: the word (strip, band, chain) of every frame of
- * rows x * images is withheld and the poll bound is lowered to spin_limit polls (0 = the default).  strip < 0 switches the hook off. */
-int pwn_hip_debug_withhold_carry(pwn_hip_ctx* ctx, int strip, int band, int chain, int rows, int spin_limit);
 /* enable/disable hipEvent timing around every kernel launch (adds host overhead; default off) */
 int pwn_hip_set_profiling(pwn_hip_ctx* ctx, int enabled);
 

@@ -1,0 +1,21 @@
+/* pwn_hip_testing.h -- entry points that exist for the test suite only.  NOT part of the drop-in boundary (include/pwn_hip.h): a
+ * reference-side binding never calls them.  They are exported by the same library so that the tests exercise the product build. */
+#ifndef PWN_HIP_TESTING_H
+#define PWN_HIP_TESTING_H
+#include "pwn_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* The converter's integral-image kernels hand the running sums of a strip to the strip on its right through tagged words,
+ * polled with a bound: a word that never arrives raises a fault flag and the convert call returns PWN_HIP_ERR_LAUNCH ("strip hand-over
+ * timed out") instead of hanging the device.  This call makes that happen on purpose: the word (strip, band, chain) of every frame of
+ * rows x * images is withheld and the poll bound is lowered to spin_limit polls (0 = the default).  strip < 0 switches the hook off.
+ * While the hook is on every convert call of the context fails; the word index is the same in both kernels that hand over
+ * (k_unproject_integral, k_unproject_integral_rows: 10 planes x band rows chains per (strip, band)). */
+int pwn_hip_debug_withhold_carry(pwn_hip_ctx* ctx, int strip, int band, int chain, int rows, int spin_limit);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
