@@ -58,8 +58,6 @@ struct pwn_hip_ctx {
   hipEvent_t fork_ev = nullptr, join_ev = nullptr, join_extra[2] = { nullptr, nullptr };
   hipStream_t copy_stream = nullptr;       // host frames of a batch call are copied on their own stream, one sub-batch ahead of the kernels
   std::vector<hipEvent_t> sync_events;     // ordering events of that hand-over (copied[k], converted[k]); grown on demand
-  std::vector<hipEvent_t> stagger_events;  // front_done[k] of a converter batch call: sub-batch k+1's front end starts when sub-batch k's has finished (convert_batch_impl)
-  int convert_stagger = 1;                 // PWN_CONVERT_STAGGER=0 switches the staggered schedule off (A/B)
   hipEvent_t copy_ev = nullptr;            // pwn_hip_copy_async: the next call that reads frames waits for the copies issued so far
   bool copy_pending = false;
   int max_rows = 0, max_cols = 0, max_batch = 0;
@@ -72,6 +70,12 @@ struct pwn_hip_ctx {
   uint16_t* raw_ws = nullptr;
   unsigned long long* carry_ws = nullptr; size_t carry_slot = 0; size_t rowoff_slot = 0;   // single-pass integral image: hand-over words, strip offsets
   unsigned convert_epoch = 0; int* fault_dev = nullptr;
+  unsigned long long* fsync_ws = nullptr; size_t fsync_slot = 0;      // k_convert_fused: progress words of a frame slot (FrameDesc::fsync)
+  int last_convert_fault = 0;              // fault word of the last converter launch (1 = a bounded poll timed out, 2 = workgroup placement)
+  int fused_convert = 0;                   // PWN_FUSED_CONVERT=1: k_convert_fused (planes in a ring, never in HBM) for launches of >= PWN_SINGLE_PASS_MIN_FRAMES
+                                           // frames in lean mode.  Bit-identical to the two-kernel path and SLOWER on MI355X (6.0 against 3.4 ms per 256 VGA
+                                           // frames: see k_convert_fused), so it is off unless asked for; switched off for the context when a launch
+                                           // reports that its workgroups were not placed as the kernel needs
   int spin_limit = kSpinLimit; int dbg_withhold = -1;        // pwn_hip_debug_withhold_carry (test hook)
   // align workspaces (per slot)
   unsigned long long* zref_ws = nullptr;        // 64-bit z-buffer of the stand-alone projection and of Merger::merge (one image)
@@ -389,14 +393,13 @@ int ensure_desc(pwn_hip_ctx* ctx, int n) {
 }
 
 // launch sequence of the converter for the frames [base, base+n) of the uploaded descriptor array
-// front_wait / front_done (optional): the front end (strip counts + k_unproject_integral) starts after `front_wait` and records `front_done`
-// when it has finished -- the staggered schedule of convert_batch_impl
-int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, hipStream_t st, hipEvent_t front_wait = nullptr, hipEvent_t front_done = nullptr) {
-  if (front_wait) HIPCHK(ctx, hipStreamWaitEvent(st, front_wait, 0), PWN_HIP_ERR_LAUNCH);
-  const FrameDesc* fr = ctx->frames_dev + base;
+int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, hipStream_t st) {
 #ifndef PWN_SINGLE_PASS_MIN_FRAMES
 #define PWN_SINGLE_PASS_MIN_FRAMES 16     // measured on MI355X at VGA (tools/ab_convert_n.py), three kernels vs single pass: 8 frames 0.20 vs 0.27 ms, 16 frames 0.38 vs 0.35, 32 frames 0.74 vs 0.58
 #endif
+  // the fused kernel serves the lean mode (no interval image, no point stores by the front end); the planes are never complete in memory
+  const bool use_fused = ctx->fused_convert && cp.lean && n >= PWN_SINGLE_PASS_MIN_FRAMES;
+  const FrameDesc* fr = ctx->frames_dev + base;
   if (n >= PWN_SINGLE_PASS_MIN_FRAMES) {
     // throughput path: the integral planes are written once; a frame is a chain of strips * bands hand-over steps, so it
     // needs several frames in flight to fill the device
@@ -412,6 +415,16 @@ int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, h
       else if (aligned) hipLaunchKernelGGL(k_strip_count<false>, dim3((cp.rows + 3) / 4, n), dim3(256), 0, st, fr, cp);
       else hipLaunchKernelGGL(k_strip_count_any, dim3(cp.rows, n), dim3(256), 0, st, fr, cp);
       hipLaunchKernelGGL(k_row_offsets, dim3(n), dim3(1024), 0, st, fr, cp.rows * strips_of(cp.cols)); }
+    if (use_fused) {
+      // one launch for the rest of the converter: producers (front end) and consumers (stats pass) of a frame side by side, planes in a ring
+      StageTimer t(ctx, "convert_fused", st);
+      const unsigned epoch = ++ctx->convert_epoch;
+      if (epoch == 0) return fail(ctx, PWN_HIP_ERR_LAUNCH, "convert epoch wrapped: recreate the context");
+      hipLaunchKernelGGL(k_convert_fused, dim3(8u * (unsigned)((n + 7) / 8) * (unsigned)(1 + kConsWG) * (unsigned)strips_of(cp.cols)), dim3(kII_Threads), 0, st, fr, cp, n,
+                         epoch, ctx->fault_dev);
+      HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
+      return PWN_HIP_OK;
+    }
     { StageTimer t(ctx, "integral", st);           // unProject + intervals + the three integral-image passes
       const unsigned epoch = ++ctx->convert_epoch;
       if (epoch == 0) return fail(ctx, PWN_HIP_ERR_LAUNCH, "convert epoch wrapped: recreate the context");
@@ -430,7 +443,6 @@ int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, h
     { StageTimer t(ctx, "integral_cols", st);
       hipLaunchKernelGGL(k_integral_cols, dim3((cp.cols + kIC_Block - 1) / kIC_Block, kIntegralChannels, n), dim3(kIC_Block), 0, st, fr, cp.rows, cp.cols); }
   }
-  if (front_done) HIPCHK(ctx, hipEventRecord(front_done, st), PWN_HIP_ERR_LAUNCH);
   { StageTimer t(ctx, "stats", st);
     const unsigned perFrame = (unsigned)cp.rows * (unsigned)((cp.cols + 255) / 256);
     const unsigned nblk = (n >= 8 ? 8u * (unsigned)((n + 7) / 8) : (unsigned)n) * perFrame;      // see k_stats: XCD-aware placement from 8 frames on
@@ -452,6 +464,7 @@ void fill_frame(pwn_hip_ctx* ctx, int entry, int slot, const float* depth_dev, c
   (void)rows;
   f.rowoff = ctx->rowoff_ws + (size_t)slot * ctx->rowoff_slot;
   f.carry = ctx->carry_ws + (size_t)slot * ctx->carry_slot;
+  f.fsync = ctx->fsync_ws + (size_t)slot * ctx->fsync_slot;
   f.cloud = cl;
 }
 int ensure_stats(pwn_hip_ctx* ctx, pwn_hip_cloud* c) {
@@ -467,9 +480,13 @@ int sync_and_counts(pwn_hip_ctx* ctx, pwn_hip_cloud* const* clouds, int n) {
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
   collect_stage_times(ctx);
   if (n > 0 && ctx->counts_host[n] != 0) {
+    const int code = ctx->counts_host[n];
     (void)hipMemset(ctx->fault_dev, 0, sizeof(int));
+    ctx->last_convert_fault = code;
+    if (code & 2) return fail(ctx, PWN_HIP_ERR_LAUNCH, "fused converter: the workgroups of a frame were not placed on one XCD (results invalid)");
     return fail(ctx, PWN_HIP_ERR_LAUNCH, "integral image: strip hand-over timed out (results invalid)");
   }
+  ctx->last_convert_fault = 0;
   for (int i = 0; i < n; ++i) {
     if (ctx->counts_host[i] > clouds[i]->d.capacity) return fail(ctx, PWN_HIP_ERR_CAPACITY, "cloud capacity smaller than the number of valid depth pixels");
     clouds[i]->n_host = ctx->counts_host[i];
@@ -548,13 +565,6 @@ int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, cons
     }
     HIPCHK(ctx, hipStreamWaitEvent(ctx->copy_stream, ctx->fork_ev, 0), PWN_HIP_ERR_LAUNCH);      // after everything queued before this call
   }
-  const bool stagger = plan.dual() && ctx->convert_stagger && nsub > 1 && !ctx->profiling;
-  if (stagger)
-    while ((int)ctx->stagger_events.size() < nsub) {
-      hipEvent_t e = nullptr;
-      HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming), PWN_HIP_ERR_ALLOCATION);
-      ctx->stagger_events.push_back(e);
-    }
   for (int base = 0, k = 0; base < n; base += sub, ++k) {
     const int m = std::min(sub, n - base);
     hipStream_t st = plan.stream(k);
@@ -578,17 +588,18 @@ int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, cons
         HIPCHK(ctx, hipStreamWaitEvent(st, ctx->sync_events[2 * k], 0), PWN_HIP_ERR_LAUNCH);
       }
     }
-    // Staggered schedule (two or more streams): the front end of sub-batch k+1 starts when the front end of sub-batch k has finished, so it
-    // runs NEXT TO k_stats of sub-batch k instead of next to the other stream's front end.  The two kernels want different things from a CU
-    // -- the front end is a chain of dependent LDS steps and hand-over waits that leaves the vector ALUs and most of the memory system idle,
-    // k_stats is gathers + arithmetic + streamed stores -- and overlap far better with each other than each does with itself.
-    hipEvent_t fw = nullptr, fd = nullptr;
-    if (stagger) { fw = k > 0 ? ctx->stagger_events[k - 1] : nullptr; fd = ctx->stagger_events[k]; }
-    if (int rc = launch_convert(ctx, cp, base, m, st, fw, fd)) return rc;
+    if (int rc = launch_convert(ctx, cp, base, m, st)) return rc;
     if (ahead) HIPCHK(ctx, hipEventRecord(ctx->sync_events[2 * k + 1], st), PWN_HIP_ERR_LAUNCH);
   }
   if (int rc = plan_join(ctx, plan)) return rc;
-  return sync_and_counts(ctx, clouds, n);
+  const int rc = sync_and_counts(ctx, clouds, n);
+  if (rc != PWN_HIP_OK && (ctx->last_convert_fault & 2) && ctx->fused_convert) {
+    // the fused kernel found its workgroups on different XCDs (the round-robin placement it is built on did not hold on this device /
+    // partition mode): never use it again on this context and convert the batch again with the two-kernel path
+    ctx->fused_convert = 0;
+    return convert_batch_impl<SRC>(ctx, p, frames, depth_scale, n, rows, cols, clouds, keep_stats, want_interval);
+  }
+  return rc;
 }
 
 }  // namespace
@@ -695,7 +706,7 @@ int pwn_hip_ctx_create(pwn_hip_ctx** out, int device, int max_rows, int max_cols
   pwn_hip_ctx* ctx = new pwn_hip_ctx();
   ctx->device = device; ctx->max_rows = max_rows; ctx->max_cols = max_cols; ctx->max_batch = max_batch;
   ctx->N = (size_t)max_rows * max_cols;
-  if (const char* e = std::getenv("PWN_CONVERT_STAGGER")) ctx->convert_stagger = std::atoi(e);      // A/B switch of the converter's staggered schedule
+  if (const char* e = std::getenv("PWN_FUSED_CONVERT")) ctx->fused_convert = std::atoi(e);          // 1 = k_convert_fused instead of k_unproject_integral + k_stats
   { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->num_cus = cus; }
   const size_t N = ctx->N, B = (size_t)max_batch;
   ctx->nblocks_max = align_nblocks((int)N);
@@ -717,11 +728,14 @@ int pwn_hip_ctx_create(pwn_hip_ctx** out, int device, int max_rows, int max_cols
     const size_t M = (size_t)std::max(max_rows, max_cols);
     ctx->rowoff_slot = N / 64 + M + 64;
     ctx->carry_slot = (N / ((size_t)kIR_Cols * kIR_Rows) + M / kIR_Cols + M / kIR_Rows + 2) * (size_t)kII_Chains;
+    ctx->fsync_slot = (1 + 4 * kConsWG) * (M / kIR_Cols + 1) + 2;      // prod[strips], cons[strips][4 kConsWG], XCC id
   }
   ALLOC(ctx->rowoff_ws, B * ctx->rowoff_slot * sizeof(int));
   ALLOC(ctx->carry_ws, B * ctx->carry_slot * sizeof(unsigned long long));
   ALLOC(ctx->fault_dev, sizeof(int));
-  if (hipMemset(ctx->carry_ws, 0, B * ctx->carry_slot * sizeof(unsigned long long)) != hipSuccess || hipMemset(ctx->fault_dev, 0, sizeof(int)) != hipSuccess) {
+  ALLOC(ctx->fsync_ws, B * ctx->fsync_slot * sizeof(unsigned long long));
+  if (hipMemset(ctx->carry_ws, 0, B * ctx->carry_slot * sizeof(unsigned long long)) != hipSuccess || hipMemset(ctx->fault_dev, 0, sizeof(int)) != hipSuccess ||
+      hipMemset(ctx->fsync_ws, 0, B * ctx->fsync_slot * sizeof(unsigned long long)) != hipSuccess) {
     pwn_hip_ctx_destroy(ctx); return fail(nullptr, PWN_HIP_ERR_ALLOCATION, "hipMemset of the hand-over workspace failed"); }
   ALLOC(ctx->zref_ws, N * sizeof(unsigned long long));
   ALLOC(ctx->z32ref_ws, B * N * sizeof(unsigned));
@@ -745,7 +759,7 @@ int pwn_hip_ctx_destroy(pwn_hip_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);      // pwn_hip_copy_async transfers still in flight
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  void* dev[] = { ctx->depth_ws, ctx->raw_ws, ctx->index_ws, ctx->interval_ws, ctx->integral_ws, ctx->rowoff_ws, ctx->carry_ws, ctx->fault_dev, ctx->zref_ws, ctx->z32ref_ws, ctx->z32cur_ws, ctx->curidx_ws,
+  void* dev[] = { ctx->depth_ws, ctx->raw_ws, ctx->index_ws, ctx->interval_ws, ctx->integral_ws, ctx->rowoff_ws, ctx->carry_ws, ctx->fsync_ws, ctx->fault_dev, ctx->zref_ws, ctx->z32ref_ws, ctx->z32cur_ws, ctx->curidx_ws,
                   ctx->partials_ws, ctx->state_ws, ctx->frames_dev, ctx->pairs_dev, ctx->raw_dev, ctx->counts_dev, ctx->solve_dev, ctx->counters_dev,
                   ctx->corr_ws, ctx->scratch_count, ctx->io_ws };
   for (void* p : dev) if (p) (void)hipFree(p);
@@ -770,8 +784,6 @@ int pwn_hip_ctx_destroy(pwn_hip_ctx* ctx) {
   if (ctx->copy_ev) (void)hipEventDestroy(ctx->copy_ev);
   for (hipEvent_t e : ctx->sync_events) (void)hipEventDestroy(e);
   ctx->sync_events.clear();
-  for (hipEvent_t e : ctx->stagger_events) (void)hipEventDestroy(e);
-  ctx->stagger_events.clear();
   if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
   if (ctx->join_ev) (void)hipEventDestroy(ctx->join_ev);
   delete ctx;

@@ -93,6 +93,7 @@ struct FrameDesc {
   float* integral;   // [10][rows*cols]
   int* rowoff;       // [rows] (stand-alone unProject) or [rows][strips] (converter fast path)
   unsigned long long* carry; // [strips][bands][160] strip-to-strip hand-over words of k_unproject_integral
+  unsigned long long* fsync; // k_convert_fused: [strips] bands stored by the producers, [strips][4 kConsWG] bands finished by the consumer waves, [1] XCC id; each = launch epoch << 32 | value
   CloudDev cloud;
 };
 
@@ -519,7 +520,7 @@ __global__ void __launch_bounds__(256) k_unproject_integral_rows(const FrameDesc
       unsigned long long w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       int spins = 0;
       while ((unsigned)(w >> 32) != epoch) {
-        if (++spins >= cp.spinLimit) { atomicExch(fault, 1); break; }    // a starved chain finishes with garbage instead of hanging the device
+        if (++spins >= cp.spinLimit) { atomicOr(fault, 1); break; }    // a starved chain finishes with garbage instead of hanging the device
         __builtin_amdgcn_s_sleep(1);
         w = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
@@ -643,20 +644,41 @@ __device__ __forceinline__ void lds_barrier() {
 // wait for memory at all.  The loader wave therefore does every global read of the block (depth and strip offsets of the NEXT
 // band, hand-over words of the current one) and passes the values on through LDS; it never stores to global memory.
 #ifndef PWN_II_X
-#define PWN_II_X 0   // timing experiments only: 1 = no plane stores, 2 = no point/index/interval stores, 4 = no hand-over wait
+#define PWN_II_X 0   // timing experiments only: 1 = no plane stores, 2 = no point/index/interval stores, 4 = no hand-over wait, 8 = planes stored into a 128-row ring
 #endif
 #ifndef PWN_II_NT
 #define PWN_II_NT 3  // 1 = non-temporal plane stores, 2 = non-temporal index/interval stores, 3 = both (measured: strip kernel -5 %, k_stats after it -4 %)
 #endif
 constexpr int kII_Threads = 320;
-__global__ void __launch_bounds__(kII_Threads) k_unproject_integral(const FrameDesc* __restrict__ frames, ConvertParams cp, int nframes,
-                                                                    unsigned epoch, int* __restrict__ fault) {
+#ifndef PWN_CONS_WG
+#define PWN_CONS_WG 2                // k_convert_fused: consumer workgroups per strip (each takes every PWN_CONS_WG-th row pair of a band)
+#endif
+#ifndef PWN_FUSED_X
+#define PWN_FUSED_X 0                // timing experiments only (results wrong): 1 = consumers do nothing, 2 = consumers wait and load but skip the arithmetic
+#endif
+constexpr int kConsWG = PWN_CONS_WG;
+static_assert(kConsWG == 1 || kConsWG == 2, "consumer workgroups per strip");
+constexpr int kRingRows = 128;       // k_convert_fused: rows of a frame's plane ring -- a power of two, a multiple of the band height, >= the window reach
+                                     // (31 rows back, 29 ahead) + the bands a producer may run ahead of the consumers that still read the old rows
+static_assert(kRingRows % kIR_Rows == 0 && (kRingRows & (kRingRows - 1)) == 0, "ring rows");
+// bounded poll of a tagged progress word (launch epoch << 32 | count) until count >= need; false = timed out (the caller raises the fault flag)
+__device__ __forceinline__ bool wait_progress(gptr<unsigned long long> w, unsigned epoch, unsigned need, int spinLimit) {
+  unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  int spins = 0;
+  while ((unsigned)(v >> 32) != epoch || (unsigned)v < need) {
+    if (++spins >= spinLimit) return false;
+    __builtin_amdgcn_s_sleep(2);
+    v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return true;
+}
+// Body of the single-pass front end for strip s of frame f.  FUSED = false: k_unproject_integral (planes [10][rows][cols], read back by
+// k_stats).  FUSED = true: the producer side of k_convert_fused -- the planes are a ring of kRingRows rows that the consumer workgroups of
+// the same launch read while it is being written (see k_convert_fused for the protocol).
+template <bool FUSED>
+__device__ __forceinline__ void unproject_integral_body(const FrameDesc& f, const ConvertParams& cp, const int s, const unsigned epoch, int* __restrict__ fault) {
   const int rows = cp.rows, cols = cp.cols;
   const int S = strips_of(cols), NB = bands_of(rows);
-  const unsigned j = blockIdx.x >> 3;
-  const int fi = 8 * (int)(j / (unsigned)S) + (int)(blockIdx.x & 7u), s = (int)(j % (unsigned)S);
-  if (fi >= nframes) return;
-  const FrameDesc& f = frames[fi];
   __shared__ float tile[kIntegralChannels * kIR_Rows * kIR_Stride];
   __shared__ float stage[2][kIR_Rows * kIR_Cols];     // depth of the band (metres; 0 outside the image), double-buffered
   __shared__ int sbase[2][kIR_Rows];                  // point-index offset of (row, strip)
@@ -732,13 +754,22 @@ __global__ void __launch_bounds__(kII_Threads) k_unproject_integral(const FrameD
             unsigned long long w = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             int spins = 0;
             while ((unsigned)(w >> 32) != epoch && !starved) {    // after one time-out this lane stops waiting: the launch is lost anyway
-              if (++spins >= cp.spinLimit) { atomicExch(fault, 1); starved = true; break; }
+              if (++spins >= cp.spinLimit) { atomicOr(fault, 1); starved = true; break; }
               __builtin_amdgcn_s_sleep(1);
               w = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
             cin[k] = __uint_as_float((unsigned)w);
           }
         }
+      }
+      if (FUSED && band >= kRingRows / kIR_Rows - 4 && !starved) {
+        // ring back-pressure: band `band` overwrites the slots of rows [8 band - kRingRows, +7]; the consumers of this strip and of its two
+        // neighbours that read those rows (bands <= band - (kRingRows - 32) / 8) must have finished.  Consumers normally trail the producers
+        // by 5-7 bands, so this wait is not taken in a healthy pipeline.
+        const unsigned need = (unsigned)(band - (kRingRows - 32) / kIR_Rows + 1);
+        const int sp = s - 1 + lane / (4 * kConsWG);            // lanes 0 .. 3 * 4 kConsWG - 1: the words of the consumer waves of strips s-1, s, s+1
+        if (!(PWN_FUSED_X & 1) && lane < 3 * 4 * kConsWG && sp >= 0 && sp < S &&
+            !wait_progress(as_global(f.fsync) + S + sp * (4 * kConsWG) + lane % (4 * kConsWG), epoch, need, cp.spinLimit)) { atomicOr(fault, 1); starved = true; }
       }
       stage_band(band + 1);
     } else {
@@ -806,6 +837,8 @@ __global__ void __launch_bounds__(kII_Threads) k_unproject_integral(const FrameD
     }
     lds_barrier();
     // 3. y pass, chain q = (channel = q / 64, column = q % 64)
+    if (FUSED && !loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the plane stores of the PREVIOUS band (issued a band ago) have landed in L2:
+                                                                               // what the progress word published below promises
     if (!loader) {
 #pragma unroll
       for (int jj = 0; jj < 3; ++jj) {
@@ -820,7 +853,7 @@ __global__ void __launch_bounds__(kII_Threads) k_unproject_integral(const FrameD
           for (int r = 0; r < kIR_Rows; ++r) { vc = vals[r] + vc; vals[r] = vc; }
           vcarry[jj] = vc;
           if (c < cols && (!(PWN_II_X & 1) || vc == 12345.678f)) {
-            const gptr<float> dst = gintegral + ((size_t)ch * N + (size_t)r0 * cols + c);
+            const gptr<float> dst = gintegral + ((size_t)ch * N + (size_t)((FUSED || (PWN_II_X & 8)) ? (r0 & (kRingRows - 1)) : r0) * cols + c);      // PWN_II_X & 8: timing experiment, planes as a ring
 #pragma unroll
             for (int r = 0; r < kIR_Rows; ++r) if (r0 + r < rows) {
               if (PWN_II_NT & 1) __builtin_nontemporal_store(vals[r], dst + (unsigned)(r * cols));
@@ -831,7 +864,24 @@ __global__ void __launch_bounds__(kII_Threads) k_unproject_integral(const FrameD
       }
     }
     lds_barrier();
+    // every compute wave has passed its drain of this band: the planes of bands < band are complete in L2
+    if (FUSED && tid == 0)
+      __hip_atomic_store(as_global(f.fsync) + s, ((unsigned long long)epoch << 32) | (unsigned long long)(unsigned)band, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
+  if (FUSED) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0)
+      __hip_atomic_store(as_global(f.fsync) + s, ((unsigned long long)epoch << 32) | (unsigned long long)(unsigned)NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__global__ void __launch_bounds__(kII_Threads) k_unproject_integral(const FrameDesc* __restrict__ frames, ConvertParams cp, int nframes,
+                                                                    unsigned epoch, int* __restrict__ fault) {
+  const int S = strips_of(cp.cols);
+  const unsigned j = blockIdx.x >> 3;
+  const int fi = 8 * (int)(j / (unsigned)S) + (int)(blockIdx.x & 7u), s = (int)(j % (unsigned)S);
+  if (fi >= nframes) return;
+  unproject_integral_body<false>(frames[fi], cp, s, epoch, fault);
 }
 // pass 3 (pwn_core/pointintegralimage.cpp:38-43): prefix-sum along image y inside each image column, sequential.
 // one thread per (column, channel) chain, lanes along x.  grid = (ceil(cols/64), 10, frames), block = 64: this kernel only runs on the
@@ -905,25 +955,25 @@ __device__ __forceinline__ void stream_store3(gptr<float> p, v3f_raw v) {
 
 #ifndef PWN_ST_X
 #define PWN_ST_X 0   // timing experiments only (results wrong): 1 = no cloud stores, 2 = no arithmetic between the corner loads and the stores
-                     // (memory traffic alone), 4 = no integral-plane loads (the corner sums come from registers: arithmetic + stores alone)
+                     // (memory traffic alone), 4 = no integral-plane loads (the corner sums come from registers: arithmetic + stores alone),
+                     // 8 = plane rows taken modulo 128 (the gathers of a ring that stays in the XCD's L2)
 #endif
-__global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ frames, ConvertParams cp, int nframes) {
-  const int nxb = (cp.cols + 255) / 256;
-  const int perFrame = nxb * cp.rows;
-  int frame, rem;
-  if (nframes >= 8) {
-    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-    frame = (k / perFrame) * 8 + xcd;
-    rem = k % perFrame;
-  } else {                                   // fewer frames than XCDs (tracker, makeCloud): a frame per XCD would idle the others; grid = nframes * perFrame
-    frame = blockIdx.x / perFrame;
-    rem = blockIdx.x % perFrame;
-  }
-  if (frame >= nframes) return;
-  const FrameDesc& f = frames[frame];
-  const int r = rem / nxb;
-  const int c = (rem % nxb) * 256 + threadIdx.x;
-  if (c >= cp.cols) return;
+// One pixel of the stats pass (everything after the thread has found its pixel).  RING = false: k_stats (planes [10][rows][cols], point index
+// from the index image).  RING = true: the consumer side of k_convert_fused (planes are a ring of kRingRows rows, index and depth handed in).
+#ifndef PWN_RING_LOAD
+#define PWN_RING_LOAD 1      // 0 = nt, 1 = sc1 (agent-scope relaxed atomic load), 2 = plain (timing only: may read stale L1 lines)
+#endif
+__device__ __forceinline__ float ring_load(gptr<const float> p) {
+#if PWN_RING_LOAD == 0
+  return __builtin_nontemporal_load(p);
+#elif PWN_RING_LOAD == 1
+  return __uint_as_float(__hip_atomic_load((gptr<const unsigned>)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#else
+  return *p;
+#endif
+}
+template <bool RING>
+__device__ __forceinline__ void stats_pixel(const FrameDesc& f, const ConvertParams& cp, const int r, const int c, const int idx_in, const float d_in) {
   const int rows = cp.rows, cols = cp.cols;
   const size_t N = (size_t)rows * cols;
   // descriptor pointers are generic to the compiler; they all point to hipMalloc'ed memory: global_* instructions with a scalar
@@ -933,14 +983,15 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
   const gptr<float> gP = as_global(f.cloud.P3), gN = as_global((float*)f.cloud.Nc), gOm = as_global(f.cloud.Om);
   const int cap = f.cloud.capacity;
   const unsigned upix = (unsigned)(r * cols + c);
-  const int idx = stream_load(gindex + upix);
+  const int idx = RING ? idx_in : stream_load(gindex + upix);      // RING: the caller ranked the pixel itself (row / strip offset + ballot)
   if (idx < 0 || idx >= cap) return;
   int itv;
   float4 P;
-  if (cp.lean) {
+  if (RING || cp.lean) {
     // the front end kept the point and the interval to itself: the same expressions on the same depth (pinholepointprojector.h:246-251,264-274)
     float d;
-    if (f.raw) { const unsigned sv = stream_load(as_global(f.raw) + upix); d = sv ? f.raw_scale * (float)sv : 0.0f; }
+    if (RING) d = d_in;
+    else if (f.raw) { const unsigned sv = stream_load(as_global(f.raw) + upix); d = sv ? f.raw_scale * (float)sv : 0.0f; }
     else d = stream_load(as_global(f.depth) + upix);
     const float a = (float)c * d, b = (float)r * d;
     P.x = dot4seq(cp.iKRt(0,0), a, cp.iKRt(0,1), b, cp.iKRt(0,2), d, cp.iKRt(0,3), 1.0f);
@@ -971,8 +1022,10 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
     // PointIntegralImage::getRegion (pointintegralimage.cpp:53-66)
     const int xmin = clampi(c - rad - 1, 0, cols - 1), xmax = clampi(c + rad - 1, 0, cols - 1);
     const int ymin = clampi(r - rad - 1, 0, rows - 1), ymax = clampi(r + rad - 1, 0, rows - 1);
-    const unsigned oA = (unsigned)(ymax * cols + xmax), oB = (unsigned)(ymin * cols + xmin);
-    const unsigned oC = (unsigned)(ymax * cols + xmin), oD = (unsigned)(ymin * cols + xmax);
+    // RING (fused converter): the planes are a ring of kRingRows image rows per frame, row y at slot y & (kRingRows - 1)
+    const int ya = (RING || (PWN_ST_X & 8)) ? (ymax & (kRingRows - 1)) : ymax, yb = (RING || (PWN_ST_X & 8)) ? (ymin & (kRingRows - 1)) : ymin;
+    const unsigned oA = (unsigned)(ya * cols + xmax), oB = (unsigned)(yb * cols + xmin);
+    const unsigned oC = (unsigned)(ya * cols + xmin), oD = (unsigned)(yb * cols + xmax);
     float a[kIntegralChannels];
 #if PWN_ST_X & 4
     {   // timing experiment: a plausible window (a few thousand points around the pixel's own point) without touching the planes
@@ -986,10 +1039,21 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
 #pragma unroll
     for (int k = 0; k < kIntegralChannels; ++k) {
       const gptr<const char> pl = (gptr<const char>)(gintegral + (size_t)k * N);      // plane base: scalar; lane offsets: 32-bit bytes
-      float v = *(gptr<const float>)(pl + 4u * oA);
-      v = v + *(gptr<const float>)(pl + 4u * oB);
-      v = v - *(gptr<const float>)(pl + 4u * oC);
-      v = v - *(gptr<const float>)(pl + 4u * oD);
+      float v;
+      if (RING) {
+        // ring slots are rewritten while the kernel runs and a CU's L1 is never refreshed by other CUs' stores: every load is an sc1 load
+        // (L2-served, L1 bypassed).  NOT a non-temporal load: nt lines are not kept in L2, and every ring line is read by ~40 pixels --
+        // measured 7.8 ms per 256 VGA frames with nt loads against 6.0 with sc1 (tools/ab_fused.sh).
+        v = ring_load((gptr<const float>)(pl + 4u * oA));
+        v = v + ring_load((gptr<const float>)(pl + 4u * oB));
+        v = v - ring_load((gptr<const float>)(pl + 4u * oC));
+        v = v - ring_load((gptr<const float>)(pl + 4u * oD));
+      } else {
+        v = *(gptr<const float>)(pl + 4u * oA);
+        v = v + *(gptr<const float>)(pl + 4u * oB);
+        v = v - *(gptr<const float>)(pl + 4u * oC);
+        v = v - *(gptr<const float>)(pl + 4u * oD);
+      }
       a[k] = v;
     }
 #endif
@@ -1104,6 +1168,146 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
     v3f_raw rw; rw.x = om[3 * r3]; rw.y = om[3 * r3 + 1]; rw.z = om[3 * r3 + 2];
     stream_store3(gOm + (size_t)r3 * 3u * (size_t)cap + 3u * (unsigned)idx, rw);
   }
+}
+
+__global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ frames, ConvertParams cp, int nframes) {
+  const int nxb = (cp.cols + 255) / 256;
+  const int perFrame = nxb * cp.rows;
+  int frame, rem;
+  if (nframes >= 8) {
+    const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+#if PWN_ST_X & 16     /* timing experiment: the frames of an XCD advance together, row by row (what consumers of a 64-frame producer launch would do) */
+    const int fpx = (nframes + 7) / 8;              // frames per XCD
+    frame = (k % fpx) * 8 + xcd;
+    rem = k / fpx;
+#else
+    frame = (k / perFrame) * 8 + xcd;
+    rem = k % perFrame;
+#endif
+  } else {                                   // fewer frames than XCDs (tracker, makeCloud): a frame per XCD would idle the others; grid = nframes * perFrame
+    frame = blockIdx.x / perFrame;
+    rem = blockIdx.x % perFrame;
+  }
+  if (frame >= nframes) return;
+  const FrameDesc& f = frames[frame];
+  const int r = rem / nxb;
+  const int c = (rem % nxb) * 256 + threadIdx.x;
+  if (c >= cp.cols) return;
+  stats_pixel<false>(f, cp, r, c, 0, 0.f);
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Fused converter (throughput path, lean mode): DepthImageConverterIntegralImage::compute (depthimageconverterintegralimage.cpp:15-55) as ONE
+// launch in which the integral planes never travel to HBM and back.  Per frame there are S producer workgroups (the single-pass front end,
+// unproject_integral_body<true>: strip s walks its 64 columns top to bottom in 8-row bands) and S consumer workgroups (the stats pass of the
+// same 64 columns, stats_pixel<true>, trailing the producers).  The ten planes are a RING of kRingRows image rows per frame (row y at slot
+// y mod kRingRows): a row is written once, read by the consumers of its own strip and of the two neighbouring strips (the window reaches 31
+// columns / rows back and 29 ahead) while it is still in the XCD's L2 / the Infinity Cache, and overwritten 128 rows later.  Against the
+// two-kernel form (k_unproject_integral + k_stats) that removes 40 bytes per pixel written to HBM and 40 read back, and the two halves --
+// a chain of dependent LDS steps that leaves the vector ALUs idle, and gathers + arithmetic + streamed stores -- share the CUs.
+//
+// Protocol (all words are launch epoch << 32 | value, so nothing is ever cleared; relaxed agent-scope atomics):
+//   prod[s] = bands of strip s whose plane stores have landed in L2 (every storing wave drains its stores -- s_waitcnt vmcnt(0) one band
+//             later, when they have long completed -- then a workgroup barrier, then one lane publishes);
+//   cons[s][m] = bands consumer wave m of strip s has finished (its ring loads have returned: their values were used), updated every 2nd band.
+//   consumer of band b: waits prod[s-1], prod[s], prod[s+1] >= min(NB, b + 5)        (rows up to 8 b + 36 are stored); it polls only when it
+//                       has caught up with the counts it read last -- producers run ahead, so most bands start without a poll;
+//   producer of band b >= 12: waits cons[s-1..s+1][*] >= b - 11                      (nobody still needs the rows its stores overwrite).
+//   Consumers load the ring with L1-bypassing (nt) loads: a CU's L1 is never refreshed by other CUs' stores and ring addresses are reused.
+// Forward progress: the 2 S workgroups of a frame are consecutive in dispatch order on one XCD (ids are dealt round-robin over the XCDs);
+// a workgroup waits only for workgroups of its own frame, so the lowest unfinished frame of every XCD is resident as a whole and completes
+// -- the same in-order-dispatch assumption as the strip hand-over, with the same safety net: every poll is bounded and raises *fault
+// (1 = time-out) instead of hanging.  Producers and consumers of a frame must share an L2: every workgroup checks its XCC id against the
+// frame's first arrival and raises *fault = 2 on a mismatch (the host then repeats the batch with the two-kernel path and stops using this
+// kernel).  Results are bit-identical to the two-kernel path: the same chains, the same per-pixel code.
+//
+// MEASURED (MI355X, round 3, tools/ab_fused.sh, profiles/r03_converter_experiments.txt): correct and bit-identical, but SLOWER than the two
+// kernels -- 5.8-6.2 ms per 256 VGA frames against 3.3-3.5 -- whatever the consumer waves per strip (4 or 8), the VGPR cap (5, 6, 7 or 8
+// waves per SIMD), the frames per launch (32 or 64) or the producers' wave priority.  One stats row of 64 pixels is ~12 us of latency (a
+// depth load, 40 dependent gathers, ~1000 arithmetic instructions, 5 stores) of which 1.3 us is arithmetic: k_stats hides that with 8
+// short-lived waves per SIMD = 8 192 rows in flight; here the rows in flight are the RESIDENT consumer waves (~2 700: the 3 200 producer
+// waves -- chains of dependent LDS steps that issue little -- hold the other slots, and the kernel needs 85 VGPRs), each walking its rows
+// one after the other.  Throughput = rows in flight / 12 us in both kernels; the ring removes the HBM round trip of the planes (the same
+// plane traffic emulated in the two-kernel form saves 20 %, PWN_ST_X=8 / PWN_II_X=8) but cannot pay for 3x fewer rows in flight.  Kept as an
+// opt-in path (PWN_FUSED_CONVERT=1) and a tested reference for the protocol; the product path is the two kernels.
+// grid = 8 * ceil(frames / 8) * (1 + kConsWG) * strips, block = kII_Threads.
+constexpr int kConsWaves = 4 * kConsWG;        // consumer waves per strip; each is an independent agent (no workgroup barriers): wave m takes
+                                               // rows m, m + kConsWaves, ... of every band, polls the producers only when it has caught up
+                                               // with what it last saw of them, and publishes its own progress word every second band
+static_assert(kIR_Rows % kConsWaves == 0, "rows of a band per consumer wave");
+constexpr int kConsPublish = 2;                // bands between two updates of a consumer wave's progress word
+__device__ __forceinline__ void stats_consumer(const FrameDesc& f, const ConvertParams& cp, const int s, const int part, const unsigned epoch, int* __restrict__ fault) {
+  const int rows = cp.rows, cols = cp.cols;
+  const int S = strips_of(cols), NB = bands_of(rows);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (wave >= 4 || (PWN_FUSED_X & 1)) return;
+  const int me = part * 4 + wave;
+  const int c = s * kIR_Cols + lane;
+  const gptr<unsigned long long> gsync = as_global(f.fsync);
+  const gptr<const int> growoff = as_global((const int*)f.rowoff);
+  const gptr<const uint16_t> graw = as_global(f.raw);
+  const gptr<const float> gdepth = as_global(f.depth);
+  const bool is_raw = f.raw != nullptr;
+  bool starved = false;
+  unsigned seen = 0;                                          // bands all three producers had stored when this wave last looked
+  for (int band = 0; band < NB; ++band) {
+    const unsigned need = (unsigned)((band + 5 < NB) ? band + 5 : NB);
+    if (seen < need && !starved) {
+      const int sp = s - 1 + lane;
+      unsigned got = 0xFFFFFFFFu;
+      if (lane < 3 && sp >= 0 && sp < S) {
+        if (!wait_progress(gsync + sp, epoch, need, cp.spinLimit)) { atomicOr(fault, 1); starved = true; }
+        got = (unsigned)__hip_atomic_load(gsync + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // same epoch: wait_progress has seen it
+      }
+      got = min(got, (unsigned)__shfl_xor((int)got, 1, 64));
+      got = min(got, (unsigned)__shfl_xor((int)got, 2, 64));
+      seen = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
+      starved = __ballot(starved) != 0ull;
+      if (starved) seen = 0xFFFFFFFFu;                        // the launch is lost: finish without further waits
+    }
+#pragma unroll 1
+    for (int jj = 0; jj < kIR_Rows / kConsWaves; ++jj) {
+      const int r = band * kIR_Rows + me + kConsWaves * jj;   // wave-uniform
+      if (r >= rows) continue;
+      const bool in = c < cols;
+      const unsigned pix = in ? (unsigned)(r * cols + c) : 0u;
+      float d;
+      if (is_raw) { const unsigned sv = __builtin_nontemporal_load(graw + pix); d = sv ? f.raw_scale * (float)sv : 0.0f; }      // pwn_static.cpp:54-68
+      else d = __builtin_nontemporal_load(gdepth + pix);
+      const bool valid = in && !(d < cp.minD || d > cp.maxD);
+      const unsigned long long bal = __ballot(valid);
+      const int base = growoff[r * S + s];                    // point index of the strip row's first valid pixel (k_strip_count + k_row_offsets)
+      const int idx = valid ? base + __popcll(bal & ((1ull << lane) - 1ull)) : -1;
+      stats_pixel<true>(f, cp, r, c, idx, d);
+    }
+    // this wave's ring loads of the band have returned (their values went into the stores above)
+    if (lane == 0 && ((band + 1) % kConsPublish == 0 || band + 1 == NB))
+      __hip_atomic_store(gsync + S + s * kConsWaves + me, ((unsigned long long)epoch << 32) | (unsigned long long)(unsigned)(band + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+__global__ void __launch_bounds__(kII_Threads) k_convert_fused(const FrameDesc* __restrict__ frames, ConvertParams cp, int nframes,
+                                                               unsigned epoch, int* __restrict__ fault) {
+  const int S = strips_of(cp.cols);
+  const unsigned j = blockIdx.x >> 3;
+  const int G = (1 + kConsWG) * S;                               // workgroups of a frame: S producers, then kConsWG consumers per strip
+  const int fi = 8 * (int)(j / (unsigned)G) + (int)(blockIdx.x & 7u), w = (int)(j % (unsigned)G);
+  if (fi >= nframes) return;
+  const FrameDesc& f = frames[fi];
+  if (threadIdx.x == 0) {
+    // placement check: all workgroups of a frame must sit on one XCD (they hand data over through its L2)
+    const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 0xFu;      // hwreg(HW_REG_XCC_ID, 0, 4)
+    const gptr<unsigned long long> wd = as_global(f.fsync) + (1 + 4 * kConsWG) * S;
+    const unsigned long long mine = ((unsigned long long)epoch << 32) | xcc;
+    unsigned long long cur = __hip_atomic_load(wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int t = 0; t < 8 && (unsigned)(cur >> 32) != epoch; ++t) {
+      const unsigned long long prev = atomicCAS((unsigned long long*)f.fsync + (1 + 4 * kConsWG) * S, cur, mine);
+      cur = (prev == cur) ? mine : prev;
+    }
+    if ((unsigned)(cur >> 32) != epoch || (unsigned)cur != xcc) atomicOr(fault, 2);
+  }
+  if (w < S) unproject_integral_body<true>(f, cp, w, epoch, fault);
+  else stats_consumer(f, cp, (w - S) / kConsWG, (w - S) % kConsWG, epoch, fault);
 }
 
 // Cloud::transformInPlace on an existing device cloud (cloud.cpp:173-186); grid = ceil(cap/256)

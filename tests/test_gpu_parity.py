@@ -22,7 +22,10 @@ from conftest import case_params, make_depth_pair
 pytestmark = pytest.mark.gpu
 
 CHI2_RTOL = 1e-5        # north_star: chi2 within 1e-5 rel of CPU -- enforced from the same iterate (teacher-forced)
-FREE_CHI2_RTOL_VGA = 1e-4   # free-running trace at VGA: a flipped correspondence moves chi2 by its own term; measured worst over 16 seeds 1.4e-5-class
+# free-running trace at VGA: measured over 16 seeds (test_free_running_chi2_many_seeds, profiles/r03_parity_measured.txt): worst 1.9e-4, 9 of 16
+# seeds above 1e-5, every one with 1-3 correspondences more or fewer than the oracle at that iteration (or one swapped); a term at the finder's
+# thresholds is 20-40 x the mean term (chi2 ~ 32 000 over ~205 000 terms at convergence).  Final poses agree to 3e-7.
+FREE_CHI2_RTOL_VGA = 5e-4
 POSE_TTOL = 1e-5        # metres
 POSE_RTOL = 1e-5        # rotation-matrix entries (~rad)
 

@@ -10,9 +10,14 @@ pytestmark = pytest.mark.gpu
 
 from oracle_tracker import OracleTracker  # noqa: E402  (processFrame restated on top of the oracle)
 
-# bars of test_config2_full_size_stream_matches_oracle (measured values are printed by the test; profiles/r03_tracker_parity.txt)
-FREE_INLIERS_BAR, FREE_POSE_BAR = 64, 2e-4          # free-running chain of 200 frames / 5 key-cloud switches
-FORCED_INLIERS_BAR, FORCED_POSE_BAR = 64, 2e-4      # one alignment from the oracle's own state (tightened below the free-running bars once measured)
+# bars of test_config2_full_size_stream_matches_oracle; measured on MI355X (printed by the test, profiles/r03_parity_measured.txt):
+#   free-running, 200 frames / 5 key-cloud switches: worst |inliers diff| 6 of ~150 000, worst |globalT diff| 5.5e-6
+#   teacher-forced (one alignment from the oracle's own state): inliers equal on 158 of 199 frames, worst diff 4, worst |T diff| 2.0e-6
+# An inlier difference is a correspondence at a pixel border of the z-buffer or at a threshold of the finder: the ten iterations of an
+# alignment run free on both sides and their iterates differ in the last bits (summation order of H, b); from the SAME iterate the
+# counters are equal (tests/test_gpu_parity.py: teacher-forced per iteration).
+FREE_INLIERS_BAR, FREE_POSE_BAR = 16, 2e-5
+FORCED_INLIERS_BAR, FORCED_POSE_BAR = 8, 1e-5
 
 
 def test_processFrame_trajectory_and_keyframes_match_oracle(oracle):
