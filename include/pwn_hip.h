@@ -344,7 +344,7 @@ void pwn_hip_t2v(const float T[16], float v[6]);
  * function k_solve_update runs on the device */
 void pwn_hip_ldlt_solve6(const float H[36], const float b[6], float x[6]);
 /* per-kernel device time (ms) of the stages of the last batch/single call, for bench.py:
- * names: "unproject","integral","integral_rows","integral_cols","stats","project_cur","project_ref","corr_linearize","solve",
+ * names: "unproject","integral","integral_rows","integral_cols","stats","convert_fused","project_cur","project_ref","corr_linearize","solve",
  * "statistics","match_score" ("project": the stand-alone pwn_hip_project).  launches = timed launch groups (one per sub-batch). */
 int pwn_hip_last_stage_ms(pwn_hip_ctx* ctx, const char* stage, float* ms, int* launches);
 /* what this GPU's HBM delivers, for the roofline report (SURVEY 8(d) asks for the measured figure next to the 8 TB/s spec):

@@ -208,7 +208,6 @@ def test_fused_converter_is_bit_identical_to_the_two_kernel_path(world, monkeypa
     for n in (24, 19):
         clouds = [api.Cloud(ctx, rows * cols) for _ in range(n)]
         converter.computeBatch(clouds, frames[:n], raw_scale=0.001)
-        assert ctx.stage_ms("convert_fused")[1] == 0 or True                               # (stage counters only with profiling on)
         for i in (0, 7, n - 1):
             ref = (world["refs"] + world["curs"])[i].arrays()
             got = clouds[i].arrays()
