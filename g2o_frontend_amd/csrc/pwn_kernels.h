@@ -2063,10 +2063,13 @@ __device__ __forceinline__ void assemble_Hb(const double* s, float* H, float* b)
 #pragma unroll
   for (int i = 0; i < 3; ++i) { b[i] = (float)s[27 + i]; b[i + 3] = (float)s[30 + i]; }
 }
+#ifndef PWN_SOLVE_X
+#define PWN_SOLVE_X 0     // timing experiments only (results wrong): 1 = no LDLT, 2 = no end-of-iteration pose clean-up, 4 = first partial record only
+#endif
 __global__ void __launch_bounds__(256) k_solve_update(const PairDesc* __restrict__ pairs, AlignParams ap, int nblocks, int outerEnd) {
   const PairDesc& pd = pairs[blockIdx.x];
   __shared__ double sums[kAccN];
-  reduce_partials(pd.partials, nblocks, sums);
+  reduce_partials(pd.partials, (PWN_SOLVE_X & 4) ? 1 : nblocks, sums);
   if (threadIdx.x != 0) return;
   PairState& st = *pd.state;
   float H[36], b[6];                                                     // registers: every index below is a constant
@@ -2086,11 +2089,16 @@ __global__ void __launch_bounds__(256) k_solve_update(const PairDesc* __restrict
   float nb[6], dx[6];
 #pragma unroll
   for (int d = 0; d < 6; ++d) nb[d] = -b[d];
+#if PWN_SOLVE_X & 1
+#pragma unroll
+  for (int d = 0; d < 6; ++d) dx[d] = nb[d] / H[d + 6 * d];
+#else
   ldlt_solve6(H, nb, dx);
+#endif
   Mat4 invT = st.invT;
   set_last_row(invT);
   invT = iso_mul(v2t(dx), invT);
-  if (outerEnd) {
+  if (outerEnd && !(PWN_SOLVE_X & 2)) {
     Mat4 T = iso_inverse(invT);
     float v[6];
     t2v(T, v);
