@@ -16,7 +16,7 @@ pwn_hip_cloud* DeviceCloudRegistry::deviceCloud(const Cloud* cloud, int capacity
   std::map<const Cloud*, Entry>::iterator it = _entries.find(cloud);
   if (it != _entries.end() && it->second.capacity >= capacity) return it->second.dev;
   if (it != _entries.end()) { pwn_hip_cloud_destroy(_ctx, it->second.dev); _entries.erase(it); }      // retired into the context's pool
-  Entry e; e.dev = 0; e.capacity = capacity < 1 ? 1 : capacity; e.deviceOnly = false;
+  Entry e; e.dev = 0; e.capacity = capacity < 1 ? 1 : capacity; e.deviceOnly = false; e.hostSynced = false; e.hostSizeAtSync = 0;
   check(_ctx, pwn_hip_cloud_create(_ctx, e.capacity, &e.dev));
   _entries[cloud] = e;
   return e.dev;
@@ -24,7 +24,7 @@ pwn_hip_cloud* DeviceCloudRegistry::deviceCloud(const Cloud* cloud, int capacity
 
 void DeviceCloudRegistry::markDeviceOnly(const Cloud* cloud) {
   std::map<const Cloud*, Entry>::iterator it = _entries.find(cloud);
-  if (it != _entries.end()) it->second.deviceOnly = true;
+  if (it != _entries.end()) { it->second.deviceOnly = true; it->second.hostSynced = false; it->second.hostSizeAtSync = 0; }
 }
 
 // The reference's element types carry a vptr (Point / Normal: 32 B, InformationMatrix: 80 B, Stats: 112 B), so
@@ -45,11 +45,23 @@ void DeviceCloudRegistry::upload(const Cloud* cloud, Entry& e) {
 
 pwn_hip_cloud* DeviceCloudRegistry::deviceCloudForAlign(const Cloud* cloud) {
   std::map<const Cloud*, Entry>::iterator it = _entries.find(cloud);
-  if (it != _entries.end() && it->second.deviceOnly) return it->second.dev;
+  if (it != _entries.end() && it->second.deviceOnly) {
+    // the device twin is the valid copy as long as the host side cannot have diverged from it: the host vectors are still empty (nobody
+    // downloaded), or they are the very download this registry made and nobody reported a change (markHostModified) or resized them
+    const size_t hostSize = cloud->points().size();
+    if (hostSize == 0 || (it->second.hostSynced && hostSize == it->second.hostSizeAtSync)) return it->second.dev;
+    it->second.deviceOnly = false;          // the caller filled or changed the host vectors (Cloud::transformInPlace, add, load ...): they win
+  }
   deviceCloud(cloud, (int)cloud->points().size());
   Entry& e = _entries[cloud];
   upload(cloud, e);
+  e.hostSynced = true; e.hostSizeAtSync = cloud->points().size();
   return e.dev;
+}
+
+void DeviceCloudRegistry::markHostModified(const Cloud* cloud) {
+  std::map<const Cloud*, Entry>::iterator it = _entries.find(cloud);
+  if (it != _entries.end()) { it->second.hostSynced = false; it->second.deviceOnly = false; }
 }
 
 void DeviceCloudRegistry::download(Cloud* cloud) {
@@ -78,6 +90,7 @@ void DeviceCloudRegistry::download(Cloud* cloud) {
     cloud->pointInformationMatrix()[i] = InformationMatrix(Eigen::Matrix4f(Eigen::Map<Eigen::Matrix4f>(&OP[16 * (size_t)i])));
     cloud->normalInformationMatrix()[i] = InformationMatrix(Eigen::Matrix4f(Eigen::Map<Eigen::Matrix4f>(&ON[16 * (size_t)i])));
   }
+  it->second.hostSynced = true; it->second.hostSizeAtSync = (size_t)n;      // host == device from here until markHostModified / a resize
 }
 
 void DeviceCloudRegistry::release(const Cloud* cloud) {

@@ -24,18 +24,22 @@ class DeviceCloudRegistry {
 
   // device twin of `cloud` with room for `capacity` points, created on first use; a twin that is too small is replaced
   pwn_hip_cloud* deviceCloud(const Cloud* cloud, int capacity);
-  // the twin the aligner needs: the registered one if the cloud came from HipDepthImageConverter (hostIsStale), else an upload
-  // of the host vectors (every call: the host side may have changed, e.g. Cloud::transformInPlace by the caller)
+  // the twin the aligner needs: the registered one if the cloud came from HipDepthImageConverter and the host vectors are still empty or
+  // are this registry's own download (size unchanged, no markHostModified), else an upload of the host vectors
   pwn_hip_cloud* deviceCloudForAlign(const Cloud* cloud);
   // marks the device twin as the only valid copy (after a device-side compute())
   void markDeviceOnly(const Cloud* cloud);
+  // the caller changed the host vectors of a cloud this registry knows (Cloud::transformInPlace, Cloud::add, direct writes): the next
+  // align uploads them again.  A change of points().size() is noticed without this call; an in-place change of values is not.
+  void markHostModified(const Cloud* cloud);
   // fills the host vectors (points, normals, stats, both information-matrix vectors) from the device twin
   void download(Cloud* cloud);
-  // call from wherever the caller deletes the Cloud (pwn_matcher_base users own their clouds)
+  // MUST be called wherever the caller deletes the Cloud (pwn_matcher_base users own their clouds): the registry is keyed by the Cloud's
+  // address, and a new Cloud allocated at a released address would otherwise inherit the old device twin
   void release(const Cloud* cloud);
 
  private:
-  struct Entry { pwn_hip_cloud* dev; int capacity; bool deviceOnly; };
+  struct Entry { pwn_hip_cloud* dev; int capacity; bool deviceOnly; bool hostSynced; size_t hostSizeAtSync; };
   void upload(const Cloud* cloud, Entry& e);
   pwn_hip_ctx* _ctx;
   std::map<const Cloud*, Entry> _entries;

@@ -13,7 +13,7 @@ HipDepthImageConverter::HipDepthImageConverter(DeviceCloudRegistry* registry, Po
                                                PointInformationMatrixCalculator* pointInformationMatrixCalculator,
                                                NormalInformationMatrixCalculator* normalInformationMatrixCalculator)
     : DepthImageConverterIntegralImage(projector, statsCalculator, pointInformationMatrixCalculator, normalInformationMatrixCalculator),
-      _registry(registry), _downloadToHost(false), _computeGaussians(false) {}
+      _registry(registry), _downloadToHost(true), _computeGaussians(false) {}
 
 pwn_hip_converter_params HipDepthImageConverter::params(const Eigen::Isometry3f& sensorOffset) const {
   const PinholePointProjector* pp = dynamic_cast<const PinholePointProjector*>(_projector);
