@@ -693,7 +693,7 @@ RECORDS_CRC_FILE = os.path.join(ROOT, "profiles", "records_crc.json")
 
 
 def records_crc(allrec):
-    """CRC32 of every assembled 80-byte result record (pose, chi2, inliers, iterations, pair id), in global pair order"""
+    """CRC32 of every assembled 256-byte result record (shard.py: pose, final values, per-iteration traces, counts, pair id), in global pair order"""
     import zlib
     a = np.ascontiguousarray(allrec, np.float32)
     return [int(zlib.crc32(a[i].tobytes())) for i in range(a.shape[0])]

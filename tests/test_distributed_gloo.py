@@ -60,3 +60,26 @@ def test_shard_ranges_partition():
                 assert all(shard.owner_of(p, n, w) == r for p in rg)
             assert seen == list(range(n))
     assert len(shard.shard_range(1024, 3, 8)) == 128
+
+
+def test_record_layout_carries_the_per_iteration_traces():
+    """the gathered record holds {T, chi2[10], inliers[10], C[10], flags}; both packers give the same 256 bytes."""
+    from g2o_frontend_amd import shard
+    from g2o_frontend_amd.api import ALIGN_RESULT_DTYPE
+    assert shard.RECORD_FLOATS * 4 == 256
+    raw = np.zeros(2, ALIGN_RESULT_DTYPE)
+    dicts = []
+    for i in range(2):
+        it = 10 if i == 0 else 7
+        T = np.eye(4, dtype=np.float32); T[:3, 3] = (0.1 * i, -0.2, 0.3)
+        raw["T"][i] = T.T.reshape(-1); raw["iterations"][i] = it; raw["n_reference"][i] = 298000 + i; raw["n_current"][i] = 297000 + i
+        raw["chi2"][i, :it] = np.linspace(1e6, 3e4, it); raw["iter_inliers"][i, :it] = 200000 + np.arange(it)
+        raw["iter_correspondences"][i, :it] = 201000 + np.arange(it); raw["iter_candidates"][i, :it] = 250000 + np.arange(it)
+        raw["chi2"][i, it:it + 2] = 12345.0                                   # stale tail past the last iteration: must not travel
+        raw["error"][i] = raw["chi2"][i, it - 1]; raw["inliers"][i] = raw["iter_inliers"][i, it - 1]
+        dicts.append(dict(T=T, error=float(raw["error"][i]), inliers=int(raw["inliers"][i]), iterations=it, chi2=raw["chi2"][i, :it].copy(),
+                          iter_inliers=raw["iter_inliers"][i, :it].copy(), C=raw["iter_correspondences"][i, :it].copy(), K=raw["iter_candidates"][i, :it].copy(),
+                          n_reference=int(raw["n_reference"][i]), n_current=int(raw["n_current"][i])))
+    a = shard.pack_results_raw(raw, [5, 6]); b = shard.pack_results(dicts, [5, 6])
+    assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+    assert a[1, 19] == 6 and a[1, 62] == 7 and a[1, 27] == 0 and a[1, 26] == raw["chi2"][1, 6] and a[0, 49] == 201009 and a[0, 60] == 298000
