@@ -14,6 +14,8 @@ Bars (BASELINE.json north_star):
     (C ~ 2e5; measured worst over 16 seeds: test_free_running_chi2_many_seeds prints it), 1e-2 at 120x160;
   * final SE(3): translation <= 1e-5 m, rotation matrix entries <= 1e-5.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -607,7 +609,7 @@ def test_error_paths(ctx):
     assert e.value.code == 6
 
 
-@pytest.mark.parametrize("rows,cols", [(113, 150), (97, 131), (33, 70), (17, 65), (16, 64), (121, 63), (5, 300)])
+@pytest.mark.parametrize("rows,cols", [(113, 150), (97, 131), (33, 70), (17, 65), (16, 64), (121, 63), (5, 300), (203, 170)])
 def test_odd_image_sizes(oracle, rows, cols):
     """Image sizes that are no multiple of anything the kernels tile by (64-column strips, 16-row bands, 256-pixel blocks, 2048-pixel
     tiles of the fused kernel): converter arrays and images bit for bit -- alone (three-kernel integral image) and in a 26-frame batch
@@ -642,6 +644,22 @@ def test_odd_image_sizes(oracle, rows, cols):
         converter.computeBatch(many, [ref_mm, cur_mm] * 13, raw_scale=0.001)
         for k in (0, 1, 24, 25):
             same((oref if k % 2 == 0 else ocur).arrays(), many[k].arrays())
+        # the opt-in fused converter (planes in a 128-row ring, producers and consumers in one launch) at the same odd size: partial strips,
+        # partial bands, rings that wrap (rows > 128) or never wrap (rows < 128)
+        os.environ["PWN_FUSED_CONVERT"] = "1"
+        try:
+            fctx = api.Context(0, rows, cols, 32)
+        finally:
+            del os.environ["PWN_FUSED_CONVERT"]
+        _, fconv, _ = gpu_objects(fctx, "small")
+        fconv.projector().setCameraMatrix([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]]); fconv.projector().setImageSize(rows, cols)
+        fused = [api.Cloud(fctx, rows * cols) for _ in range(21)]
+        fctx.set_profiling(True)
+        fconv.computeBatch(fused, ([ref_mm, cur_mm] * 11)[:21], raw_scale=0.001)
+        assert fctx.stage_ms("convert_fused")[1] == 1
+        for k in (0, 1, 19, 20):
+            same((oref if k % 2 == 0 else ocur).arrays(), fused[k].arrays())
+        fctx.close()
         if len(oref) == 0 or len(ocur) == 0:
             return
         ap = oracle.aligner_params(rows, cols, K=K, accumulate_fp64=1, **alig)
