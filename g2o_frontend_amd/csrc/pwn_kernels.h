@@ -2066,22 +2066,18 @@ __device__ __forceinline__ void assemble_Hb(const double* s, float* H, float* b)
 #ifndef PWN_SOLVE_X
 #define PWN_SOLVE_X 0     // timing experiments only (results wrong): 1 = no LDLT, 2 = no end-of-iteration pose clean-up, 4 = first partial record only
 #endif
-__global__ void __launch_bounds__(256) k_solve_update(const PairDesc* __restrict__ pairs, AlignParams ap, int nblocks, int outerEnd) {
-  const PairDesc& pd = pairs[blockIdx.x];
-  __shared__ double sums[kAccN];
-  reduce_partials(pd.partials, (PWN_SOLVE_X & 4) ? 1 : nblocks, sums);
-  if (threadIdx.x != 0) return;
-  PairState& st = *pd.state;
+// One Gauss-Newton step from the reduced sums: what k_solve_update stores into the PairState, as a pure function of (sums, the state before the
+// step).  (Round 3 evaluated it redundantly in every workgroup of the next projection -- one launch instead of two on the latency path: 26 us
+// against 9 + 6 us, the serial step is paid by every workgroup; docs/experiments.md.)
+struct StateUpdate {
+  float chi2; int inliers, ncorr, ncand, it;
+  Mat4 T, invTcorrPrev, invTcorr, invT, KRtLast, KRt;
+};
+__device__ __forceinline__ void solve_step(const double* sums, const PairState& st, const AlignParams& ap, const int outerEnd, StateUpdate& u) {
   float H[36], b[6];                                                     // registers: every index below is a constant
   assemble_Hb(sums, H, b);
-  const int it = st.it;
-  if (it < kMaxIter) {
-    st.chi2[it] = (float)sums[33];
-    st.inliers[it] = (int)sums[34];
-    st.ncorr[it] = (int)sums[35];
-    st.ncand[it] = (int)sums[36];
-  }
-  st.it = it + 1;
+  u.it = st.it;
+  u.chi2 = (float)sums[33]; u.inliers = (int)sums[34]; u.ncorr = (int)sums[35]; u.ncand = (int)sums[36];
 #pragma unroll
   for (int d = 0; d < 6; ++d) H[d + 6 * d] = H[d + 6 * d] + 1.0f;        // aligner.cpp:92
 #pragma unroll
@@ -2098,24 +2094,41 @@ __global__ void __launch_bounds__(256) k_solve_update(const PairDesc* __restrict
   Mat4 invT = st.invT;
   set_last_row(invT);
   invT = iso_mul(v2t(dx), invT);
+  u.T = st.T; u.invTcorrPrev = st.invTcorrPrev; u.invTcorr = st.invTcorr; u.KRtLast = st.KRtLast; u.KRt = st.KRt;
   if (outerEnd && !(PWN_SOLVE_X & 2)) {
     Mat4 T = iso_inverse(invT);
     float v[6];
     t2v(T, v);
     T = v2t(v);
     set_last_row(T);
-    st.T = T;
+    u.T = T;
     const Mat4 Tinv = iso_inverse(T);
-    st.invTcorrPrev = st.invTcorr;
-    st.invTcorr = Tinv;
+    u.invTcorrPrev = st.invTcorr;
+    u.invTcorr = Tinv;
     invT = Tinv;
     Mat4 KRt, iKRt; Mat3 iK;
     projector_matrices(ap.K, iso_mul(T, ap.refOffset), KRt, iKRt, iK);
-    st.KRtLast = st.KRt;        // the reference projection of this outer iteration (what the finder's depth image belongs to)
-    st.KRt = KRt;
+    u.KRtLast = st.KRt;         // the reference projection of this outer iteration (what the finder's depth image belongs to)
+    u.KRt = KRt;
   }
   set_last_row(invT);
-  st.invT = invT;
+  u.invT = invT;
+}
+__device__ __forceinline__ void apply_update(PairState& st, const StateUpdate& u, const int outerEnd) {
+  if (u.it < kMaxIter) { st.chi2[u.it] = u.chi2; st.inliers[u.it] = u.inliers; st.ncorr[u.it] = u.ncorr; st.ncand[u.it] = u.ncand; }
+  st.it = u.it + 1;
+  if (outerEnd) { st.T = u.T; st.invTcorrPrev = u.invTcorrPrev; st.invTcorr = u.invTcorr; st.KRtLast = u.KRtLast; st.KRt = u.KRt; }
+  st.invT = u.invT;
+}
+__global__ void __launch_bounds__(256) k_solve_update(const PairDesc* __restrict__ pairs, AlignParams ap, int nblocks, int outerEnd) {
+  const PairDesc& pd = pairs[blockIdx.x];
+  __shared__ double sums[kAccN];
+  reduce_partials(pd.partials, (PWN_SOLVE_X & 4) ? 1 : nblocks, sums);
+  if (threadIdx.x != 0) return;
+  PairState& st = *pd.state;
+  StateUpdate u;
+  solve_step(sums, st, ap, outerEnd, u);
+  apply_update(st, u, outerEnd && !(PWN_SOLVE_X & 2));
 }
 // reduction only, one record per pair (Aligner::_computeStatistics' 11th update).  grid = pairs, block = 256
 __global__ void __launch_bounds__(256) k_reduce_pairs(const PairDesc* __restrict__ pairs, int nblocks, SolveOut* __restrict__ out) {
