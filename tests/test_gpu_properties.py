@@ -222,3 +222,38 @@ def test_fused_converter_is_bit_identical_to_the_two_kernel_path(world, monkeypa
     base = world["aligner"].alignBatch(world["refs"], world["curs"])
     assert _digest(res) == _digest(base)
     ctx.close()
+
+
+def test_pinned_blocks_live_as_long_as_their_views_and_buffers_outlive_their_context():
+    """Round-2 advisor findings: (1) a page-locked block (pwn_hip_host_alloc) is released with its LAST numpy view, not by pinned_free while
+    views are alive; (2) a DeviceBuffer freed after its context was closed is released (pwn_hip_device_free with a NULL context) instead
+    of leaking; (3) data queued with pwn_hip_copy_async is seen by pwn_hip_cloud_upload (every entry point that reads caller pointers absorbs
+    the queued copies)."""
+    import gc
+    from g2o_frontend_amd import api
+    a = api.pinned_empty((4, 8), np.float32)
+    a[...] = 7.0
+    v = a[1]
+    api.pinned_free(a)                     # the earlier interface: must not free under the views
+    del a; gc.collect()
+    assert float(v.sum()) == 56.0          # still mapped
+    del v; gc.collect()
+    ctx = api.Context(0, 16, 16, 2)
+    buf = ctx.upload(np.arange(12, dtype=np.float32))
+    ctx.close()
+    buf.free()                             # no context any more: plain hipFree inside the library, no error, no leak
+    # copy_async -> cloud_upload
+    ctx = api.Context(0, 16, 16, 2)
+    n = 50
+    pts = np.zeros((n, 4), np.float32); pts[:, :3] = np.random.default_rng(0).normal(size=(n, 3)); pts[:, 3] = 1
+    host = api.pinned_empty((n, 4), np.float32); host[...] = pts
+    dev = ctx.upload(np.zeros((n, 4), np.float32))
+    dev.copy_from_async(host)              # queued on the copy stream
+    nrm = np.zeros((n, 4), np.float32); curv = np.zeros(n, np.float32); om = np.zeros((n, 16), np.float32)
+    c = api.Cloud(ctx, n)
+    L = ctx._L
+    import ctypes as C
+    ctx.check(L.pwn_hip_cloud_upload(ctx.h, c.h, n, C.c_void_p(dev.data_ptr()), nrm.ctypes.data_as(C.c_void_p), curv.ctypes.data_as(C.c_void_p),
+                                     om.ctypes.data_as(C.c_void_p), om.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(c.arrays()["points"][:, :3], pts[:, :3])
+    dev.free(); ctx.close()
