@@ -1,0 +1,41 @@
+"""CPU checks of the measurement tooling the bench line depends on: tools/summarize_pmc.py (per-kernel HBM bytes from the committed PMC
+summary -> profiles/traffic.json) and the consistency of the committed traffic table with the committed summary."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_traffic_json_is_what_the_newest_pmc_summary_gives(tmp_path):
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+    src = t["source"].split(" ")[0]
+    assert src.startswith("profiles/") and os.path.exists(os.path.join(ROOT, src)), src
+    newest = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if "_pmc_summary_v" in f)[-1]
+    assert os.path.basename(src) == newest, (src, newest)                      # weak #8 of the round-2 review: the table was one version stale
+    out = tmp_path / "traffic.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "summarize_pmc.py"), os.path.join(ROOT, src), "--traffic-json", str(out),
+                        "--version", t["version"]], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    again = json.load(open(out))
+    for k, e in t["kernels"].items():
+        assert abs(again["kernels"][k]["bytes_per_launch"] - e["bytes_per_launch"]) <= 1e-6 * e["bytes_per_launch"] + 1024.0, k      # the text summary rounds to 0.1 KB
+    # the gfx950 FETCH_SIZE correction holds in these very passes: the 2 GiB streaming probe reads back as 2 GiB (+- 0.1 %)
+    chk = t["k_probe_read_check"]
+    assert abs(chk["bytes_from_counters"] / chk["bytes_streamed"] - 1.0) < 1e-3
+    # the dominant kernel's traffic is within 15 % of its algorithmic bytes (1.09 x): the roofline fraction is not an artefact of re-reads
+    assert 1.0 < t["k_corr_linearize_bytes_per_pair_iteration"] / 27.6e6 < 1.15
+
+
+def test_bench_line_of_the_round_is_committed_and_self_consistent():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_line_b.json")))
+    r = d["roofline"]
+    assert d["unit"] == "alignments/s" and d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["bound"] == "hbm"
+    assert abs(r["achieved"] - r["bytes_per_launch_algorithmic"] / (r["avg_launch_ms"] * 1e-3) / 1e9) < 1e-3 * r["achieved"]
+    assert abs(d["value"] - d["config"]["pairs_per_gpu"] / d["ms_per_step"] * 1e3) < 1e-6 * d["value"]
+    assert r["traffic_source"]["version"] and abs(r["traffic_over_algorithmic"] - r["traffic"] / r["bytes_per_launch_algorithmic"]) < 1e-9
+    assert set(r["other_kernels"]) == {"k_stats", "k_unproject_integral", "k_project"}
+    assert d["chi2_match"]["ok"] and d["chi2_match"]["max_rel_diff"] <= 1e-5 and d["chi2_match"]["free_running_ok"]
+    assert d["gather"]["records_equal_local"] and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
