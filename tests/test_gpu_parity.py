@@ -727,3 +727,56 @@ def test_aligner_finder_images_bit_exact_and_collisions(oracle, shrink):
             assert np.array_equal(b["K"], single["K"]) and np.array_equal(b["C"], single["C"])
     finally:
         ctx.close()
+
+
+def test_gpu_linearizer_against_the_references_octave_model(ctx):
+    """The GPU linearizer (pwn_hip_linearize: k_linearize_list + the fixed-order reduction) directly against the one executable model of this
+    path the reference repository holds -- octave/pwn/pwn_iteration.m restated in numpy (tests/test_reference_octave_model.py), no oracle in
+    between: PWNTest.m's scenario (100 points with normals in a 100 m cube, 120-degree ground-truth rotation), chi2 at every iterate of the
+    model's own 40-iteration trajectory; and H, b at the identity on a small-motion pair (where the model's Jacobian is the C++ one)."""
+    from g2o_frontend_amd import api
+    from test_reference_octave_model import m_v2t, m_remap, m_iteration_sums
+    _, _, aligner = gpu_objects(ctx, "small")
+    aligner.linearizer().setInlierMaxChi2(1e30)
+
+    def cloud(P6, Omega):
+        n = P6.shape[1]
+        P = np.ones((n, 4), np.float32); P[:, :3] = P6[:3].T
+        N = np.zeros((n, 4), np.float32); N[:, :3] = P6[3:].T
+        op = np.zeros((n, 4, 4), np.float32); op[:, :3, :3] = Omega[:3, :3]
+        on = np.zeros((n, 4, 4), np.float32); on[:, :3, :3] = Omega[3:, 3:]
+        c = api.Cloud(ctx, n)
+        c.upload(P, N, np.full(n, 0.01, np.float32), op.transpose(0, 2, 1).reshape(n, 16), on.transpose(0, 2, 1).reshape(n, 16))
+        return c
+    rng = np.random.default_rng(11)
+    n = 100
+    Pi = rng.uniform(-0.5, 0.5, (6, n)); Pi[:3] *= 100.0; Pi[3:] /= np.linalg.norm(Pi[3:], axis=0, keepdims=True)
+    gtX = m_v2t(np.array([100.0, 200.0, 300.0, 0.5, 0.5, 0.5]))
+    Pj = np.stack([m_remap(gtX, Pi[:, i]) for i in range(n)], 1)
+    Omega = np.eye(6); Omega[3:, 3:] *= 100.0
+    aligner.setCurrentCloud(cloud(Pi, Omega)); aligner.setReferenceCloud(cloud(Pj, Omega))
+    corr = np.stack([np.arange(n), np.arange(n)], 1).astype(np.int32)
+    X = np.eye(4); worst = 0.0
+    for it in range(40):
+        H, b, err = m_iteration_sums(Pi, Pj, Omega, X)
+        g = aligner.linearize(corr, X.astype(np.float32))
+        assert g["inliers"] == n
+        # fp32 terms of 100 m coordinates against float64: relative 2e-4; once the noise-free scenario has converged chi2 is rounding noise of
+        # ~300 m coordinates (1e-5), hence the absolute term
+        assert abs(g["chi2"] - err) <= 2e-4 * err + 1e-3, (it, g["chi2"], err)
+        if err > 1.0:
+            worst = max(worst, abs(g["chi2"] - err) / err)
+        X = X @ m_v2t(-np.linalg.solve(H, b))
+    # H, b at the identity, small motion
+    X = m_v2t(np.array([0.004, -0.003, 0.002, 0.001, -0.002, 0.0015]))
+    Pi2 = rng.uniform(-1, 1, (6, 400)); Pi2[:3] += np.array([[0.0], [0.0], [2.5]]); Pi2[3:] /= np.linalg.norm(Pi2[3:], axis=0, keepdims=True)
+    Pj2 = np.stack([m_remap(np.linalg.inv(X), Pi2[:, i]) for i in range(400)], 1)
+    Q = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+    Om2 = np.zeros((6, 6)); Om2[:3, :3] = Q @ np.diag([1000.0, 1.0, 1.0]) @ Q.T; Om2[3:, 3:] = np.eye(3) * 100.0
+    aligner.setCurrentCloud(cloud(Pi2, Om2)); aligner.setReferenceCloud(cloud(Pj2, Om2))
+    corr2 = np.stack([np.arange(400), np.arange(400)], 1).astype(np.int32)
+    H, b, err = m_iteration_sums(Pi2, Pj2, Om2, np.eye(4))
+    g = aligner.linearize(corr2, np.eye(4, dtype=np.float32))
+    assert abs(g["chi2"] - err) <= 5e-5 * err
+    assert np.abs(g["H"] - H).max() <= 5e-5 * np.abs(H).max() and np.abs(g["b"] - b).max() <= 5e-5 * np.abs(b).max() + 1e-6 * np.abs(H).max()
+    print(f"GPU linearizer vs pwn_iteration.m model: worst chi2 rel diff {worst:.1e} over 40 iterates of PWNTest.m's trajectory")

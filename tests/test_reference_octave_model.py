@@ -120,3 +120,37 @@ def test_linearizer_matches_the_octave_model(oracle):
         _, _, err = m_iteration_sums(cur.T, ref.T, Omega, Xg)
         o = oracle.linearize(ap, cref, ccur, corr, Xg.astype(np.float32))
         assert abs(o["chi2_fp64"] - err) <= 5e-5 * err
+
+
+def test_PWNTest_scenario_chi2_along_the_models_own_trajectory(oracle):
+    """octave/PWNTest.m's scenario at its first noise level (100 random points with unit normals in a 100 m cube, ground truth transform
+    v2t([100 200 300 .5 .5 .5]) = 120 degrees about (1,1,1), Omega = diag(1,1,1,100,100,100), start at the identity), run with the numpy
+    restatement of pwn_solve.m / pwn_iteration.m (update Xnew = X * v2t(-H \\ b)).  The model must find the ground truth (its script prints the
+    transform error and asserts nothing), and the ORACLE's chi2 (Linearizer::update, linearizer.cpp:17-115) must agree with the model's at
+    every iterate of that trajectory -- large rotations and 100 m coordinates, where the small-motion cases of the test above do not go."""
+    rng = np.random.default_rng(11)
+    n, tscale = 100, 100.0
+    Pi = rng.uniform(-0.5, 0.5, (6, n)); Pi[:3] *= tscale; Pi[3:] /= np.linalg.norm(Pi[3:], axis=0, keepdims=True)       # PWNTest.m:7-11
+    gtX = m_v2t(np.array([100.0, 200.0, 300.0, 0.5, 0.5, 0.5]))                                                          # :14-15
+    Pj = np.stack([m_remap(gtX, Pi[:, i]) for i in range(n)], 1)                                                         # :23 (noise level 1: none)
+    Omega = np.eye(6); Omega[3:, 3:] *= 100.0                                                                           # :25-28
+    # the oracle's clouds: Pi = current (the fixed side of e = pi - X pj), Pj = reference (moved by invT = X), one information matrix for all
+    def cloud(P6):
+        P = np.ones((n, 4), np.float32); P[:, :3] = P6[:3].T
+        N = np.zeros((n, 4), np.float32); N[:, :3] = P6[3:].T
+        op = np.zeros((n, 4, 4), np.float32); op[:, :3, :3] = Omega[:3, :3]
+        on = np.zeros((n, 4, 4), np.float32); on[:, :3, :3] = Omega[3:, 3:]
+        return oracle.Cloud.from_arrays(P, N, np.full(n, 0.01, np.float32), op.transpose(0, 2, 1).reshape(n, 16), on.transpose(0, 2, 1).reshape(n, 16))
+    ccur, cref = cloud(Pi), cloud(Pj)
+    corr = np.stack([np.arange(n), np.arange(n)], 1).astype(np.int32)
+    ap = oracle.aligner_params(120, 160, accumulate_fp64=1, **dict(oracle.QVGA4_CONF_ALIGNER, inlier_max_chi2=1e30))
+    X = np.eye(4); errs = []
+    for it in range(40):                                                                                                # :47-52, pwn_solve.m:13-20
+        H, b, err = m_iteration_sums(Pi, Pj, Omega, X)
+        o = oracle.linearize(ap, cref, ccur, corr, X.astype(np.float32))
+        assert o["inliers"] == n
+        assert abs(o["chi2_fp64"] - err) <= 2e-4 * err + 1e-3, (it, o["chi2_fp64"], err)      # fp32 terms of 100 m coordinates against float64
+        errs.append(err)
+        X = X @ m_v2t(-np.linalg.solve(H, b))                                                                           # pwn_iteration.m:28-30
+    assert errs[0] > 1e6 and errs[-1] < 1e-12 * errs[0]                                                                 # the model converges ...
+    assert np.abs(m_t2v(X @ gtX)).max() < 1e-6                                                                          # ... to the ground truth (PWNTest.m:57-58)
