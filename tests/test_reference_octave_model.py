@@ -154,3 +154,18 @@ def test_PWNTest_scenario_chi2_along_the_models_own_trajectory(oracle):
         X = X @ m_v2t(-np.linalg.solve(H, b))                                                                           # pwn_iteration.m:28-30
     assert errs[0] > 1e6 and errs[-1] < 1e-12 * errs[0]                                                                 # the model converges ...
     assert np.abs(m_t2v(X @ gtX)).max() < 1e-6                                                                          # ... to the ground truth (PWNTest.m:57-58)
+
+
+def test_products_se3_chart_against_the_octave_model_directly():
+    """pwn_hip_v2t / pwn_hip_t2v / pwn_hip_iso_mul / pwn_hip_iso_inverse (host compilations of the device functions k_solve_update runs;
+    no GPU needed) against v2t.m / t2v.m / quat2mat.m / mat2quat.m -- the product's SE(3) chart on the reference's model, without the oracle."""
+    from g2o_frontend_amd import api
+    rng = np.random.default_rng(8)
+    for _ in range(200):
+        x = np.concatenate([rng.uniform(-2, 2, 3), rng.uniform(-0.5, 0.5, 3)])
+        X = m_v2t(x)
+        assert np.abs(api.v2t(x.astype(np.float32)) - X).max() < 2e-6
+        assert np.abs(api.t2v(X.astype(np.float32)) - m_t2v(X)).max() < 2e-6
+        Y = m_v2t(np.concatenate([rng.uniform(-1, 1, 3), rng.uniform(-0.4, 0.4, 3)]))
+        assert np.abs(api.iso_mul(X.astype(np.float32), Y.astype(np.float32)) - X @ Y).max() < 5e-6
+        assert np.abs(api.iso_inverse(X.astype(np.float32)) - np.linalg.inv(X)).max() < 5e-6
