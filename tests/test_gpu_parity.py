@@ -780,3 +780,86 @@ def test_gpu_linearizer_against_the_references_octave_model(ctx):
     assert abs(g["chi2"] - err) <= 5e-5 * err
     assert np.abs(g["H"] - H).max() <= 5e-5 * np.abs(H).max() and np.abs(g["b"] - b).max() <= 5e-5 * np.abs(b).max() + 1e-6 * np.abs(H).max()
     print(f"GPU linearizer vs pwn_iteration.m model: worst chi2 rel diff {worst:.1e} over 40 iterates of PWNTest.m's trajectory")
+
+
+def test_gpu_converter_against_float64_brute_force():
+    """The GPU converter without the oracle in between: a float64 numpy brute force of the reference's per-pixel statistics
+    (statscalculatorintegralimage.cpp:33-80: window x in (c-rad-1, c+rad-1], y in (r-rad-1, r+rad-1] after the clamps of
+    pointintegralimage.cpp:57-60, mean / covariance of pointaccumulator.h:66-86, smallest eigenvector, curvature of stats.h:98-103, normal
+    turned towards the sensor) on a 120x160 frame: window counts exactly, normals and curvatures to the accuracy of fp32 integral-image sums."""
+    from g2o_frontend_amd import api, synth
+    name = "small"
+    rows, cols, K, conv, _ = case_params(name)
+    depth_mm = synth.render_depth_mm(21, np.eye(4), rows, cols, K)
+    depth = depth_mm.astype(np.float32) * np.float32(0.001); depth[depth_mm == 0] = 0
+    c = api.Context(0, rows, cols, 2)
+    _, converter, _ = gpu_objects(c, name)
+    g = api.Cloud(c, rows * cols)
+    converter.compute(g, depth, keep_stats=True)
+    idx, itv = converter.indexImage(), converter.intervalImage()
+    a = g.arrays(stats=True)
+    fx, fy, cx, cy = K
+    valid = (depth >= conv["min_distance"]) & (depth <= conv["max_distance"])
+    assert np.array_equal(valid, idx >= 0) and np.array_equal(idx[valid], np.arange(valid.sum()))          # ordered compaction
+    d64 = depth.astype(np.float64)
+    cc, rr = np.meshgrid(np.arange(cols, dtype=np.float64), np.arange(rows, dtype=np.float64))
+    P = np.stack([(cc - cx) / fx * d64, (rr - cy) / fy * d64, d64], -1)                                      # iK * (c d, r d, d)
+    assert np.abs(a["points"][:, :3] - P[valid]).max() < 2e-6 * 4.5
+    # interval image: int(max(fx R / d, fy R / d)) in fp32 (pinholepointprojector.h:264-274)
+    R = np.float32(conv["world_radius"])
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = np.float32(1.0) / np.where(valid, depth, np.float32(1.0))
+        want_itv = np.where(valid, np.maximum(np.float32(fx) * R * inv, np.float32(fy) * R * inv).astype(np.int32), -1)
+    assert (want_itv != itv).sum() <= 2                                                                     # (K R) / d vs (K R) * (1/d): a truncation boundary at most
+    rng = np.random.default_rng(3)
+    checked = big = 0
+    worst_ang = worst_curv = 0.0
+    angs = []; ncomp = 0
+    Pv = np.where(valid[..., None], P, 0.0)
+    for _ in range(600):
+        r, cpx = int(rng.integers(0, rows)), int(rng.integers(0, cols))
+        if not valid[r, cpx]:
+            continue
+        rad = int(np.clip(itv[r, cpx], conv["min_image_radius"], conv["max_image_radius"]))
+        cl = lambda x, hi: min(max(x, 0), hi)
+        x0, x1 = cl(cpx - rad - 1, cols - 1), cl(cpx + rad - 1, cols - 1)
+        y0, y1 = cl(r - rad - 1, rows - 1), cl(r + rad - 1, rows - 1)
+        m = valid[y0 + 1:y1 + 1, x0 + 1:x1 + 1]
+        n = int(m.sum())
+        i = idx[r, cpx]
+        assert a["npoints"][i] == (n if n >= conv["min_points"] else 0), (r, cpx, rad, n, a["npoints"][i])
+        if n < conv["min_points"]:
+            assert not a["normals"][i, :3].any()
+            continue
+        pts = Pv[y0 + 1:y1 + 1, x0 + 1:x1 + 1][m]
+        mean = pts.mean(0)
+        cov = pts.T @ pts / n - np.outer(mean, mean)
+        w, V = np.linalg.eigh(cov)
+        curv = max(w[0], 0.0) / (max(w[0], 0.0) + w[1] + w[2] + 1e-9)
+        checked += 1
+        # fp32 sums of ~n squared coordinates: the covariance is a difference of terms ~|p|^2 with relative error ~1e-6, i.e. absolute ~1e-5 m^2
+        # against eigenvalues down to ~1e-7 on the planes: compare where the plane is well conditioned
+        if w[1] < 50 * 2e-5:
+            continue
+        big += 1
+        nrm = a["normals"][i, :3].astype(np.float64)
+        p2 = float(P[r, cpx] @ P[r, cpx])
+        tolc = 8e-5 * p2 / (max(w[0], 0.0) + w[1] + w[2])          # the same covariance error seen by the curvature ratio
+        if tolc > 0.05:
+            continue                                               # small window far away: fp32 sums leave no comparable curvature (the reference's do not either)
+        assert abs(float(a["curvature"][i]) - curv) <= tolc + 1e-4 or not nrm.any(), (r, cpx, float(a["curvature"][i]), curv, tolc)
+        if curv + tolc < conv["stats_curvature_threshold"]:
+            assert nrm.any(), (r, cpx, curv, tolc)
+            want = V[:, 0] * (-1.0 if V[:, 0] @ P[r, cpx] > 0 else 1.0)
+            ang = np.arccos(np.clip(abs(nrm @ want), -1, 1))
+            # the fp32 sums put an absolute error of a few 1e-5 |p|^2 on the covariance (the reference's integral image has the same); the normal
+            # turns by that over the eigen-gap
+            tol = min(0.2, 4e-5 * float(P[r, cpx] @ P[r, cpx]) / (w[1] - max(w[0], 0.0)))
+            assert nrm @ P[r, cpx] <= 0 and ang < tol, (r, cpx, ang, tol, w)
+            worst_ang = max(worst_ang, ang); angs.append(ang)
+            worst_curv = max(worst_curv, abs(float(a["curvature"][i]) - curv))
+            ncomp += 1
+    assert checked > 200 and ncomp > 60 and worst_curv < 0.05 and np.median(angs) < 0.01
+    print(f"GPU converter vs float64 brute force: {checked} windows counted exactly, {ncomp} normals compared, median angle {np.median(angs):.1e} rad, "
+          f"worst {worst_ang:.1e} rad, worst |curvature diff| {worst_curv:.1e}")
+    c.close()
