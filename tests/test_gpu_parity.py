@@ -863,3 +863,194 @@ def test_gpu_converter_against_float64_brute_force():
     print(f"GPU converter vs float64 brute force: {checked} windows counted exactly, {ncomp} normals compared, median angle {np.median(angs):.1e} rad, "
           f"worst {worst_ang:.1e} rad, worst |curvature diff| {worst_curv:.1e}")
     c.close()
+
+
+def test_gpu_projector_against_a_numpy_zbuffer():
+    """PinholePointProjector::project on the GPU (pwn_hip_project and the aligner's 32-bit z-buffer path through align(images=True)) against a
+    numpy restatement of pinholepointprojector.cpp:33-66 / .h:224-233 written with the same fp32 operations -- no oracle in between: for every
+    point KRt p with left-to-right fp32 sums, 1/d, roundf, bounds; per pixel the nearest point, ties to the lowest index: index and depth
+    images bit for bit, on a real converted cloud projected from a moved pose (collisions, out-of-image points, range limits)."""
+    from g2o_frontend_amd import api, synth
+    name = "small"
+    rows, cols, K, conv, _ = case_params(name)
+    c = api.Context(0, rows, cols, 2)
+    proj, converter, _ = gpu_objects(c, name)
+    depth_mm = synth.render_depth_mm(23, np.eye(4), rows, cols, K)
+    g = api.Cloud(c, rows * cols)
+    converter.compute(g, c.DepthImage_convert_16UC1_to_32FC1(depth_mm))
+    P = g.arrays()["points"][:, :3].astype(np.float32)
+    f32 = np.float32
+    for v in ([0.0] * 6, [0.03, -0.02, 0.05, 0.01, -0.015, 0.02], [-0.2, 0.1, 0.3, -0.05, 0.04, 0.03]):
+        T = synth.v2t(np.array(v)).astype(np.float32)
+        proj.setImageSize(rows, cols); proj.setTransform(T)
+        gi, gd = proj.project(g)
+        KRt = proj.matrices()[0].astype(np.float32)              # pwn_hip_projector_matrices: K * inverse(T), row-major view
+        x, y, z = P[:, 0], P[:, 1], P[:, 2]
+        def row(r):                                              # ((a x + b y) + c z) + d * 1, every operation rounded to fp32
+            return ((KRt[r, 0] * x + KRt[r, 1] * y) + KRt[r, 2] * z) + KRt[r, 3] * f32(1.0)
+        ix, iy, d = row(0), row(1), row(2)
+        ok = ~((d < f32(conv["min_distance"])) | (d > f32(conv["max_distance"])))
+        with np.errstate(divide="ignore", invalid="ignore"):
+            inv = f32(1.0) / d
+            fxp, fyp = ix * inv, iy * inv
+        def roundf(a):                                           # half away from zero, exactly
+            t = np.trunc(a); fr = a - t
+            return np.where(fr >= f32(0.5), t + 1, np.where(fr <= f32(-0.5), t - 1, t)).astype(np.float32)
+        with np.errstate(invalid="ignore"):
+            rx, ry = roundf(fxp), roundf(fyp)
+            ok &= (rx >= 0) & (rx < cols) & (ry >= 0) & (ry < rows)
+        idx = np.nonzero(ok)[0]
+        pix = ry[idx].astype(np.int64) * cols + rx[idx].astype(np.int64)
+        order = np.lexsort((idx, d[idx], pix))                   # per pixel: nearest first, ties to the lowest index
+        pix_s, idx_s = pix[order], idx[order]
+        first = np.ones(len(pix_s), bool); first[1:] = pix_s[1:] != pix_s[:-1]
+        wi = np.full(rows * cols, -1, np.int32); wd = np.full(rows * cols, np.finfo(np.float32).max, np.float32)
+        wi[pix_s[first]] = idx_s[first]; wd[pix_s[first]] = d[idx_s[first]]
+        assert np.array_equal(gi.reshape(-1), wi), (v, int((gi.reshape(-1) != wi).sum()))
+        assert np.array_equal(gd.reshape(-1).view(np.uint32), wd.view(np.uint32)), v
+        collisions = int(len(pix_s) - first.sum())
+        print(f"projector vs numpy z-buffer, motion {v}: {int(first.sum())} pixels, {collisions} collisions settled, bit-exact")
+    c.close()
+
+
+def test_gpu_correspondence_finder_against_numpy():
+    """CorrespondenceFinder::compute on the GPU against a numpy restatement of correspondencefinder.cpp:45-106 with the same fp32 operations
+    (T applied as the homogeneous 4x4 product with left-to-right sums; the curvature ratio in double, rounded to float) -- no oracle in
+    between: the correspondence list (row-major order) and the candidate count exactly, for a near pose and for one that rejects many."""
+    from g2o_frontend_amd import api, synth
+    name = "small"
+    rows, cols, K, conv, alig = case_params(name)
+    c = api.Context(0, rows, cols, 2)
+    proj, converter, aligner = gpu_objects(c, name)
+    ref_mm, cur_mm, _ = synth.make_pair(31, rows, cols, K)
+    gr, gc = api.Cloud(c, rows * cols), api.Cloud(c, rows * cols)
+    converter.compute(gr, c.DepthImage_convert_16UC1_to_32FC1(ref_mm)); ri = converter.indexImage().copy()
+    converter.compute(gc, c.DepthImage_convert_16UC1_to_32FC1(cur_mm)); ci = converter.indexImage().copy()
+    aligner.setReferenceCloud(gr); aligner.setCurrentCloud(gc)
+    A, B = gr.arrays(), gc.arrays()
+    f32 = np.float32
+    for v in ([0.0] * 6, [0.01, -0.02, 0.03, 0.02, -0.01, 0.015], [0.3, 0.0, 0.0, 0.0, 0.05, 0.0]):
+        T = synth.v2t(np.array(v)).astype(np.float32); T[3] = (0, 0, 0, 1)
+        gcorr, gK = aligner.computeCorrespondences(ri, ci, T)
+        r_i, c_i = ri.reshape(-1), ci.reshape(-1)
+        cand = (r_i >= 0) & (c_i >= 0)                                                                       # :60
+        K_want = int(cand.sum())
+        rI, cI = r_i[cand], c_i[cand]
+        rP, rN, cP, cN = A["points"][rI], A["normals"][rI], B["points"][cI], B["normals"][cI]
+        def sq3(a): return (a[:, 0] * a[:, 0] + a[:, 1] * a[:, 1]) + a[:, 2] * a[:, 2]
+        ok = (sq3(cN) != 0) & (sq3(rN) != 0)                                                                # :69
+        def iso(Tm, p, w):                                                                                  # Isometry3f * Vector4f, left to right
+            return np.stack([((Tm[k, 0] * p[:, 0] + Tm[k, 1] * p[:, 1]) + Tm[k, 2] * p[:, 2]) + Tm[k, 3] * f32(w) for k in range(3)], 1)
+        rp, rn = iso(T, rP, 1.0), iso(T, rN, 0.0)
+        ok &= ~(((cN[:, 0] * rn[:, 0] + cN[:, 1] * rn[:, 1]) + cN[:, 2] * rn[:, 2]) < f32(alig["inlier_normal_angular_threshold"]))      # :78
+        dd = cP[:, :3] - rp
+        ok &= ~(sq3(dd) > f32(alig["inlier_distance_threshold"]) * f32(alig["inlier_distance_threshold"]))                                 # :84
+        flat = f32(alig["flat_curvature_threshold"])
+        rc = np.maximum(A["curvature"][rI], flat); cc = np.maximum(B["curvature"][cI], flat)                  # :89-93
+        ratio = ((rc.astype(np.float64) + 1e-5) / (cc.astype(np.float64) + 1e-5)).astype(np.float32)          # :96
+        mx = f32(alig["inlier_curvature_ratio_threshold"]); mn = f32(1.0) / mx
+        ok &= ~((ratio < mn) | (ratio > mx))                                                                # :97-99
+        want = np.stack([rI[ok], cI[ok]], 1).astype(np.int32)
+        assert gK == K_want and np.array_equal(gcorr, want), (v, gK, K_want, len(gcorr), len(want))
+        print(f"finder vs numpy, motion {v}: K {gK}, C {len(gcorr)}: exact")
+    c.close()
+
+
+def test_gpu_unproject_and_integral_image_against_numpy_fp32():
+    """unProject (pinholepointprojector.cpp:93-133, .h:246-251) and PointIntegralImage::compute (pointintegralimage.cpp:7-44) on the GPU against
+    numpy float32 arithmetic in the reference's order -- no oracle in between: points iKRt * (c d, r d, d, 1) with left-to-right fp32 sums, the ten
+    accumulator planes (x y z 1 xx xy xz yy yz zz), a sequential fp32 prefix sum along image x, then along image y (numpy's float32 cumsum adds
+    strictly left to right).  Bit for bit, VGA."""
+    from g2o_frontend_amd import api, synth
+    name = "vga"
+    rows, cols, K, conv, _ = case_params(name)
+    c = api.Context(0, rows, cols, 2)
+    proj, _, _ = gpu_objects(c, name)
+    depth = c.DepthImage_convert_16UC1_to_32FC1(synth.render_depth_mm(33, np.eye(4), rows, cols, K))
+    cloud = api.Cloud(c, rows * cols)
+    gidx = proj.unProject(cloud, depth)
+    gI = api.StatsCalculatorIntegralImage.integralImage(cloud, gidx)
+    f32 = np.float32
+    proj.setTransform(np.eye(4, dtype=np.float32))
+    iKRt = proj.matrices()[1].astype(np.float32)
+    valid = ~((depth < f32(conv["min_distance"])) | (depth > f32(conv["max_distance"])))
+    assert np.array_equal(gidx >= 0, valid) and np.array_equal(gidx[valid], np.arange(valid.sum()))
+    cc, rr = np.meshgrid(np.arange(cols, dtype=np.float32), np.arange(rows, dtype=np.float32))
+    a, b, d = cc * depth, rr * depth, depth
+    def row(k): return ((iKRt[k, 0] * a + iKRt[k, 1] * b) + iKRt[k, 2] * d) + iKRt[k, 3] * f32(1.0)
+    x, y, z = [np.where(valid, row(k), f32(0)).astype(np.float32) for k in range(3)]
+    pts = cloud.arrays()["points"]
+    assert np.array_equal(pts[:, 0].view(np.uint32), x[valid].view(np.uint32)) and np.array_equal(pts[:, 1].view(np.uint32), y[valid].view(np.uint32))
+    assert np.array_equal(pts[:, 2].view(np.uint32), z[valid].view(np.uint32))
+    one = valid.astype(np.float32)
+    planes = [x, y, z, one, x * x, x * y, x * z, y * y, y * z, z * z]
+    for k, p in enumerate(planes):
+        want = np.cumsum(np.cumsum(p.astype(np.float32), axis=1, dtype=np.float32), axis=0, dtype=np.float32)
+        assert np.array_equal(np.asarray(gI[k]).reshape(rows, cols).view(np.uint32), want.view(np.uint32)), k
+    print("unProject + integral image vs numpy float32: points and all ten planes bit-exact at VGA")
+    c.close()
+
+
+EIG_TOL = 1e-4      # closed-form roots in fp32 (trig of the scaled characteristic polynomial): relative to the largest eigenvalue
+
+
+def test_gpu_stats_against_numpy_fp32_sums_and_lapack():
+    """StatsCalculatorIntegralImage::compute on the GPU (statscalculatorintegralimage.cpp:33-80) without the oracle: numpy float32 integral planes
+    (bit-equal to the GPU's, see the test above), getRegion's A + B - C - D in that order (pointintegralimage.cpp:61-64), mean and covariance as
+    pointaccumulator.h:66-86 -- every operation fp32 -- give the window count and the mean of EVERY valid pixel bit for bit; the eigenvalues /
+    normal of the GPU's closed-form solver (Eigen's computeDirect restated) are then compared with LAPACK on that very fp32 covariance, so the
+    noise of the fp32 sums cancels out of the comparison: eigenvalues to 2e-5 of the largest, normals to the solver's accuracy over the eigen-gap."""
+    from g2o_frontend_amd import api, synth
+    name = "small"
+    rows, cols, K, conv, _ = case_params(name)
+    c = api.Context(0, rows, cols, 2)
+    proj, converter, _ = gpu_objects(c, name)
+    depth = c.DepthImage_convert_16UC1_to_32FC1(synth.render_depth_mm(35, np.eye(4), rows, cols, K))
+    g = api.Cloud(c, rows * cols)
+    converter.compute(g, depth, keep_stats=True)
+    idx, itv = converter.indexImage(), converter.intervalImage()
+    a = g.arrays(stats=True)
+    f32 = np.float32
+    valid = idx >= 0
+    P = np.zeros((rows, cols, 3), np.float32); P[valid] = a["points"][:, :3]
+    x, y, z = P[..., 0], P[..., 1], P[..., 2]
+    planes = [x, y, z, valid.astype(np.float32), x * x, x * y, x * z, y * y, y * z, z * z]
+    I = [np.cumsum(np.cumsum(p, axis=1, dtype=np.float32), axis=0, dtype=np.float32) for p in planes]
+    rr, cc = np.nonzero(valid)
+    rad = np.clip(itv[rr, cc], conv["min_image_radius"], conv["max_image_radius"])
+    xmin, xmax = np.clip(cc - rad - 1, 0, cols - 1), np.clip(cc + rad - 1, 0, cols - 1)
+    ymin, ymax = np.clip(rr - rad - 1, 0, rows - 1), np.clip(rr + rad - 1, 0, rows - 1)
+    v = [((Ik[ymax, xmax] + Ik[ymin, xmin]) - Ik[ymax, xmin]) - Ik[ymin, xmax] for Ik in I]       # pa = I(xmax,ymax); += I(xmin,ymin); -= I(xmin,ymax); -= I(xmax,ymin)
+    n = v[3].astype(np.int32)
+    has = n >= conv["min_points"]
+    assert np.array_equal(a["npoints"], np.where(has, n, 0))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        d = f32(1.0) / v[3]
+    mean = [v[k] * d for k in range(3)]
+    gmean = a["stats"][:, 12:15]
+    for k in range(3):
+        assert np.array_equal(gmean[has, k].view(np.uint32), mean[k][has].astype(np.float32).view(np.uint32)), k
+    cov = np.zeros((len(n), 3, 3), np.float64)
+    ent = {(0, 0): v[4] * d - mean[0] * mean[0], (1, 0): v[5] * d - mean[1] * mean[0], (2, 0): v[6] * d - mean[2] * mean[0],
+           (1, 1): v[7] * d - mean[1] * mean[1], (2, 1): v[8] * d - mean[2] * mean[1], (2, 2): v[9] * d - mean[2] * mean[2]}
+    for (i, j), e in ent.items():
+        cov[:, i, j] = e; cov[:, j, i] = e
+    sel = np.nonzero(has)[0]
+    w, V = np.linalg.eigh(cov[sel])
+    gev = a["eigenvalues"][sel].astype(np.float64)
+    lam = np.abs(w).max(1)
+    e0 = np.abs(np.maximum(w[:, 0], 0) - gev[:, 0]) / (lam + 1e-12); e12 = np.abs(w[:, 1:] - gev[:, 1:]).max(1) / (lam + 1e-12)
+    print(f"eigenvalues vs LAPACK: worst |d lambda0| / lambda_max {e0.max():.1e}, worst |d lambda1,2| / lambda_max {e12.max():.1e}")
+    assert e0.max() <= EIG_TOL and e12.max() <= EIG_TOL
+    nrm = a["normals"][sel, :3].astype(np.float64)
+    nz = np.abs(nrm).sum(1) > 0
+    gap = w[:, 1] - w[:, 0]
+    good = nz & (gap > 1e-3 * lam)
+    ang = np.arccos(np.clip(np.abs((nrm[good] * V[good, :, 0]).sum(1)), -1, 1))
+    tol = 1.5e-4 * lam[good] / gap[good] + 1e-3          # the closed-form solver's accuracy (Eigen documents computeDirect as less accurate than the iterative solver)
+    assert good.sum() > 2000 and (ang <= tol).all(), (int(good.sum()), float(ang.max()), float((ang / tol).max()))
+    # orientation: towards the sensor (normal . point <= 0)
+    assert ((nrm[nz] * a["points"][sel][nz, :3]).sum(1) <= 0).all()
+    print(f"stats vs numpy fp32 + LAPACK: {int(has.sum())} windows (count and mean bit-exact), {int(good.sum())} normals, median angle {np.median(ang):.1e}, worst {ang.max():.1e} rad "
+          f"(worst angle / tolerance {float((ang / tol).max()):.2f})")
+    c.close()
