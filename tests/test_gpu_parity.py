@@ -1051,6 +1051,29 @@ def test_gpu_stats_against_numpy_fp32_sums_and_lapack():
     assert good.sum() > 2000 and (ang <= tol).all(), (int(good.sum()), float(ang.max()), float((ang / tol).max()))
     # orientation: towards the sensor (normal . point <= 0)
     assert ((nrm[nz] * a["points"][sel][nz, :3]).sum(1) <= 0).all()
+    # what follows the eigen-solve, from the GPU's own eigenvalues / eigenvectors, in numpy with the reference's operations: curvature
+    # (stats.h:98-103: fp32 sum, double + 1e-9 and division, rounded to float), the normal's survival (statscalculatorintegralimage.cpp:72-78), the
+    # point information matrix U diag U^T of informationmatrixcalculator.cpp:9-36 with its 1 / eigenvalue branch, the class of the normal one -- bit for bit
+    ev = a["eigenvalues"][sel]
+    U = a["stats"][sel].reshape(-1, 4, 4).transpose(0, 2, 1)[:, :3, :3]                      # column-major 4x4 -> U[:, i, k]
+    curv = (ev[:, 0].astype(np.float64) / ((ev[:, 0] + ev[:, 1] + ev[:, 2]).astype(np.float32).astype(np.float64) + 1e-9)).astype(np.float32)
+    assert np.array_equal(a["curvature"][sel].view(np.uint32), curv.view(np.uint32))
+    keep = curv < f32(conv["stats_curvature_threshold"])
+    assert np.array_equal(nz, keep)
+    n0 = U[:, :, 0]
+    assert np.array_equal(np.abs(a["normals"][sel][keep, :3]).view(np.uint32), np.abs(n0[keep]).view(np.uint32))      # column 0, sign by the flip
+    flat = curv < f32(conv["point_info_curvature_threshold"])
+    with np.errstate(divide="ignore"):
+        dg = np.where(flat[:, None], np.array([1000.0, 1.0, 1.0], np.float32)[None, :], f32(1.0) / ev).astype(np.float32)
+    om = np.zeros((len(sel), 3, 3), np.float32)
+    for i in range(3):
+        for j in range(3):
+            om[:, i, j] = ((U[:, i, 0] * dg[:, 0]) * U[:, j, 0] + (U[:, i, 1] * dg[:, 1]) * U[:, j, 1]) + (U[:, i, 2] * dg[:, 2]) * U[:, j, 2]
+    gom = a["omega_p"][sel].reshape(-1, 4, 4).transpose(0, 2, 1)[:, :3, :3]
+    assert np.array_equal(gom[keep].view(np.uint32), om[keep].view(np.uint32)) and not gom[~keep].any()
+    gon = a["omega_n"][sel].reshape(-1, 4, 4).transpose(0, 2, 1)[:, :3, :3]
+    want_n = np.where((curv < f32(conv["normal_info_curvature_threshold"]))[:, None, None], np.eye(3, dtype=np.float32) * f32(100.0), np.eye(3, dtype=np.float32))
+    assert np.array_equal(gon[keep], want_n[keep]) and not gon[~keep].any()
     print(f"stats vs numpy fp32 + LAPACK: {int(has.sum())} windows (count and mean bit-exact), {int(good.sum())} normals, median angle {np.median(ang):.1e}, worst {ang.max():.1e} rad "
           f"(worst angle / tolerance {float((ang / tol).max()):.2f})")
     c.close()
