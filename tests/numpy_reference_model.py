@@ -1,0 +1,96 @@
+"""A third, independent statement of the aligner half of the path: numpy, written from the reference's source lines (cited), sharing no code
+with oracle/ -- used by tests/test_gpu_parity.py to check the GPU without the oracle in between.  Integer-valued results (index images,
+correspondence lists) are produced with the same fp32 operations as the reference and must match the GPU exactly; the least-squares sums are
+float64 (the bar for them is a tolerance).  Test infrastructure only."""
+import numpy as np
+
+f32 = np.float32
+
+
+def roundf(a):
+    """C roundf: half away from zero, exactly"""
+    t = np.trunc(a); fr = a - t
+    return np.where(fr >= f32(0.5), t + 1, np.where(fr <= f32(-0.5), t - 1, t)).astype(np.float32)
+
+
+def project(P, KRt, min_d, max_d, rows, cols):
+    """PinholePointProjector::project (pinholepointprojector.cpp:33-66, .h:224-233): index + depth image; nearest point per pixel, ties keep the
+    lower index (the sequential loop's strict '>').  P [n,3] float32, KRt row-major 4x4 float32."""
+    x, y, z = P[:, 0], P[:, 1], P[:, 2]
+    def row(r): return ((KRt[r, 0] * x + KRt[r, 1] * y) + KRt[r, 2] * z) + KRt[r, 3] * f32(1.0)
+    ix, iy, d = row(0), row(1), row(2)
+    ok = ~((d < f32(min_d)) | (d > f32(max_d)))
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = f32(1.0) / d
+        rx, ry = roundf(ix * inv), roundf(iy * inv)
+        ok &= (rx >= 0) & (rx < cols) & (ry >= 0) & (ry < rows)
+    idx = np.nonzero(ok)[0]
+    pix = ry[idx].astype(np.int64) * cols + rx[idx].astype(np.int64)
+    order = np.lexsort((idx, d[idx], pix))
+    pix_s, idx_s = pix[order], idx[order]
+    first = np.ones(len(pix_s), bool); first[1:] = pix_s[1:] != pix_s[:-1]
+    wi = np.full(rows * cols, -1, np.int32); wd = np.full(rows * cols, np.finfo(np.float32).max, np.float32)
+    wi[pix_s[first]] = idx_s[first]; wd[pix_s[first]] = d[idx_s[first]]
+    return wi.reshape(rows, cols), wd.reshape(rows, cols)
+
+
+def _sq3(a):
+    return (a[:, 0] * a[:, 0] + a[:, 1] * a[:, 1]) + a[:, 2] * a[:, 2]
+
+
+def _iso(T, p, w):
+    """Isometry3f * Vector4f with left-to-right fp32 sums"""
+    return np.stack([((T[k, 0] * p[:, 0] + T[k, 1] * p[:, 1]) + T[k, 2] * p[:, 2]) + T[k, 3] * f32(w) for k in range(3)], 1)
+
+
+def correspondences(ref, cur, ref_index, cur_index, T, normal_thr, dist_thr, flat_thr, ratio_thr):
+    """CorrespondenceFinder::compute (correspondencefinder.cpp:45-106), one thread: (list [C,2] in row-major pixel order, K)"""
+    r_i, c_i = ref_index.reshape(-1), cur_index.reshape(-1)
+    cand = (r_i >= 0) & (c_i >= 0)
+    rI, cI = r_i[cand], c_i[cand]
+    rP, rN, cP, cN = ref["points"][rI], ref["normals"][rI], cur["points"][cI], cur["normals"][cI]
+    ok = (_sq3(cN) != 0) & (_sq3(rN) != 0)
+    rp, rn = _iso(T, rP, 1.0), _iso(T, rN, 0.0)
+    ok &= ~(((cN[:, 0] * rn[:, 0] + cN[:, 1] * rn[:, 1]) + cN[:, 2] * rn[:, 2]) < f32(normal_thr))
+    ok &= ~(_sq3(cP[:, :3] - rp) > f32(dist_thr) * f32(dist_thr))
+    rc = np.maximum(ref["curvature"][rI], f32(flat_thr)); cc = np.maximum(cur["curvature"][cI], f32(flat_thr))
+    ratio = ((rc.astype(np.float64) + 1e-5) / (cc.astype(np.float64) + 1e-5)).astype(np.float32)
+    mx = f32(ratio_thr); mn = f32(1.0) / mx
+    ok &= ~((ratio < mn) | (ratio > mx))
+    return np.stack([rI[ok], cI[ok]], 1).astype(np.int32), int(cand.sum())
+
+
+def _skew(v):
+    """bm_se3.h:54-66: S = -2 [v]x  (n, 3, 3)"""
+    S = np.zeros((len(v), 3, 3))
+    S[:, 0, 1] = 2 * v[:, 2]; S[:, 1, 0] = -2 * v[:, 2]
+    S[:, 0, 2] = -2 * v[:, 1]; S[:, 2, 0] = 2 * v[:, 1]
+    S[:, 1, 2] = 2 * v[:, 0]; S[:, 2, 1] = -2 * v[:, 0]
+    return S
+
+
+def linearize(ref, cur, corr, invT, max_chi2, robust=True):
+    """Linearizer::update (linearizer.cpp:33-114) in float64 from the fp32 clouds: H, b, chi2, inliers"""
+    T = np.asarray(invT, np.float64)
+    ri, ci = corr[:, 0], corr[:, 1]
+    rp = ref["points"][ri, :3].astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+    rn = ref["normals"][ri, :3].astype(np.float64) @ T[:3, :3].T
+    pe = rp - cur["points"][ci, :3]; ne = rn - cur["normals"][ci, :3]
+    oP = cur["omega_p"][ci].reshape(-1, 4, 4).transpose(0, 2, 1)[:, :3, :3].astype(np.float64)
+    oN = cur["omega_n"][ci].reshape(-1, 4, 4).transpose(0, 2, 1)[:, :3, :3].astype(np.float64)
+    ep = np.einsum("nij,nj->ni", oP, pe); en = np.einsum("nij,nj->ni", oN, ne)
+    le = (pe * ep).sum(1) + (ne * en).sum(1)
+    k = np.ones(len(le))
+    over = le > max_chi2
+    if robust:
+        k[over] = np.sqrt(max_chi2 / le[over]); keep = np.ones(len(le), bool)
+    else:
+        keep = ~over
+    Sp, Sn = _skew(rp), _skew(rn)
+    Htt = oP[keep].sum(0)
+    Htr = np.einsum("nij,njk->ik", oP[keep], Sp[keep])
+    Hrr = np.einsum("nji,njk,nkl->il", Sp[keep], oP[keep], Sp[keep]) + np.einsum("nji,njk,nkl->il", Sn[keep], oN[keep], Sn[keep])
+    bt = (k[keep, None] * ep[keep]).sum(0)
+    br = (k[keep, None] * (np.einsum("nji,nj->ni", Sp[keep], ep[keep]) + np.einsum("nji,nj->ni", Sn[keep], en[keep]))).sum(0)
+    H = np.zeros((6, 6)); H[:3, :3] = Htt; H[:3, 3:] = Htr; H[3:, 3:] = Hrr; H[3:, :3] = Htr.T
+    return H, np.concatenate([bt, br]), float((k[keep] * le[keep]).sum()), int(keep.sum())

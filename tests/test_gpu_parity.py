@@ -1077,3 +1077,54 @@ def test_gpu_stats_against_numpy_fp32_sums_and_lapack():
     print(f"stats vs numpy fp32 + LAPACK: {int(has.sum())} windows (count and mean bit-exact), {int(good.sum())} normals, median angle {np.median(ang):.1e}, worst {ang.max():.1e} rad "
           f"(worst angle / tolerance {float((ang / tol).max()):.2f})")
     c.close()
+
+
+@pytest.mark.parametrize("name,seed", [("small", 37), ("vga", 5)])
+def test_gpu_alignment_against_the_numpy_model(name, seed):
+    """Aligner::align (aligner.cpp:49-125) on the GPU against tests/numpy_reference_model.py -- a numpy statement of projector, finder, linearizer and
+    Gauss-Newton step written from the reference's source lines, no oracle anywhere: ten iterations, the model leads (the GPU runs every iteration from
+    the model's iterate T_i): index images bit for bit, K_i / C_i / inliers_i equal, chi2_i within 1e-5 of the model's float64 sums, and the pose the
+    GPU's own 6x6 step arrives at (H + 1001 I, LDL^T, v2t, t2v) within 5e-6 of the model's float64 step."""
+    from g2o_frontend_amd import api, synth
+    import numpy_reference_model as M
+    rows, cols, K, conv, alig = case_params(name)
+    c = api.Context(0, rows, cols, 2)
+    proj, converter, aligner = gpu_objects(c, name)
+    ref_mm, cur_mm, Ttrue = synth.make_pair(seed, rows, cols, K)
+    gr, gc = api.Cloud(c, rows * cols), api.Cloud(c, rows * cols)
+    converter.compute(gr, c.DepthImage_convert_16UC1_to_32FC1(ref_mm)); converter.compute(gc, c.DepthImage_convert_16UC1_to_32FC1(cur_mm))
+    A, B = gr.arrays(), gc.arrays()
+    aligner.setReferenceCloud(gr); aligner.setCurrentCloud(gc); aligner.setOuterIterations(1)
+    proj.setImageSize(rows, cols)
+    proj.setTransform(np.eye(4, dtype=np.float32))
+    cur_index, _ = M.project(B["points"][:, :3], proj.matrices()[0], alig["min_distance"], alig["max_distance"], rows, cols)      # aligner.cpp:60-64
+    T = np.eye(4, dtype=np.float32)
+    worst_chi2 = worst_step = 0.0
+    for it in range(10):
+        T[3] = (0, 0, 0, 1)                                                                                   # :72
+        proj.setTransform(T)
+        ref_index, ref_depth = M.project(A["points"][:, :3], proj.matrices()[0], alig["min_distance"], alig["max_distance"], rows, cols)   # :73-76
+        Tinv = api.iso_inverse(T)                                                                             # :79 (Isometry3f::inverse in fp32)
+        corr, Kc = M.correspondences(A, B, ref_index, cur_index, Tinv, alig["inlier_normal_angular_threshold"], alig["inlier_distance_threshold"],
+                                     alig["flat_curvature_threshold"], alig["inlier_curvature_ratio_threshold"])
+        H, b, chi2, inl = M.linearize(A, B, corr, Tinv, alig["inlier_max_chi2"], bool(alig["robust_kernel"]))   # :84-91
+        dx = np.linalg.solve(H + 1001.0 * np.eye(6), -b)                                                      # :92-94,110
+        invT = api.iso_mul(api.v2t(dx.astype(np.float32)), Tinv)                                              # :111-112
+        Tn = api.v2t(api.t2v(api.iso_inverse(invT)))                                                          # :115-116
+        # the GPU, one outer iteration from the model's iterate
+        aligner.setInitialGuess(T)
+        g = aligner.align(images=True)
+        f = aligner.correspondenceFinder()
+        assert np.array_equal(f.referenceIndexImage(), ref_index) and np.array_equal(f.currentIndexImage(), cur_index), it
+        assert np.array_equal(f.referenceDepthImage().view(np.uint32), ref_depth.view(np.uint32)), it
+        assert (int(g["K"][0]), int(g["C"][0]), int(g["iter_inliers"][0])) == (Kc, len(corr), inl), (it, g["K"][0], Kc, g["C"][0], len(corr))
+        rel = abs(float(g["chi2"][0]) - chi2) / chi2
+        assert rel <= CHI2_RTOL, (it, rel)
+        step = float(np.abs(g["T"] - Tn).max())
+        assert step <= 5e-6, (it, step)
+        worst_chi2, worst_step = max(worst_chi2, rel), max(worst_step, step)
+        T = Tn.astype(np.float32)
+    assert np.abs(T[:3, 3] - Ttrue[:3, 3]).max() < 5e-3                    # the model itself converges to the synthetic motion
+    print(f"GPU vs numpy model of Aligner::align ({name}): 10 iterations, index images bit-exact, counters equal, worst chi2 rel diff {worst_chi2:.1e}, "
+          f"worst |T_next - model| {worst_step:.1e}")
+    c.close()
