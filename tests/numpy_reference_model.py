@@ -94,3 +94,92 @@ def linearize(ref, cur, corr, invT, max_chi2, robust=True):
     br = (k[keep, None] * (np.einsum("nji,nj->ni", Sp[keep], ep[keep]) + np.einsum("nji,nj->ni", Sn[keep], en[keep]))).sum(0)
     H = np.zeros((6, 6)); H[:3, :3] = Htt; H[:3, 3:] = Htr; H[3:, 3:] = Hrr; H[3:, :3] = Htr.T
     return H, np.concatenate([bt, br]), float((k[keep] * le[keep]).sum()), int(keep.sum())
+
+
+# ---------------------------------------------------------------------------------------------------------------- projector matrices, converter
+def _mm3(A, B):
+    """3x3 (or 3x3 . 3xk) fp32 product with left-to-right inner products"""
+    A = np.asarray(A, np.float32); B = np.asarray(B, np.float32)
+    out = np.empty((3, B.shape[1]), np.float32)
+    for i in range(3):
+        for j in range(B.shape[1]):
+            out[i, j] = f32(f32(f32(A[i, 0] * B[0, j]) + f32(A[i, 1] * B[1, j])) + f32(A[i, 2] * B[2, j]))
+    return out
+
+
+def inverse3(m):
+    """Eigen's Matrix3f::inverse() (compute_inverse<.., 3>: cofactors of the first column, det = (c0 * m00 + c1 * m10) + c2 * m20, the adjugate
+    times 1 / det), every operation fp32"""
+    m = np.asarray(m, np.float32)
+    def cof(i, j):
+        i1, i2, j1, j2 = (i + 1) % 3, (i + 2) % 3, (j + 1) % 3, (j + 2) % 3
+        return f32(f32(m[i1, j1] * m[i2, j2]) - f32(m[i1, j2] * m[i2, j1]))
+    c0 = [cof(0, 0), cof(1, 0), cof(2, 0)]
+    det = f32(f32(f32(c0[0] * m[0, 0]) + f32(c0[1] * m[1, 0])) + f32(c0[2] * m[2, 0]))
+    invdet = f32(1.0) / det
+    r = np.empty((3, 3), np.float32)
+    for i in range(3):
+        for j in range(3):
+            r[i, j] = f32(cof(j, i) * invdet)
+    return r
+
+
+def projector_matrices(K, T):
+    """PinholePointProjector::_updateMatrices (pinholepointprojector.cpp:17-31): KRt = [K R' | K t'] with (R', t') = inverse(T) = (R^T, -R^T t);
+    iKRt = [R iK | t].  K = (fx, fy, cx, cy)."""
+    fx, fy, cx, cy = [f32(k) for k in K]
+    Km = np.array([[fx, 0, cx], [0, fy, cy], [0, 0, 1]], np.float32)
+    T = np.asarray(T, np.float32)
+    Rt = T[:3, :3].T.copy()
+    tp = _mm3(-Rt, T[:3, 3:4])
+    KRt = np.eye(4, dtype=np.float32); KRt[:3, :3] = _mm3(Km, Rt); KRt[:3, 3:4] = _mm3(Km, tp)
+    iK = inverse3(Km)                                                  # _iK = _cameraMatrix.inverse(): Eigen's 3x3 cofactor inverse
+    iKRt = np.eye(4, dtype=np.float32); iKRt[:3, :3] = _mm3(T[:3, :3], iK); iKRt[:3, 3] = T[:3, 3]
+    return KRt, iKRt, iK
+
+
+def unproject(depth, iKRt, min_d, max_d):
+    """PinholePointProjector::unProject (pinholepointprojector.cpp:93-133, .h:246-251): (valid mask, x, y, z images); a valid pixel's point index is
+    its row-major rank"""
+    rows, cols = depth.shape
+    valid = ~((depth < f32(min_d)) | (depth > f32(max_d)))
+    cc, rr = np.meshgrid(np.arange(cols, dtype=np.float32), np.arange(rows, dtype=np.float32))
+    a, b, d = cc * depth, rr * depth, depth
+    def row(k): return ((iKRt[k, 0] * a + iKRt[k, 1] * b) + iKRt[k, 2] * d) + iKRt[k, 3] * f32(1.0)
+    x, y, z = [np.where(valid, row(k), f32(0)).astype(np.float32) for k in range(3)]
+    return valid, x, y, z
+
+
+def integral_planes(valid, x, y, z):
+    """PointIntegralImage::compute (pointintegralimage.cpp:7-44): the ten distinct sums, sequential fp32 prefix along image x, then along image y"""
+    planes = [x, y, z, valid.astype(np.float32), x * x, x * y, x * z, y * y, y * z, z * z]
+    return [np.cumsum(np.cumsum(p.astype(np.float32), axis=1, dtype=np.float32), axis=0, dtype=np.float32) for p in planes]
+
+
+def intervals(depth, valid, K, world_radius):
+    """projectIntervals (pinholepointprojector.cpp:135-147, .h:264-274): int(max(fx R / d, fy R / d)) with p = K (R, R, 0) * (1 / d)"""
+    fx, fy = f32(K[0]), f32(K[1]); R = f32(world_radius)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        inv = f32(1.0) / np.where(valid, depth, f32(1.0))
+        px, py = (fx * R) * inv, (fy * R) * inv
+        return np.where(valid, np.where(px > py, px, py).astype(np.int32), -1)
+
+
+def window_sums(I, itv, valid, min_radius, max_radius):
+    """getRegion (pointintegralimage.cpp:53-66) for every valid pixel in row-major order: the ten sums ((A + B) - C) - D in that order"""
+    rows, cols = valid.shape
+    rr, cc = np.nonzero(valid)
+    rad = np.clip(itv[rr, cc], min_radius, max_radius)
+    xmin, xmax = np.clip(cc - rad - 1, 0, cols - 1), np.clip(cc + rad - 1, 0, cols - 1)
+    ymin, ymax = np.clip(rr - rad - 1, 0, rows - 1), np.clip(rr + rad - 1, 0, rows - 1)
+    return [((Ik[ymax, xmax] + Ik[ymin, xmin]) - Ik[ymax, xmin]) - Ik[ymin, xmax] for Ik in I]
+
+
+def mean_and_covariance(v):
+    """PointAccumulator::mean / covariance (pointaccumulator.h:66-86), fp32: (n, mean[3], the six lower-triangle covariance entries)"""
+    with np.errstate(divide="ignore", invalid="ignore"):
+        d = f32(1.0) / v[3]
+        mean = [v[k] * d for k in range(3)]
+        cov = {(0, 0): v[4] * d - mean[0] * mean[0], (1, 0): v[5] * d - mean[1] * mean[0], (2, 0): v[6] * d - mean[2] * mean[0],
+               (1, 1): v[7] * d - mean[1] * mean[1], (2, 1): v[8] * d - mean[2] * mean[1], (2, 2): v[9] * d - mean[2] * mean[2]}
+    return v[3].astype(np.int32), mean, cov
