@@ -183,3 +183,54 @@ def mean_and_covariance(v):
         cov = {(0, 0): v[4] * d - mean[0] * mean[0], (1, 0): v[5] * d - mean[1] * mean[0], (2, 0): v[6] * d - mean[2] * mean[0],
                (1, 1): v[7] * d - mean[1] * mean[1], (2, 1): v[8] * d - mean[2] * mean[1], (2, 2): v[9] * d - mean[2] * mean[2]}
     return v[3].astype(np.int32), mean, cov
+
+
+# ---------------------------------------------------------------------------------------------------------------- depth helpers, matchClouds score
+def depth_16u_to_32f(raw, scale=0.001):
+    """DepthImage_convert_16UC1_to_32FC1 (pwn_static.cpp:54-68): scale * raw where raw != 0, else 0"""
+    raw = np.asarray(raw, np.uint16)
+    return np.where(raw != 0, f32(scale) * raw.astype(np.float32), f32(0)).astype(np.float32)
+
+
+def depth_32f_to_16u(img, scale=1000.0):
+    """DepthImage_convert_32FC1_to_16UC1 (pwn_static.cpp:38-52): (unsigned short)(scale * f) where f < FLT_MAX, else 0"""
+    img = np.asarray(img, np.float32)
+    fin = img < np.finfo(np.float32).max
+    return np.where(fin, (f32(scale) * np.where(fin, img, f32(0))).astype(np.int64), 0).astype(np.uint16)
+
+
+def depth_scale(src, step, max_depth_cov=0.01):
+    """DepthImage_scale (pwn_static.cpp:5-36): block mean of ALL pixels of a step x step block over the count of its positive ones, dropped when
+    acc2 / np - mu * mu > maxDepthCov; fp32 accumulation in the loop's order (i over rows, j over columns)"""
+    src = np.asarray(src, np.float32)
+    rows, cols = src.shape[0] // step, src.shape[1] // step
+    acc = np.zeros((rows, cols), np.float32); acc2 = np.zeros((rows, cols), np.float32); cnt = np.zeros((rows, cols), np.int32)
+    for i in range(step):
+        for j in range(step):
+            blk = src[i:rows * step:step, j:cols * step:step][:rows, :cols]
+            acc = acc + blk; acc2 = acc2 + blk * blk; cnt += (blk > 0)
+    out = np.zeros((rows, cols), np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        npf = cnt.astype(np.float32)
+        mu = acc / npf
+        sigma = acc2 / npf - mu * mu
+    ok = (cnt > 0) & ~(sigma > f32(max_depth_cov))
+    out[ok] = mu[ok]
+    return out
+
+
+def match_score(ref_depth, cur_depth, threshold=50.0):
+    """PwnMatcherBase::matchClouds' depth-agreement score (pwn_tracker/pwn_matcher_base.cpp:153-182): both finder depth images to uint16 millimetres,
+    mask = both > 0, diff = abs(cur - ref) BITWISE-ANDed with the float mask 255.0f (what cv::Mat's operator& does on CV_32F data), inliers = masked
+    and diff < threshold, sum over ALL pixels in row-major order (fp32), distance = sum / nonZeros"""
+    cur = depth_32f_to_16u(cur_depth).astype(np.float32); ref = depth_32f_to_16u(ref_depth).astype(np.float32)
+    mask = (cur > 0) & (ref > 0)
+    ad = np.abs(cur - ref).astype(np.float32)
+    bits = ad.view(np.uint32) & np.where(mask, np.uint32(0x437F0000), np.uint32(0))
+    diff = bits.view(np.float32)
+    non_zeros = int(mask.sum())
+    inliers = int((mask & (diff < f32(threshold))).sum())
+    total = np.cumsum(diff.reshape(-1), dtype=np.float32)[-1]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        dist = float(f32(total) / f32(non_zeros))
+    return dict(image_nonZeros=non_zeros, image_inliers=inliers, image_outliers=non_zeros - inliers, image_reprojectionDistance=dist)

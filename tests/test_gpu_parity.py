@@ -1128,3 +1128,40 @@ def test_gpu_alignment_against_the_numpy_model(name, seed):
     print(f"GPU vs numpy model of Aligner::align ({name}): 10 iterations, index images bit-exact, counters equal, worst chi2 rel diff {worst_chi2:.1e}, "
           f"worst |T_next - model| {worst_step:.1e}")
     c.close()
+
+
+def test_gpu_depth_helpers_and_match_score_against_the_numpy_model():
+    """pwn_static.cpp's depth helpers and PwnMatcherBase::matchClouds' depth-agreement score (pwn_matcher_base.cpp:153-182) on the GPU against
+    tests/numpy_reference_model.py (no oracle): conversions and DepthImage_scale bit for bit, the score's counts exactly (the float bitwise '&' with
+    the mask included), its mean distance to 1e-6."""
+    import ctypes as C
+    from g2o_frontend_amd import api, synth
+    from g2o_frontend_amd._lib import MatchResult
+    import numpy_reference_model as M
+    name = "small"
+    rows, cols, K, conv, alig = case_params(name)
+    big = api.Context(0, 480, 640, 2)
+    raw = synth.render_depth_mm(43, np.eye(4), 480, 640, synth.K_VGA)
+    d = big.DepthImage_convert_16UC1_to_32FC1(raw)
+    assert np.array_equal(d.view(np.uint32), M.depth_16u_to_32f(raw).view(np.uint32))
+    back = d.copy(); back[::7, ::5] = np.finfo(np.float32).max
+    assert np.array_equal(big.DepthImage_convert_32FC1_to_16UC1(back), M.depth_32f_to_16u(back))
+    for step in (2, 3, 4):
+        assert np.array_equal(big.DepthImage_scale(d, step).view(np.uint32), M.depth_scale(d, step).view(np.uint32)), step
+    big.close()
+    c = api.Context(0, rows, cols, 2)
+    _, converter, aligner = gpu_objects(c, name)
+    ref_mm, cur_mm, _ = synth.make_pair(45, rows, cols, K)
+    gr, gc = api.Cloud(c, rows * cols), api.Cloud(c, rows * cols)
+    converter.compute(gr, c.DepthImage_convert_16UC1_to_32FC1(ref_mm)); converter.compute(gc, c.DepthImage_convert_16UC1_to_32FC1(cur_mm))
+    aligner.setReferenceCloud(gr); aligner.setCurrentCloud(gc)
+    for outer, thr in ((1, 50.0), (10, 50.0), (3, 5.0)):
+        aligner.setOuterIterations(outer)
+        aligner.align(images=True)
+        f = aligner.correspondenceFinder()
+        m = MatchResult()
+        c.check(c._L.pwn_hip_match_score(c.h, thr, C.byref(m)))
+        w = M.match_score(f.referenceDepthImage(), f.currentDepthImage(), thr)
+        assert (m.image_non_zeros, m.image_inliers, m.image_outliers) == (w["image_nonZeros"], w["image_inliers"], w["image_outliers"]), (outer, thr)
+        assert abs(m.image_reprojection_distance - w["image_reprojectionDistance"]) <= 1e-6 * w["image_reprojectionDistance"] + 1e-7
+    c.close()

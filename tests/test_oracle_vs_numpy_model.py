@@ -123,3 +123,24 @@ def test_alignment_teacher_forced_by_the_model(oracle, scene):
         assert np.abs(o["T"] - Tn).max() <= 5e-6, it
         T = Tn.astype(np.float32)
     assert np.abs(T[:3, 3] - s["Ttrue"][:3, 3]).max() < 5e-3
+
+
+def test_depth_helpers_and_match_score(oracle, scene):
+    from g2o_frontend_amd import synth
+    s = scene; rows, cols = s["rows"], s["cols"]
+    raw = synth.render_depth_mm(43, np.eye(4), 480, 640, synth.K_VGA)
+    d = oracle.convert_16u_to_32f(raw)
+    assert np.array_equal(d.view(np.uint32), M.depth_16u_to_32f(raw).view(np.uint32))
+    back = d.copy(); back[::7, ::5] = np.finfo(np.float32).max
+    assert np.array_equal(oracle.convert_32f_to_16u(back), M.depth_32f_to_16u(back))
+    for step in (2, 3, 4):
+        assert np.array_equal(oracle.depth_scale(d, step).view(np.uint32), M.depth_scale(d, step).view(np.uint32)), step
+    # the score on the finder's depth images of two poses (FLT_MAX where nothing projects)
+    A = s["oref"].arrays(); B = s["ocur"].arrays(); alig = s["alig"]
+    _, cd = M.project(B["points"][:, :3], M.projector_matrices(s["K"], np.eye(4, dtype=np.float32))[0], alig["min_distance"], alig["max_distance"], rows, cols)
+    for v in ([0.0] * 6, [0.02, -0.01, 0.04, 0.01, 0.0, -0.01]):
+        T = synth.v2t(np.array(v)).astype(np.float32)
+        _, rd = M.project(A["points"][:, :3], M.projector_matrices(s["K"], T)[0], alig["min_distance"], alig["max_distance"], rows, cols)
+        o, m = oracle.match_score(rd, cd, 50.0), M.match_score(rd, cd, 50.0)
+        assert (o["image_nonZeros"], o["image_inliers"], o["image_outliers"]) == (m["image_nonZeros"], m["image_inliers"], m["image_outliers"]), v
+        assert abs(o["image_reprojectionDistance"] - m["image_reprojectionDistance"]) <= 1e-6 * abs(m["image_reprojectionDistance"]) + 1e-7, v
