@@ -1165,3 +1165,31 @@ def test_gpu_depth_helpers_and_match_score_against_the_numpy_model():
         assert (m.image_non_zeros, m.image_inliers, m.image_outliers) == (w["image_nonZeros"], w["image_inliers"], w["image_outliers"]), (outer, thr)
         assert abs(m.image_reprojection_distance - w["image_reprojectionDistance"]) <= 1e-6 * w["image_reprojectionDistance"] + 1e-7
     c.close()
+
+
+@pytest.mark.parametrize("name", ["small", "vga", "kinect"])
+def test_gpu_whole_converter_against_the_numpy_model(name):
+    """DepthImageConverterIntegralImage::compute on the GPU against the numpy model's complete converter (tests/numpy_reference_model.py: written from
+    the reference's source lines, Eigen's computeDirect included; no oracle): every cloud array, the index and the interval image bit for bit -- single
+    frame (three-kernel path) and inside a 20-frame batch (single-pass strip kernel + k_stats), synthetic and real Kinect frames."""
+    from g2o_frontend_amd import api
+    import numpy_reference_model as M
+    from test_oracle_vs_numpy_model import _frames, _nz
+    rows, cols, K, conv, alig, ref_mm, cur_mm = _frames(name)
+    case = "vga" if name == "kinect" else name
+    c = api.Context(0, rows, cols, 32)
+    _, converter, _ = gpu_objects(c, case)
+    want = [M.convert(M.depth_16u_to_32f(f), K, conv) for f in (ref_mm, cur_mm)]
+    g = api.Cloud(c, rows * cols)
+    converter.compute(g, c.DepthImage_convert_16UC1_to_32FC1(ref_mm), keep_stats=True)
+    a = g.arrays(stats=True)
+    assert np.array_equal(converter.indexImage(), want[0]["index"]) and np.array_equal(converter.intervalImage(), want[0]["interval"])
+    for k in ("points", "normals", "curvature", "omega_p", "omega_n", "eigenvalues", "npoints"):
+        assert np.array_equal(_nz(a[k]), _nz(want[0][k])), (name, k)
+    many = [api.Cloud(c, rows * cols) for _ in range(20)]
+    converter.computeBatch(many, [ref_mm, cur_mm] * 10, raw_scale=0.001)
+    for i in (0, 1, 18, 19):
+        b = many[i].arrays()
+        for k in ("points", "normals", "curvature", "omega_p", "omega_n"):
+            assert np.array_equal(_nz(b[k]), _nz(want[i % 2][k])), (name, i, k)
+    c.close()

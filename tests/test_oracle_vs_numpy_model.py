@@ -144,3 +144,43 @@ def test_depth_helpers_and_match_score(oracle, scene):
         o, m = oracle.match_score(rd, cd, 50.0), M.match_score(rd, cd, 50.0)
         assert (o["image_nonZeros"], o["image_inliers"], o["image_outliers"]) == (m["image_nonZeros"], m["image_inliers"], m["image_outliers"]), v
         assert abs(o["image_reprojectionDistance"] - m["image_reprojectionDistance"]) <= 1e-6 * abs(m["image_reprojectionDistance"]) + 1e-7, v
+
+
+def _nz(a):
+    """bits with the sign of zero dropped (the reference's 4x4 products add exact-zero fourth terms: -0 + 0 = +0)"""
+    a = np.ascontiguousarray(a)
+    if a.dtype != np.float32:
+        return a
+    a = a.copy(); a[a == 0] = 0
+    return a.view(np.uint32)
+
+
+def _frames(name):
+    import os
+    from g2o_frontend_amd import synth
+    if name == "kinect":
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kinect_real_pair.npz"))
+        rows, cols, K, conv, alig = case_params("vga")
+        return rows, cols, K, conv, alig, z["ref_mm"], z["cur_mm"]
+    rows, cols, K, conv, alig = case_params(name)
+    ref_mm, cur_mm, _ = synth.make_pair(3, rows, cols, K)
+    return rows, cols, K, conv, alig, ref_mm, cur_mm
+
+
+@pytest.mark.parametrize("name", ["small", "vga", "kinect"])
+def test_whole_converter_bit_for_bit(oracle, name):
+    """DepthImageConverterIntegralImage::compute: every array the oracle produces against the numpy model's -- points, index and interval images,
+    window counts, eigenvalues (Eigen's computeDirect restated in numpy fp32), normals, curvature, both information matrices -- bit for bit, on a
+    synthetic frame at 120x160 and VGA and on a real Kinect frame of the reference repository (25 000 points on the 1 / eigenvalue branch of
+    informationmatrixcalculator.cpp:27-29)."""
+    rows, cols, K, conv, alig, ref_mm, _ = _frames(name)
+    depth = oracle.convert_16u_to_32f(ref_mm)
+    o, oidx, oitv = oracle.convert(oracle.converter_params(K=K, **conv), depth)
+    a = o.arrays(stats=True)
+    m = M.convert(depth, K, conv)
+    assert np.array_equal(oidx, m["index"]) and np.array_equal(oitv, m["interval"])
+    for k in ("points", "normals", "curvature", "omega_p", "omega_n", "eigenvalues", "npoints"):
+        assert np.array_equal(_nz(a[k]), _nz(m[k])), (name, k)
+    if name == "kinect":
+        flat = a["curvature"] < 0.02
+        assert int(((np.abs(a["normals"][:, :3]).sum(1) > 0) & ~flat).sum()) > 10000      # the non-flat branch is really exercised
