@@ -362,3 +362,51 @@ def convert(depth, K, conv, point_flat=(1000.0, 1.0, 1.0), normal_flat=100.0, no
     return dict(points=pts, normals=normals, curvature=curvature, omega_p=omega_p.transpose(0, 2, 1).reshape(Mn, 16).copy(),
                 omega_n=omega_n.transpose(0, 2, 1).reshape(Mn, 16).copy(), eigenvalues=ev, npoints=np.where(has, n, 0).astype(np.int32),
                 index=index, interval=itv)
+
+
+# ---------------------------------------------------------------------------------------------------------------- Aligner::_computeStatistics
+def _quat2mat(q):
+    qx, qy, qz = q; qw = np.sqrt(max(0.0, 1.0 - q @ q))
+    return np.array([[qw * qw + qx * qx - qy * qy - qz * qz, 2 * (qx * qy - qw * qz), 2 * (qx * qz + qw * qy)],
+                     [2 * (qx * qy + qz * qw), qw * qw - qx * qx + qy * qy - qz * qz, 2 * (qy * qz - qx * qw)],
+                     [2 * (qx * qz - qy * qw), 2 * (qy * qz + qx * qw), qw * qw - qx * qx - qy * qy + qz * qz]])
+
+
+def _v2t(x):
+    X = np.eye(4); X[:3, 3] = x[:3]; X[:3, :3] = _quat2mat(np.asarray(x[3:6], float)); return X
+
+
+def _t2v(X):
+    """bm_se3.h:45-52: translation + vector part of the normalised quaternion with w >= 0"""
+    R = X[:3, :3]; t = np.trace(R)
+    if t > 0:
+        s = np.sqrt(t + 1.0); w = 0.5 * s; s = 0.5 / s
+        q = np.array([(R[2, 1] - R[1, 2]) * s, (R[0, 2] - R[2, 0]) * s, (R[1, 0] - R[0, 1]) * s])
+    else:
+        i = int(np.argmax(np.diag(R))); j = (i + 1) % 3; k = (j + 1) % 3
+        s = np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0)
+        q = np.zeros(3); q[i] = 0.5 * s; s = 0.5 / s
+        w = (R[k, j] - R[j, k]) * s; q[j] = (R[j, i] + R[i, j]) * s; q[k] = (R[k, i] + R[i, k]) * s
+    nrm = np.sqrt(q @ q + w * w); q = q / nrm; w = w / nrm
+    return np.concatenate([X[:3, 3], -q if w < 0 else q])
+
+
+def compute_statistics(H, T):
+    """Aligner::_computeStatistics (aligner.cpp:152-199) from the linearizer's H and the final transform, float64: H + I, its inverse as the local
+    covariance, the unscented sigma points of unscented.h:23-47 (alpha 1e-3, beta 2) remapped by p -> t2v(T v2t(p)^-1), the Gaussian reconstructed
+    from them (unscented.h:49-65), Omega = covariance^-1 and the singular-value ratios of its two diagonal 3x3 blocks."""
+    H = np.asarray(H, np.float64) + np.eye(6); T = np.asarray(T, np.float64)
+    sigma = np.linalg.inv(H)
+    dim = 6; alpha, beta = 1e-3, 2.0
+    lam = alpha * alpha * dim
+    wi = 1.0 / (2.0 * (dim + lam))
+    L = np.linalg.cholesky(sigma * (dim + lam))
+    pts = [(np.zeros(6), lam / (dim + lam), lam / (dim + lam) + (1.0 - alpha * alpha + beta))]
+    for i in range(dim):
+        pts.append((L[:, i].copy(), wi, wi)); pts.append((-L[:, i], wi, wi))
+    samples = [(_t2v(T @ np.linalg.inv(_v2t(p))), a, b) for p, a, b in pts]
+    mean = sum(a * s for s, a, _ in samples)
+    cov = sum(b * np.outer(s - mean, s - mean) for s, _, b in samples)
+    omega = np.linalg.inv(cov)
+    sv_t = np.linalg.svd(omega[:3, :3], compute_uv=False); sv_r = np.linalg.svd(omega[3:, 3:], compute_uv=False)
+    return dict(mean=mean, omega=omega, translationalEigenRatio=sv_t[0] / sv_t[2], rotationalEigenRatio=sv_r[0] / sv_r[2])

@@ -184,3 +184,31 @@ def test_whole_converter_bit_for_bit(oracle, name):
     if name == "kinect":
         flat = a["curvature"] < 0.02
         assert int(((np.abs(a["normals"][:, :3]).sum(1) > 0) & ~flat).sum()) > 10000      # the non-flat branch is really exercised
+
+
+def test_compute_statistics_against_the_float64_model(oracle, scene):
+    """Aligner::_computeStatistics (aligner.cpp:152-199, unscented.h): the oracle's fp32 chain (JacobiSVD solve, LLT, sigma points, 6x6 inverse) and the
+    product's host function (pwn_hip_compute_statistics, no GPU needed) against the float64 numpy model on the H of real alignments and on disturbed
+    copies: mean 1e-6, omega 2e-4 of its largest entry, the two eigen ratios 1e-3."""
+    import ctypes as C
+    from g2o_frontend_amd import _lib
+    s = scene; rows, cols = s["rows"], s["cols"]
+    ap = oracle.aligner_params(rows, cols, K=s["K"], accumulate_fp64=1, **s["alig"])
+    o = oracle.align(ap, s["oref"], s["ocur"])
+    st = oracle.align_statistics(ap, s["oref"], s["ocur"], o["T"])
+    rng = np.random.default_rng(2)
+    for k in range(6):
+        H = st["H"].astype(np.float64)
+        if k:
+            E = rng.uniform(-1, 1, (6, 6)); H = H * (1.0 + 0.05 * (E + E.T) / 2) + np.diag(rng.uniform(0, 0.1, 6) * np.diag(H))
+        H = H.astype(np.float32)
+        m = M.compute_statistics(H, o["T"])
+        mean = np.empty(6, np.float32); om = np.empty(36, np.float32); tr, rr = C.c_float(0), C.c_float(0)
+        Hc = np.ascontiguousarray(H.T.reshape(-1), np.float32); Tc = np.ascontiguousarray(o["T"].T.reshape(-1), np.float32)
+        _lib.lib().pwn_hip_compute_statistics(Hc.ctypes.data_as(C.c_void_p), Tc.ctypes.data_as(C.c_void_p), mean.ctypes.data_as(C.c_void_p),
+                                             om.ctypes.data_as(C.c_void_p), C.byref(tr), C.byref(rr))
+        prod = dict(mean=mean, omega=om.reshape(6, 6).T, translationalEigenRatio=tr.value, rotationalEigenRatio=rr.value)
+        for got in (oracle.compute_statistics(H, o["T"]), prod):
+            assert np.abs(got["mean"] - m["mean"]).max() < 1e-6, k
+            assert np.abs(got["omega"] - m["omega"]).max() <= 2e-4 * np.abs(m["omega"]).max(), k
+            assert abs(got["translationalEigenRatio"] / m["translationalEigenRatio"] - 1) < 1e-3 and abs(got["rotationalEigenRatio"] / m["rotationalEigenRatio"] - 1) < 1e-3, k
