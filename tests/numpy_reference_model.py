@@ -410,3 +410,23 @@ def compute_statistics(H, T):
     omega = np.linalg.inv(cov)
     sv_t = np.linalg.svd(omega[:3, :3], compute_uv=False); sv_r = np.linalg.svd(omega[3:, 3:], compute_uv=False)
     return dict(mean=mean, omega=omega, translationalEigenRatio=sv_t[0] / sv_t[2], rotationalEigenRatio=sv_r[0] / sv_r[2])
+
+
+# ---------------------------------------------------------------------------------------------------------------- SE(3) priors
+def prior_terms(kind, mean, information, invT, reference_transform=None):
+    """SE3RelativePrior / SE3AbsolutePrior (se3_prior.cpp:8-71) as Aligner::align uses them (aligner.cpp:96-108), float64: error(invT) =
+    t2v(invT * [R^-1 *] mean); jacobian = central differences of error(v2t(+-eps e_i) * invT), eps = 1e-3; errorInformation = Jz^-T Omega Jz^-1 with
+    Jz the central differences of the error with the mean moved to mean * v2t(+-eps e_i).  Returns (Hp, bp) = (J^T I' J, J^T I' e)."""
+    mean = np.asarray(mean, np.float64); info = np.asarray(information, np.float64); invT = np.asarray(invT, np.float64)
+    pre = np.eye(4) if kind == 0 else np.linalg.inv(np.asarray(reference_transform, np.float64))
+    def err(iT, mu): return _t2v(iT @ pre @ mu)
+    eps = 1e-3
+    J = np.zeros((6, 6)); Jz = np.zeros((6, 6))
+    for i in range(6):
+        up = np.zeros(6); up[i] = eps
+        J[:, i] = (0.5 / eps) * (err(_v2t(up) @ invT, mean) - err(_v2t(-up) @ invT, mean))
+        Jz[:, i] = (0.5 / eps) * (err(invT, mean @ _v2t(up)) - err(invT, mean @ _v2t(-up)))
+    iJz = np.linalg.inv(Jz)
+    Ir = iJz.T @ info @ iJz
+    e = err(invT, mean)
+    return J.T @ Ir @ J, J.T @ Ir @ e

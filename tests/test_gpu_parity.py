@@ -1193,3 +1193,49 @@ def test_gpu_whole_converter_against_the_numpy_model(name):
         for k in ("points", "normals", "curvature", "omega_p", "omega_n"):
             assert np.array_equal(_nz(b[k]), _nz(want[i % 2][k])), (name, i, k)
     c.close()
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_gpu_alignment_with_priors_against_the_numpy_model(kind):
+    """Aligner::align with an SE(3) prior (aligner.cpp:96-108, se3_prior.cpp) on the GPU path (pwn_hip_align_with_priors) against the float64 numpy
+    model, the model leading: counters equal, the step of H + 1001 I + J^T I' J within 5e-6 (measured 1e-7; the reference's fp32 central differences, eps = 1e-3,
+    carry ~1e-4 of relative noise)."""
+    from g2o_frontend_amd import api, synth
+    import numpy_reference_model as M
+    name = "small"
+    rows, cols, K, conv, alig = case_params(name)
+    c = api.Context(0, rows, cols, 2)
+    proj, converter, aligner = gpu_objects(c, name)
+    ref_mm, cur_mm, Ttrue = synth.make_pair(41, rows, cols, K)
+    gr, gc = api.Cloud(c, rows * cols), api.Cloud(c, rows * cols)
+    converter.compute(gr, c.DepthImage_convert_16UC1_to_32FC1(ref_mm)); converter.compute(gc, c.DepthImage_convert_16UC1_to_32FC1(cur_mm))
+    A, B = gr.arrays(), gc.arrays()
+    aligner.setReferenceCloud(gr); aligner.setCurrentCloud(gc); aligner.setOuterIterations(1)
+    mean = synth.v2t(np.array([0.06, -0.03, -0.02, 0.01, -0.015, 0.01])).astype(np.float32)
+    reft = synth.v2t(np.array([0.02, 0.01, -0.01, 0.0, 0.01, 0.0])).astype(np.float32)
+    info = (np.diag([4e5, 4e5, 4e5, 2e6, 2e6, 2e6]) + 1e4).astype(np.float32)
+    if kind == 0:
+        aligner.addRelativePrior(mean, info)
+    else:
+        aligner.addAbsolutePrior(reft, mean, info)
+    cur_index, _ = M.project(B["points"][:, :3], M.projector_matrices(K, np.eye(4, dtype=np.float32))[0], alig["min_distance"], alig["max_distance"], rows, cols)
+    T = np.eye(4, dtype=np.float32); worst = 0.0
+    for it in range(6):
+        T[3] = (0, 0, 0, 1)
+        ref_index, _ = M.project(A["points"][:, :3], M.projector_matrices(K, T)[0], alig["min_distance"], alig["max_distance"], rows, cols)
+        Tinv = api.iso_inverse(T)
+        corr, Kc = M.correspondences(A, B, ref_index, cur_index, Tinv, alig["inlier_normal_angular_threshold"], alig["inlier_distance_threshold"],
+                                     alig["flat_curvature_threshold"], alig["inlier_curvature_ratio_threshold"])
+        H, b, chi2, inl = M.linearize(A, B, corr, Tinv, alig["inlier_max_chi2"], bool(alig["robust_kernel"]))
+        Hp, bp = M.prior_terms(kind, mean, info, Tinv, reft)
+        dx = np.linalg.solve(H + 1001.0 * np.eye(6) + Hp, -(b + bp))
+        Tn = api.v2t(api.t2v(api.iso_inverse(api.iso_mul(api.v2t(dx.astype(np.float32)), Tinv))))
+        aligner.setInitialGuess(T)
+        g = aligner.align()
+        assert (int(g["K"][0]), int(g["C"][0]), int(g["iter_inliers"][0])) == (Kc, len(corr), inl), it
+        assert abs(float(g["chi2"][0]) - chi2) <= CHI2_RTOL * chi2, it
+        d = float(np.abs(g["T"] - Tn).max()); worst = max(worst, d)
+        assert d <= 5e-6, (it, d)
+        T = Tn.astype(np.float32)
+    print(f"GPU align with a {'relative' if kind == 0 else 'absolute'} prior vs the numpy model: worst |T_next - model| {worst:.1e}")
+    c.close()

@@ -212,3 +212,43 @@ def test_compute_statistics_against_the_float64_model(oracle, scene):
             assert np.abs(got["mean"] - m["mean"]).max() < 1e-6, k
             assert np.abs(got["omega"] - m["omega"]).max() <= 2e-4 * np.abs(m["omega"]).max(), k
             assert abs(got["translationalEigenRatio"] / m["translationalEigenRatio"] - 1) < 1e-3 and abs(got["rotationalEigenRatio"] / m["rotationalEigenRatio"] - 1) < 1e-3, k
+
+
+@pytest.mark.parametrize("kind", [0, 1])
+def test_alignment_with_priors_teacher_forced_by_the_model(oracle, scene, kind):
+    """Aligner::align with an SE(3) prior (aligner.cpp:96-108, se3_prior.cpp:8-71), the model leads: every iteration of the oracle from the model's
+    iterate; the step of H + 1001 I + J^T I' J against the float64 model's (the reference's fp32 central differences with eps = 1e-3 carry ~1e-4 of
+    relative noise in J, hence the 5e-5 bar on the pose)."""
+    from g2o_frontend_amd import synth
+    s = scene; alig = s["alig"]; rows, cols = s["rows"], s["cols"]
+    A, B = s["oref"].arrays(), s["ocur"].arrays()
+    mean = synth.v2t(np.array([0.06, -0.03, -0.02, 0.01, -0.015, 0.01])).astype(np.float32)
+    reft = synth.v2t(np.array([0.02, 0.01, -0.01, 0.0, 0.01, 0.0])).astype(np.float32)
+    info = (np.diag([4e5, 4e5, 4e5, 2e6, 2e6, 2e6]) + 1e4).astype(np.float32)
+    oracle.clear_priors()
+    oracle.add_prior(kind, mean, info, reference_transform=reft if kind else None)
+    try:
+        cur_index, _ = M.project(B["points"][:, :3], M.projector_matrices(s["K"], np.eye(4, dtype=np.float32))[0], alig["min_distance"], alig["max_distance"], rows, cols)
+        T = np.eye(4, dtype=np.float32)
+        worst = 0.0
+        for it in range(6):
+            T[3] = (0, 0, 0, 1)
+            ref_index, _ = M.project(A["points"][:, :3], M.projector_matrices(s["K"], T)[0], alig["min_distance"], alig["max_distance"], rows, cols)
+            Tinv = oracle.iso_inverse(T)
+            corr, Kc = M.correspondences(A, B, ref_index, cur_index, Tinv, alig["inlier_normal_angular_threshold"], alig["inlier_distance_threshold"],
+                                         alig["flat_curvature_threshold"], alig["inlier_curvature_ratio_threshold"])
+            H, b, chi2, inl = M.linearize(A, B, corr, Tinv, alig["inlier_max_chi2"], bool(alig["robust_kernel"]))
+            Hp, bp = M.prior_terms(kind, mean, info, Tinv, reft)
+            dx = np.linalg.solve(H + 1001.0 * np.eye(6) + Hp, -(b + bp))
+            Tn = oracle.v2t(oracle.t2v(oracle.iso_inverse(oracle.iso_mul(oracle.v2t(dx.astype(np.float32)), Tinv))))
+            ap = oracle.aligner_params(rows, cols, K=s["K"], initial_guess=T, accumulate_fp64=1, **dict(alig, outer_iterations=1))
+            o = oracle.align(ap, s["oref"], s["ocur"])
+            i0 = o["iterations"][0]
+            assert (i0["K"], i0["C"], i0["inliers"]) == (Kc, len(corr), inl), it
+            worst = max(worst, float(np.abs(o["T"] - Tn).max()))
+            assert np.abs(o["T"] - Tn).max() <= 5e-5, (it, np.abs(o["T"] - Tn).max())
+            T = Tn.astype(np.float32)
+        # the prior is felt: the iterate sits between the free solution and the prior's mean
+        assert np.abs(T[:3, 3] - s["Ttrue"][:3, 3]).max() > 2e-3
+    finally:
+        oracle.clear_priors()
