@@ -581,6 +581,18 @@ def run_tracker(device, frames_mm, poses, scale=1):
            "keyframes": tracker.numKeyframes(), "final_translation_error_m": err,
            "stream": "synth.trajectory_sweep(9): +-28 deg pan with sway, <= 2 cm and <= 1 deg per frame",
            "input": "host float32 frames (PCIe upload inside the timed loop)"}
+    # the same stream with the next frame handed over one call ahead (a recorded / buffered stream: pwn_hip_convert_scaled_begin / _end):
+    # makeCloud of frame k+1 runs next to the alignment of frame k; results are the same bits
+    plainT, plainK = tracker.globalT().copy(), tracker.numKeyframes()
+    tracker.init()
+    tracker.prefetch(frames[0], I, Km); tracker.processFrame(frames[0], I, Km, nextDepthImage=frames[1]); tracker.init()      # warm-up: creates the helper context
+    t0 = time.perf_counter()
+    for k, d in enumerate(frames):
+        tracker.processFrame(d, I, Km, nextDepthImage=frames[k + 1] if k + 1 < len(frames) else None)
+    dt = time.perf_counter() - t0
+    out["look_ahead"] = {"frames_per_s": len(frames) / dt, "ms_per_frame": dt / len(frames) * 1e3,
+                         "bitwise_equal_to_plain": bool(np.array_equal(plainT.view(np.uint32), tracker.globalT().view(np.uint32)) and plainK == tracker.numKeyframes()),
+                         "note": "frame k+1 converted by the library's helper thread while frame k is aligned"}
     ctx.close()
     return out
 

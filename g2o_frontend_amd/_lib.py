@@ -97,6 +97,8 @@ PROTOTYPES = {
     "pwn_hip_integral_image": (_I, [_VP, _VP, _VP, _I, _I, _VP]),
     "pwn_hip_convert": (_I, [_VP, _VP, _VP, _I, _I, _VP, _VP, _VP, _I]),
     "pwn_hip_convert_scaled": (_I, [_VP, _VP, _VP, _I, _I, _I, _F, _VP]),
+    "pwn_hip_convert_scaled_begin": (_I, [_VP, _VP, _VP, _I, _I, _I, _F, _VP]),
+    "pwn_hip_convert_end": (_I, [_VP, _VP]),
     "pwn_hip_convert_batch": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP]),
     "pwn_hip_convert_batch_u16": (_I, [_VP, _VP, _VP, _F, _I, _I, _I, _VP]),
     "pwn_hip_project": (_I, [_VP, _VP, _VP, _F, _F, _I, _I, _VP, _VP, _VP]),

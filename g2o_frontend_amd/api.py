@@ -806,6 +806,33 @@ class PwnMatcherBase:
         self.numCalls += 1
         return cloud, projector.imageRows(), projector.imageCols(), projector.cameraMatrix().copy()
 
+    def makeCloudBegin(self, cameraMatrix, sensorOffset, depthImage, ctx: Context = None):
+        """makeCloud in two halves (pwn_hip_convert_scaled_begin / pwn_hip_convert_end): returns at once with a ticket, the frame is
+        converted by the library's helper thread next to whatever is run on the context meanwhile; makeCloudEnd(ticket) returns what
+        makeCloud would have returned -- the same bits.  One ticket at a time per context; `depthImage` must not change in between."""
+        ctx = ctx or self._aligner.ctx
+        projector = self._converter.projector()
+        invScale = np.float32(1.0) / np.float32(self._scale)
+        scaled = (np.asarray(cameraMatrix, np.float32).reshape(3, 3) * invScale).astype(np.float32)
+        scaled[2, 2] = 1.0
+        projector.setCameraMatrix(scaled)
+        depth = depthImage if hasattr(depthImage, "data_ptr") else np.ascontiguousarray(depthImage, np.float32)
+        rows, cols = depth.shape
+        r, c = rows // self._scale, cols // self._scale
+        projector.setImageSize(r, c)
+        cloud = Cloud(ctx, max(1, r * c))
+        projector.setTransform(np.eye(4, dtype=np.float32))
+        p = self._converter.params(sensorOffset)
+        ctx.check(ctx._L.pwn_hip_convert_scaled_begin(ctx.h, C.byref(p), _ptr(depth), rows, cols, self._scale, 0.01, cloud.h))
+        return dict(ctx=ctx, cloud=cloud, depth=depth, source=depthImage, out=(projector.imageRows(), projector.imageCols(), projector.cameraMatrix().copy()))
+
+    def makeCloudEnd(self, ticket):
+        ctx, cloud = ticket["ctx"], ticket["cloud"]
+        ctx.check(ctx._L.pwn_hip_convert_end(ctx.h, cloud.h))
+        self.numCalls += 1
+        ticket["depth"] = None
+        return (cloud,) + ticket["out"]
+
     def _configure(self, fromOffset, toOffset, toCameraMatrix, toRows, toCols, initialGuess):
         a = self._aligner
         projector = a.projector()
@@ -938,6 +965,7 @@ class PwnTracker(PwnMatcherBase):
         self._newFrameInliersFraction = 0.4          # pwn_tracker.cpp:36
         self._counter = 0
         self._numKeyframes = 0
+        self._ahead = None                           # prefetch(): (image, offset, K, ticket of makeCloudBegin)
 
     def globalT(self): return self._globalT
     def numKeyframes(self): return self._numKeyframes
@@ -945,16 +973,42 @@ class PwnTracker(PwnMatcherBase):
 
     def init(self):
         """pwn_tracker.cpp:38-49"""
+        self.dropPrefetched()
         self._previousCloud = None
         self._globalT = np.eye(4, dtype=np.float32); self._previousCloudTransform = np.eye(4, dtype=np.float32)
         self._counter = 0; self._numKeyframes = 0
 
-    def processFrame(self, depthImage, sensorOffset, cameraMatrix, initialGuess=None):
-        """pwn_tracker.cpp:106-215"""
+    def prefetch(self, depthImage, sensorOffset, cameraMatrix):
+        """Not in the reference: hand over the NEXT frame of a recorded / buffered stream before processFrame of the current one.  Its
+        makeCloud (pwn_tracker.cpp:115 -- independent of the alignment of the frames before it) then runs next to that alignment;
+        processFrame(depthImage, ...) of the very same image object and arguments picks the cloud up.  Same results, bit for bit."""
+        self.dropPrefetched()
+        off = np.asarray(sensorOffset, np.float32).copy(); Km = np.asarray(cameraMatrix, np.float32).copy()
+        self._ahead = (depthImage, off, Km, self.makeCloudBegin(Km, off, depthImage))
+
+    def dropPrefetched(self):
+        if self._ahead is not None:
+            ahead, self._ahead = self._ahead, None
+            self.makeCloudEnd(ahead[3])
+
+    def _currentCloud(self, cameraMatrix, sensorOffset, depthImage):
+        ahead = self._ahead
+        if ahead is not None and ahead[0] is depthImage and np.array_equal(ahead[1], sensorOffset) and \
+                np.array_equal(ahead[2], np.asarray(cameraMatrix, np.float32)):
+            self._ahead = None
+            return self.makeCloudEnd(ahead[3])
+        self.dropPrefetched()                                     # a different frame: the prefetched cloud is not this one's
+        return self.makeCloud(cameraMatrix, sensorOffset, depthImage)
+
+    def processFrame(self, depthImage, sensorOffset, cameraMatrix, initialGuess=None, nextDepthImage=None):
+        """pwn_tracker.cpp:106-215.  nextDepthImage (not in the reference): the frame the next call will bring; it is handed to prefetch()
+        once this frame's cloud exists, so that its conversion runs next to this frame's alignment."""
         a = self._aligner
         initialGuess = np.eye(4, dtype=np.float32) if initialGuess is None else np.asarray(initialGuess, np.float32)
         currentCloudOffset = np.asarray(sensorOffset, np.float32)
-        currentCloud, r, c, scaledCameraMatrix = self.makeCloud(cameraMatrix, currentCloudOffset, depthImage)     # :115
+        currentCloud, r, c, scaledCameraMatrix = self._currentCloud(cameraMatrix, currentCloudOffset, depthImage)     # :115
+        if nextDepthImage is not None:
+            self.prefetch(nextDepthImage, currentCloudOffset, cameraMatrix)
         out = dict(newFrame=False, aligned=False, inliers=0, error=0.0, T=None)
         if self._previousCloud is not None:
             a.setCurrentSensorOffset(currentCloudOffset); a.setCurrentCloud(currentCloud)

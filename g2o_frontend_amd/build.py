@@ -13,7 +13,7 @@ OUT = os.path.join(_HERE, "libpwn_hip.so")
 # -ffp-contract=off: the kernels reproduce the CPU path's evaluation order; a fused multiply-add would change bits.
 # -fno-slp-vectorize: the SLP vectoriser pairs scalar fp32 ops into v_pk_*_f32 and pays for it in v_mov shuffles and registers
 #   (k_corr_linearize 124 -> 98 VGPRs without it; same bits, +3 % whole-step throughput measured on MI355X).
-FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-Wall",
+FLAGS = ["-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-fPIC", "-shared", "-pthread", "-Wall",
          "-Wno-unused-function"]
 
 

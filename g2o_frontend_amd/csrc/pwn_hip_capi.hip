@@ -14,10 +14,13 @@
 #include "pwn_stats.h"
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -29,6 +32,20 @@ thread_local std::string g_err = "";
 
 struct StageAcc { float ms = 0.f; int launches = 0; };
 struct EventRec { std::string stage; hipEvent_t a, b; };
+
+// pwn_hip_convert_scaled_begin / _end: a helper context (streams and workspaces of its own) driven by a helper thread, so that a frame
+// is converted next to whatever the caller runs on the context meanwhile
+struct AsyncConvert {
+  pwn_hip_ctx* helper = nullptr;
+  std::thread worker;
+  std::mutex m;
+  std::condition_variable cv;
+  bool has_job = false, done = true, quit = false;
+  pwn_hip_converter_params p;
+  const float* depth = nullptr; int rows = 0, cols = 0, step = 1; float max_depth_cov = 0.f;
+  pwn_hip_cloud* cloud = nullptr;
+  int rc = 0; std::string err;
+};
 
 }  // namespace
 
@@ -113,6 +130,7 @@ struct pwn_hip_ctx {
   // returns a `new Cloud` per depth image, pwn_matcher_base.cpp:77-85), and hipMalloc / hipFree of the point arrays cost more than the
   // conversion of a frame.  Bounded by kCloudPoolBytes.
   std::vector<pwn_hip_cloud*> cloud_pool; size_t cloud_pool_bytes = 0;
+  AsyncConvert* async = nullptr;           // pwn_hip_convert_scaled_begin: created on first use
 };
 
 namespace {
@@ -757,6 +775,13 @@ int pwn_hip_ctx_create(pwn_hip_ctx** out, int device, int max_rows, int max_cols
 int pwn_hip_ctx_destroy(pwn_hip_ctx* ctx) {
   if (!ctx) return PWN_HIP_OK;
   (void)hipSetDevice(ctx->device);
+  if (AsyncConvert* a = ctx->async) {       // a conversion still in flight finishes first; its result is dropped
+    { std::unique_lock<std::mutex> lk(a->m); a->quit = true; }
+    a->cv.notify_all();
+    if (a->worker.joinable()) a->worker.join();
+    if (a->helper) pwn_hip_ctx_destroy(a->helper);
+    delete a; ctx->async = nullptr;
+  }
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);      // pwn_hip_copy_async transfers still in flight
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   void* dev[] = { ctx->depth_ws, ctx->raw_ws, ctx->index_ws, ctx->interval_ws, ctx->integral_ws, ctx->rowoff_ws, ctx->carry_ws, ctx->fsync_ws, ctx->fault_dev, ctx->zref_ws, ctx->z32ref_ws, ctx->z32cur_ws, ctx->curidx_ws,
@@ -919,6 +944,7 @@ int pwn_hip_cloud_create(pwn_hip_ctx* ctx, int capacity, pwn_hip_cloud** out) {
 }
 int pwn_hip_cloud_destroy(pwn_hip_ctx* ctx, pwn_hip_cloud* c) {
   if (!c) return PWN_HIP_OK;
+  if (ctx && ctx->async && ctx->async->cloud == c) (void)pwn_hip_convert_end(ctx, c);      // a conversion into this cloud is still in flight
   cloud_changes(ctx, c);
   // plain clouds (no scene-stage or uploaded extras) retire into the context's pool: every call that used them has joined its streams
   // back into ctx->stream before returning, and a reuse is enqueued on that stream
@@ -1194,6 +1220,57 @@ int pwn_hip_convert_scaled(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, 
   const float* frames[1] = { scaled };
   pwn_hip_cloud* clouds[1] = { cloud };
   return convert_batch_impl<float>(ctx, p, frames, 0.f, 1, orows, ocols, clouds, 0);
+}
+static void async_convert_loop(AsyncConvert* a, int device) {
+  (void)hipSetDevice(device);
+  for (;;) {
+    std::unique_lock<std::mutex> lk(a->m);
+    a->cv.wait(lk, [a] { return a->has_job || a->quit; });
+    if (!a->has_job) return;                                    // quit, nothing pending
+    lk.unlock();
+    const int rc = pwn_hip_convert_scaled(a->helper, &a->p, a->depth, a->rows, a->cols, a->step, a->max_depth_cov, a->cloud);
+    lk.lock();
+    a->rc = rc; a->err = rc == PWN_HIP_OK ? std::string() : a->helper->err;
+    a->has_job = false; a->done = true;
+    lk.unlock();
+    a->cv.notify_all();
+  }
+}
+int pwn_hip_convert_scaled_begin(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float* depth, int rows, int cols, int step, float max_depth_cov,
+                                 pwn_hip_cloud* cloud) {
+  if (!ctx || !p || !depth || !cloud || step <= 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "bad argument");
+  if (int rc = check_image(ctx, rows, cols)) return rc;
+  if (rows / step <= 0 || cols / step <= 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "scaled image has zero size");
+  if (!ctx->async) {
+    AsyncConvert* a = new AsyncConvert();
+    if (int rc = pwn_hip_ctx_create(&a->helper, ctx->device, ctx->max_rows, ctx->max_cols, 1)) { const std::string m = g_err; delete a; return fail(ctx, rc, "helper context: " + m); }
+    a->worker = std::thread(async_convert_loop, a, ctx->device);
+    ctx->async = a;
+  }
+  AsyncConvert* a = ctx->async;
+  {
+    std::unique_lock<std::mutex> lk(a->m);
+    if (a->cloud || !a->done) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "a conversion is already in flight on this context (pwn_hip_convert_end first)");
+    // the caller's copies (pwn_hip_copy_async into a device frame) must have landed before the helper's stream reads the frame
+    if (int rc = absorb_copies(ctx)) return rc;
+    if (is_device_ptr(depth)) HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+    cloud_changes(ctx, cloud);
+    a->p = *p; a->depth = depth; a->rows = rows; a->cols = cols; a->step = step; a->max_depth_cov = max_depth_cov; a->cloud = cloud;
+    a->rc = PWN_HIP_OK; a->err.clear();
+    a->done = false; a->has_job = true;
+  }
+  a->cv.notify_all();
+  return PWN_HIP_OK;
+}
+int pwn_hip_convert_end(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud) {
+  if (!ctx || !cloud) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  AsyncConvert* a = ctx->async;
+  if (!a || a->cloud != cloud) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "no conversion of this cloud was begun on this context");
+  std::unique_lock<std::mutex> lk(a->m);
+  a->cv.wait(lk, [a] { return a->done; });
+  a->cloud = nullptr;
+  if (a->rc != PWN_HIP_OK) return fail(ctx, a->rc, a->err);
+  return PWN_HIP_OK;
 }
 int pwn_hip_convert_batch(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float* const* depth_frames, int n, int rows, int cols,
                           pwn_hip_cloud* const* clouds) {

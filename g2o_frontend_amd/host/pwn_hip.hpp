@@ -523,7 +523,7 @@ struct PwnMatcherBase {
     float image_reprojectionDistance;
   };
   PwnMatcherBase(Context* ctx, Aligner* aligner, DepthImageConverter* converter) : _ctx(ctx), _aligner(aligner), _converter(converter) {}
-  virtual ~PwnMatcherBase() {}
+  virtual ~PwnMatcherBase() { try { makeCloudDrop(); } catch (...) {} }
   int scale() const { return _scale; }  void setScale(int s) { _scale = s; }
   float frameInlierDepthThreshold() const { return _frameInlierDepthThreshold; }  void setFrameInlierDepthThreshold(float v) { _frameInlierDepthThreshold = v; }
   Aligner* aligner() { return _aligner; }  DepthImageConverter* converter() { return _converter; }
@@ -547,6 +547,36 @@ struct PwnMatcherBase {
     ++numCalls;
     return cloud;
   }
+  // makeCloud in two halves (pwn_hip_convert_scaled_begin / _end; not in the reference): makeCloudBegin returns at once, the frame is
+  // converted by the library's helper thread next to whatever runs on the context meanwhile; makeCloudEnd returns the cloud makeCloud would
+  // have returned, bit for bit.  One at a time per context; depthImage must stay alive and unchanged in between.
+  void makeCloudBegin(Matrix3f cameraMatrix, const Isometry3f& sensorOffset, const DepthImage& depthImage) {
+    makeCloudDrop();
+    PinholePointProjector* projector = _converter->projector();
+    const float invScale = 1.0f / _scale;
+    for (int i = 0; i < 9; ++i) cameraMatrix.m[i] = cameraMatrix.m[i] * invScale;
+    cameraMatrix(2,2) = 1.0f;
+    projector->setCameraMatrix(cameraMatrix);
+    projector->setImageSize(depthImage.rows / _scale, depthImage.cols / _scale);
+    projector->setTransform(Isometry3f::Identity());
+    _pendingK = projector->cameraMatrix(); _pendingR = projector->imageRows(); _pendingC = projector->imageCols();
+    Cloud* cloud = new Cloud(*_ctx, _pendingR * _pendingC > 0 ? _pendingR * _pendingC : 1);
+    const pwn_hip_converter_params p = _converter->params(sensorOffset);
+    const int rc = pwn_hip_convert_scaled_begin(_ctx->handle(), &p, depthImage.data.data(), depthImage.rows, depthImage.cols, _scale, 0.01f, cloud->handle());
+    if (rc) { delete cloud; _ctx->check(rc); }
+    _pending = cloud; _pendingImage = &depthImage;
+  }
+  bool makeCloudPending(const DepthImage& depthImage) const { return _pending && _pendingImage == &depthImage; }
+  Cloud* makeCloudEnd(int& r, int& c, Matrix3f& cameraMatrix) {
+    if (!_pending) throw Error(PWN_HIP_ERR_INVALID_ARGUMENT, "makeCloudEnd without makeCloudBegin");
+    Cloud* cloud = _pending; _pending = nullptr; _pendingImage = nullptr;
+    const int rc = pwn_hip_convert_end(_ctx->handle(), cloud->handle());
+    if (rc) { delete cloud; _ctx->check(rc); }
+    r = _pendingR; c = _pendingC; cameraMatrix = _pendingK;
+    ++numCalls;
+    return cloud;
+  }
+  void makeCloudDrop() { if (_pending) { int r, c; Matrix3f K; delete makeCloudEnd(r, c, K); } }
   // .cpp:88-183
   void matchClouds(MatcherResult& result, Cloud* fromCloud, Cloud* toCloud, const Isometry3f& fromOffset, const Isometry3f& toOffset,
                    const Matrix3f& toCameraMatrix, int toRows, int toCols, const Isometry3f& initialGuess = Isometry3f::Identity()) {
@@ -592,6 +622,7 @@ struct PwnMatcherBase {
     result.image_nonZeros = m.image_non_zeros; result.image_outliers = m.image_outliers; result.image_inliers = m.image_inliers;
   }
   Context* _ctx; Aligner* _aligner; DepthImageConverter* _converter;
+  Cloud* _pending = nullptr; const DepthImage* _pendingImage = nullptr; Matrix3f _pendingK; int _pendingR = 0, _pendingC = 0;      // makeCloudBegin
   float _frameInlierDepthThreshold = 50.f;   // .cpp:13
   int _scale = 2;                            // .cpp:12
 };
@@ -651,15 +682,24 @@ class PwnTracker : public PwnMatcherBase {
   int numKeyframes() const { return _numKeyframes; }
   float newFrameInliersFraction() const { return _newFrameInliersFraction; }  void setNewFrameInliersFraction(float v) { _newFrameInliersFraction = v; }
   void init() {                                                                  // pwn_tracker.cpp:38-49
+    makeCloudDrop();
     delete _previousCloud; if (_currentCloud != _previousCloud) delete _currentCloud;
     _previousCloud = _currentCloud = nullptr;
     _globalT.setIdentity(); _previousCloudTransform.setIdentity(); _counter = 0; _numKeyframes = 0;
   }
-  // pwn_tracker.cpp:106-215
-  FrameResult processFrame(const DepthImage& depthImage, const Isometry3f& sensorOffset, const Matrix3f& cameraMatrix, const Isometry3f& initialGuess = Isometry3f::Identity()) {
+  // Not in the reference: hand over the NEXT frame of a recorded / buffered stream (same sensor offset and camera matrix as the call that
+  // will process it) before processFrame of the current one; its makeCloud (:115, independent of the alignments before it) then runs next
+  // to that alignment, and processFrame of the same DepthImage object picks the cloud up.  Same results, bit for bit.
+  void prefetch(const DepthImage& depthImage, const Isometry3f& sensorOffset, const Matrix3f& cameraMatrix) { makeCloudBegin(cameraMatrix, sensorOffset, depthImage); }
+  // pwn_tracker.cpp:106-215; nextDepthImage (not in the reference): prefetch()ed as soon as this frame's cloud exists
+  FrameResult processFrame(const DepthImage& depthImage, const Isometry3f& sensorOffset, const Matrix3f& cameraMatrix, const Isometry3f& initialGuess = Isometry3f::Identity(),
+                           const DepthImage* nextDepthImage = nullptr) {
     FrameResult out;
     int r, c; Matrix3f scaledCameraMatrix = cameraMatrix;
-    Cloud* currentCloud = makeCloud(r, c, scaledCameraMatrix, sensorOffset, depthImage);                         // :115
+    Cloud* currentCloud;
+    if (makeCloudPending(depthImage)) currentCloud = makeCloudEnd(r, c, scaledCameraMatrix);
+    else { makeCloudDrop(); currentCloud = makeCloud(r, c, scaledCameraMatrix, sensorOffset, depthImage); }     // :115
+    if (nextDepthImage) prefetch(*nextDepthImage, sensorOffset, cameraMatrix);
     if (_currentCloud != _previousCloud) delete _currentCloud;                                                   // the last non-key cloud
     _currentCloud = currentCloud;
     if (_previousCloud) {

@@ -229,6 +229,16 @@ int pwn_hip_convert(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const f
  * p->K must already be the scaled camera matrix. */
 int pwn_hip_convert_scaled(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float* depth, int rows, int cols, int step,
                            float max_depth_cov, pwn_hip_cloud* cloud);
+/* The same conversion in two halves, for callers that know their next frame before they are done with the current one (a recorded or
+ * buffered stream through PwnTracker::processFrame, pwn_tracker/pwn_tracker.cpp:115: makeCloud of frame k+1 does not depend on the
+ * alignment of frame k).  _begin returns at once: the frame is converted by a helper thread on streams and workspaces of its own (created
+ * on first use: one more set of single-frame workspaces), next to whatever the caller runs on `ctx` meanwhile.  _end waits for it and
+ * returns what pwn_hip_convert_scaled would have returned; the cloud then holds the same bits.  Between the two calls `depth` must stay
+ * valid and unchanged and `cloud` must not be passed to any other entry point (pwn_hip_cloud_destroy and pwn_hip_ctx_destroy wait for a
+ * conversion in flight).  One conversion in flight per context. */
+int pwn_hip_convert_scaled_begin(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float* depth, int rows, int cols, int step,
+                                 float max_depth_cov, pwn_hip_cloud* cloud);
+int pwn_hip_convert_end(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud);
 /* n independent frames of equal size in one call.  depth[i] -> clouds[i].
  * depth_frames: n pointers (host array) to rows*cols floats each (each host or device). */
 int pwn_hip_convert_batch(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float* const* depth_frames,

@@ -152,7 +152,7 @@ def test_scene_mapping_harness_matches_oracle(tmp_path, oracle):
     assert np.abs(G[:3, 3] - true[:3, 3]).max() < 0.02
 
 
-def _run_tracker_app(tmp_path, n=5):
+def _run_tracker_app(tmp_path, n=5, extra_conf="", prefix_name="run"):
     """tools/pwn_hip_tracker_app on a 5-frame VGA stream at matcher scale 4: every frame a key-frame (fraction 2.0), a cache of two clouds"""
     from g2o_frontend_amd import build, synth
     build.build_tools()
@@ -165,9 +165,9 @@ def _run_tracker_app(tmp_path, n=5):
         write_pgm16(str(p), f)
         lst.append(f"{k * 0.033:.3f} {p}")
     # every frame becomes a keyframe (inliers fraction is always < 2), a cache of two clouds forces misses and evictions
-    (tmp_path / "conf.txt").write_text(CONF + "newFrameInliersFraction 2.0\ncacheSize 2\nframeMaxOutliersThreshold 100000\n")
+    (tmp_path / "conf.txt").write_text(CONF + "newFrameInliersFraction 2.0\ncacheSize 2\nframeMaxOutliersThreshold 100000\n" + extra_conf)
     (tmp_path / "list.txt").write_text("\n".join(lst) + "\n")
-    prefix = str(tmp_path / "run")
+    prefix = str(tmp_path / prefix_name)
     subprocess.check_call([exe, str(tmp_path / "conf.txt"), str(tmp_path / "list.txt"), prefix], timeout=300)
     track = np.loadtxt(prefix + "_track.txt")
     clos = np.loadtxt(prefix + "_closures.txt", comments="#", ndmin=2)
@@ -391,3 +391,13 @@ def test_cpp_bench_matches_python_mirror(tmp_path):
             assert np.array_equal(g[19:].astype(np.float32), r["chi2"])
     finally:
         ctx.close()
+
+
+@pytest.mark.gpu
+def test_tracker_app_with_look_ahead_writes_the_same_files(tmp_path):
+    """`lookAhead 1` in the configuration: PwnTracker::prefetch hands frame k+1 to the library's helper thread before frame k is aligned
+    (pwn_hip_convert_scaled_begin / _end).  Track, closure and extras files are byte-identical to the plain run's."""
+    _run_tracker_app(tmp_path, prefix_name="plain")
+    _run_tracker_app(tmp_path, extra_conf="lookAhead 1\n", prefix_name="ahead")
+    for suffix in ("_track.txt", "_closures.txt", "_extras.txt"):
+        assert (tmp_path / ("plain" + suffix)).read_bytes() == (tmp_path / ("ahead" + suffix)).read_bytes(), suffix

@@ -163,3 +163,105 @@ def test_config2_full_size_stream_matches_oracle():
           f"teacher-forced: inliers equal on {f_equal} of {n - 1} frames, worst |diff| {f_worst_inl}, worst |T diff| {f_worst_T:.2e}, "
           f"worst |globalT diff| {f_worst_pose:.2e}")
     ctx.close()
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_makeCloud_in_two_halves_is_makeCloud(oracle):
+    """pwn_hip_convert_scaled_begin / _end: the cloud of the helper thread is the cloud of pwn_hip_convert_scaled, bit for bit, while the
+    context runs an alignment in between; the misuse cases return errors instead of racing."""
+    from g2o_frontend_amd import api, synth
+    from test_gpu_parity import gpu_objects
+    rows, cols, K, _, _ = case_params("vga")
+    ctx = api.Context(0, rows, cols, 2)
+    _, converter, aligner = gpu_objects(ctx, "vga")
+    m = api.PwnMatcherBase(aligner, converter); m.setScale(1)
+    Km = np.array([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]], np.float32)
+    I = np.eye(4, dtype=np.float32)
+    poses = synth.trajectory_sweep(9, 4)
+    frames = [oracle.convert_16u_to_32f(synth.render_depth_mm(9, poses[k], rows, cols, K, hole_stream=k)) for k in range(4)]
+    plain = [m.makeCloud(Km, I, f) for f in frames]
+    aligner.setReferenceCloud(plain[0][0]); aligner.setCurrentCloud(plain[1][0]); aligner.setInitialGuess(I)
+    base = aligner.align()
+    for k, f in enumerate(frames):
+        t = m.makeCloudBegin(Km, I, f)
+        between = aligner.align()                                  # the context is busy while the helper converts
+        cloud, r, c, Ks = m.makeCloudEnd(t)
+        assert (r, c) == plain[k][1:3] and np.array_equal(Ks, plain[k][3])
+        assert cloud.size() == plain[k][0].size() > rows * cols // 3
+        mine, ref = cloud.arrays(), plain[k][0].arrays()
+        for key in ref:
+            assert np.array_equal(_bits(mine[key]), _bits(ref[key])), (k, key)
+        assert np.array_equal(_bits(between["T"]), _bits(base["T"])) and np.array_equal(_bits(between["chi2"]), _bits(base["chi2"]))
+        # the cloud made by the helper serves as an alignment's current cloud like any other
+        aligner.setCurrentCloud(cloud); g = aligner.align(); aligner.setCurrentCloud(plain[k][0]); h = aligner.align()
+        assert np.array_equal(_bits(g["T"]), _bits(h["T"])) and np.array_equal(_bits(g["chi2"]), _bits(h["chi2"]))
+        aligner.setCurrentCloud(plain[1][0])
+    # misuse: a second begin while one is in flight; end of a cloud that was never begun; a frame larger than the context
+    t = m.makeCloudBegin(Km, I, frames[0])
+    with pytest.raises(api.PwnHipError, match="already in flight"):
+        m.makeCloudBegin(Km, I, frames[1])
+    with pytest.raises(api.PwnHipError, match="no conversion of this cloud"):
+        ctx.check(ctx._L.pwn_hip_convert_end(ctx.h, plain[0][0].h))
+    m.makeCloudEnd(t)
+    with pytest.raises(api.PwnHipError):
+        m.makeCloudBegin(Km, I, np.zeros((rows + 8, cols), np.float32))
+    # a conversion error surfaces at the end: a cloud too small for the frame's valid pixels
+    small = api.Cloud(ctx, 1000)
+    p = converter.params(I)
+    ctx.check(ctx._L.pwn_hip_convert_scaled_begin(ctx.h, api.C.byref(p), api._ptr(frames[0]), rows, cols, 1, 0.01, small.h))
+    with pytest.raises(api.PwnHipError, match="capacity"):
+        ctx.check(ctx._L.pwn_hip_convert_end(ctx.h, small.h))
+    # destroying the cloud, or the context, with a conversion in flight waits for it
+    t = m.makeCloudBegin(Km, I, frames[2]); t["cloud"].__del__()
+    t = m.makeCloudBegin(Km, I, frames[3])
+    ctx.close()
+
+
+def test_tracker_with_prefetched_frames_is_the_tracker(oracle):
+    """PwnTracker.prefetch / processFrame(nextDepthImage=...): frame k+1 converted next to the alignment of frame k -- every frame's
+    result bitwise the plain tracker's, key-cloud switches included; a prefetched frame that is not the next one is dropped."""
+    from g2o_frontend_amd import api, synth
+    from test_gpu_parity import gpu_objects
+    rows, cols, K, _, _ = case_params("vga")
+    ctx = api.Context(0, rows, cols, 2)
+    _, converter, aligner = gpu_objects(ctx, "small")
+    Km = np.array([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]], np.float32)
+    off = synth.v2t(np.array([0.0, 0.0, 0.0, 0.01, -0.005, 0.0])).astype(np.float32)
+    n = 12
+    poses = synth.trajectory(3, n)
+    frames = [oracle.convert_16u_to_32f(synth.render_depth_mm(3, poses[k], rows, cols, K, hole_stream=k)) for k in range(n)]
+
+    def run(mode):
+        tr = api.PwnTracker(aligner, converter); tr.setScale(4); tr.setNewFrameInliersFraction(0.66)
+        out = []
+        if mode == "prefetch":
+            tr.prefetch(frames[0], off, Km)
+        for k, f in enumerate(frames):
+            nxt = frames[k + 1] if k + 1 < n else None
+            if mode == "plain":
+                out.append(tr.processFrame(f, off, Km))
+            elif mode == "next":
+                out.append(tr.processFrame(f, off, Km, nextDepthImage=nxt))
+            else:
+                if k == 5:
+                    tr.prefetch(frames[0], off, Km)             # not the frame that comes next: processFrame must not take it
+                out.append(tr.processFrame(f, off, Km))
+                if nxt is not None and k != 4:
+                    tr.prefetch(nxt, off, Km)
+        tr.dropPrefetched()
+        return out, tr.numKeyframes()
+
+    plain, kf = run("plain")
+    assert 1 < kf < n
+    for mode in ("next", "prefetch"):
+        got, kf2 = run(mode)
+        assert kf2 == kf
+        for k, (a, b) in enumerate(zip(plain, got)):
+            assert a["newFrame"] == b["newFrame"] and a["inliers"] == b["inliers"], (mode, k)
+            assert np.array_equal(_bits(a["globalT"]), _bits(b["globalT"])), (mode, k)
+            if k > 0:
+                assert np.array_equal(_bits(a["T"]), _bits(b["T"])) and _bits(np.float32(a["error"])) == _bits(np.float32(b["error"])), (mode, k)
+    ctx.close()

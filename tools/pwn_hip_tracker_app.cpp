@@ -10,6 +10,7 @@
 //   g++ -O2 -std=c++17 -I. tools/pwn_hip_tracker_app.cpp -o tools/pwn_hip_tracker_app -Lg2o_frontend_amd -lpwn_hip -Wl,-rpath,$ORIGIN/../g2o_frontend_amd
 #include <algorithm>
 #include <cstdio>
+#include <chrono>
 #include <fstream>
 #include <iostream>
 #include <map>
@@ -115,13 +116,19 @@ int main(int argc, char** argv) {
     FILE* ft = std::fopen((prefix + "_track.txt").c_str(), "w");
     if (!ft) { std::cerr << "cannot write " << prefix << "_track.txt" << std::endl; return 1; }
     std::vector<int> keyframes; std::vector<Isometry3f> keyPoses;
+    const bool lookAhead = get("lookAhead", 0.f) != 0.f;       // hand frame k+1 over before frame k is aligned (PwnTracker::prefetch): same track, bit for bit
+    const auto t0 = std::chrono::steady_clock::now();
     for (size_t k = 0; k < frames.size(); ++k) {
-      const PwnTracker::FrameResult r = tracker.processFrame(frames[k], sensorOffset, cameraMatrix);
+      const DepthImage* next = (lookAhead && k + 1 < frames.size()) ? &frames[k + 1] : nullptr;
+      const PwnTracker::FrameResult r = tracker.processFrame(frames[k], sensorOffset, cameraMatrix, Isometry3f::Identity(), next);
       std::fprintf(ft, "%zu %d %d %d %.9g %.9g", k, r.newFrame ? 1 : 0, r.aligned ? 1 : 0, r.inliers, r.error, r.inliersFraction);
       put16(ft, r.globalT.data()); std::fprintf(ft, "\n");
       if (r.newFrame) { keyframes.push_back((int)k); keyPoses.push_back(r.globalT); }
     }
     std::fclose(ft);
+    { const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      std::cerr << "tracking: " << frames.size() << " frames, " << dt / frames.size() * 1e3 << " ms per frame (" << frames.size() / dt << " frames/s, file output included)"
+                << (lookAhead ? ", look-ahead" : "") << std::endl; }
 
     // 2. loop-closure pass over the keyframes
     FILE* fc = std::fopen((prefix + "_closures.txt").c_str(), "w");
