@@ -1496,6 +1496,7 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
   if (n > 0 && scores) HIPCHK(ctx, hipMemcpyAsync(ctx->match_host, ctx->match_dev, sizeof(MatchAcc) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
   if (n > 0 && statistics) HIPCHK(ctx, hipMemcpyAsync(ctx->stats_host, ctx->stats_dev, sizeof(SolveOut) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
   if (n > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->state_host, ctx->state_ws, sizeof(PairState) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipEventRecord(ctx->t1, ctx->stream), PWN_HIP_ERR_LAUNCH);      // before the wait: recording it afterwards costs a second round trip per call
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
   for (int i = 0; i < n; ++i) {
     const PairState& st = ctx->state_host[i];
@@ -1519,8 +1520,6 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
       }
     }
   }
-  HIPCHK(ctx, hipEventRecord(ctx->t1, ctx->stream), PWN_HIP_ERR_LAUNCH);
-  HIPCHK(ctx, hipEventSynchronize(ctx->t1), PWN_HIP_ERR_LAUNCH);
   float ms = 0.f; (void)hipEventElapsedTime(&ms, ctx->t0, ctx->t1);
   for (int i = 0; i < n; ++i) results[i].total_time_ms = n > 0 ? ms / n : 0.f;
   ctx->img_rows = p->rows; ctx->img_cols = p->cols; ctx->img_valid = n > 0 && !any_own;      // no current z-buffer after a skipped projection
