@@ -130,6 +130,7 @@ PROTOTYPES = {
     "pwn_hip_last_stage_ms": (_I, [_VP, C.c_char_p, C.POINTER(_F), C.POINTER(_I)]),
     "pwn_hip_set_profiling": (_I, [_VP, _I]),
     "pwn_hip_debug_withhold_carry": (_I, [_VP, _I, _I, _I, _I, _I]),
+    "pwn_hip_debug_set_index_shortcut": (_I, [_VP, _I]),
     "pwn_hip_measure_hbm": (_I, [_VP, C.c_size_t, _VP, _VP]),
 }
 

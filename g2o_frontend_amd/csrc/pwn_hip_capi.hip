@@ -111,6 +111,10 @@ struct pwn_hip_ctx {
   // images of the last single align
   int img_rows = 0, img_cols = 0; bool img_valid = false; unsigned img_ref_tag = kZ32Tag0, img_cur_tag = kZ32Tag0;
   int img_pair = 0;                         // descriptor (pairs_host / pairs_dev entry) of the pair whose images sit in workspace slot 0
+  // A single alignment whose current cloud carries its own index image (pwn_hip_cloud::idximg) does not project that cloud at all; its
+  // z-buffer is filled in only when pwn_hip_align_images asks for the finder's current images (pwn_hip_match_score reads the depths off the cloud)
+  bool img_cur_lazy = false; AlignParams img_ap; int img_cur_capacity = 0;
+  int index_shortcut = 1;                   // pwn_hip_debug_set_index_shortcut (test hook): 0 = always project
   const pwn_hip_cloud* img_ref_cloud = nullptr; const pwn_hip_cloud* img_cur_cloud = nullptr;      // its clouds: the depth images are recomputed from their points
   // z-buffer epoch tags are handed out in descending order ACROSS batch calls (a smaller tag wins, so whatever earlier calls left in
   // the buffers reads as empty): the buffers are cleared only when the 12-bit tag space is used up, not once per alignment
@@ -411,7 +415,8 @@ int ensure_desc(pwn_hip_ctx* ctx, int n) {
 }
 
 // launch sequence of the converter for the frames [base, base+n) of the uploaded descriptor array
-int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, hipStream_t st) {
+// fault_out: page-locked host word for the launch's time-out flag (latency path only; nullptr = the caller copies ctx->fault_dev itself)
+int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, hipStream_t st, int* fault_out = nullptr) {
 #ifndef PWN_SINGLE_PASS_MIN_FRAMES
 #define PWN_SINGLE_PASS_MIN_FRAMES 16     // measured on MI355X at VGA (tools/ab_convert_n.py), three kernels vs single pass: 8 frames 0.20 vs 0.27 ms, 16 frames 0.38 vs 0.35, 32 frames 0.74 vs 0.58
 #endif
@@ -459,7 +464,8 @@ int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, h
       hipLaunchKernelGGL(k_unproject_integral_rows, dim3(8u * (unsigned)((bands_of(cp.rows) + 7) / 8) * (unsigned)strips_of(cp.cols), n), dim3(256), 0, st, fr, cp,
                          epoch, ctx->fault_dev); }
     { StageTimer t(ctx, "integral_cols", st);
-      hipLaunchKernelGGL(k_integral_cols, dim3((cp.cols + kIC_Block - 1) / kIC_Block, kIntegralChannels, n), dim3(kIC_Block), 0, st, fr, cp.rows, cp.cols); }
+      hipLaunchKernelGGL(k_integral_cols, dim3((cp.cols + kIC_Block - 1) / kIC_Block, kIntegralChannels, n), dim3(kIC_Block), 0, st, fr, cp.rows, cp.cols,
+                         (const int*)ctx->fault_dev, fault_out); }
   }
   { StageTimer t(ctx, "stats", st);
     const unsigned perFrame = (unsigned)cp.rows * (unsigned)((cp.cols + 255) / 256);
@@ -484,14 +490,16 @@ void fill_frame(pwn_hip_ctx* ctx, int entry, int slot, const float* depth_dev, c
   f.carry = ctx->carry_ws + (size_t)slot * ctx->carry_slot;
   f.fsync = ctx->fsync_ws + (size_t)slot * ctx->fsync_slot;
   f.cloud = cl;
+  f.count_out = nullptr;
 }
 int ensure_stats(pwn_hip_ctx* ctx, pwn_hip_cloud* c) {
   if (!c->d.St) HIPCHK(ctx, hipMalloc(&c->d.St, sizeof(float) * 16 * (size_t)c->d.capacity), PWN_HIP_ERR_ALLOCATION);
   return PWN_HIP_OK;
 }
-int sync_and_counts(pwn_hip_ctx* ctx, pwn_hip_cloud* const* clouds, int n) {
+// direct: the kernels of the call have written counts and fault flag into counts_host themselves (FrameDesc::count_out, launch_convert's fault_out)
+int sync_and_counts(pwn_hip_ctx* ctx, pwn_hip_cloud* const* clouds, int n, bool direct = false) {
   // frames_dev[0..n) must describe clouds[0..n)
-  if (n > 0) {
+  if (n > 0 && !direct) {
     hipLaunchKernelGGL(k_gather_counts, dim3((n + 256) / 256), dim3(256), 0, ctx->stream, ctx->frames_dev, n, ctx->counts_dev, ctx->fault_dev);
     HIPCHK(ctx, hipMemcpyAsync(ctx->counts_host, ctx->counts_dev, sizeof(int) * (n + 1), hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
   }
@@ -567,6 +575,9 @@ int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, cons
       else ctx->frames_host[i].depth = ctx->depth_ws + (size_t)slot * ctx->N;
     }
   }
+  // a call of a few frames (latency path, one sub-batch): counts and fault flag land in page-locked host words straight from the kernels
+  const bool direct = n > 0 && n < PWN_SINGLE_PASS_MIN_FRAMES && n <= sub;
+  if (direct) for (int i = 0; i < n; ++i) ctx->frames_host[i].count_out = ctx->counts_host + i;
   HIPCHK(ctx, hipMemcpyAsync(ctx->frames_dev, ctx->frames_host, sizeof(FrameDesc) * n, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
   if (int rc = plan_fork(ctx, plan)) return rc;
   // Host frames travel on the copy stream, ahead of the kernels: the frames of sub-batch k are copied while sub-batches k-1, k-2 ... are
@@ -606,11 +617,11 @@ int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, cons
         HIPCHK(ctx, hipStreamWaitEvent(st, ctx->sync_events[2 * k], 0), PWN_HIP_ERR_LAUNCH);
       }
     }
-    if (int rc = launch_convert(ctx, cp, base, m, st)) return rc;
+    if (int rc = launch_convert(ctx, cp, base, m, st, direct ? ctx->counts_host + n : nullptr)) return rc;
     if (ahead) HIPCHK(ctx, hipEventRecord(ctx->sync_events[2 * k + 1], st), PWN_HIP_ERR_LAUNCH);
   }
   if (int rc = plan_join(ctx, plan)) return rc;
-  const int rc = sync_and_counts(ctx, clouds, n);
+  const int rc = sync_and_counts(ctx, clouds, n, direct);
   if (rc != PWN_HIP_OK && (ctx->last_convert_fault & 2) && ctx->fused_convert) {
     // the fused kernel found its workgroups on different XCDs (the round-robin placement it is built on did not hold on this device /
     // partition mode): never use it again on this context and convert the batch again with the two-kernel path
@@ -846,6 +857,13 @@ int pwn_hip_debug_withhold_carry(pwn_hip_ctx* ctx, int strip, int band, int chai
   if (band < 0 || chain < 0 || chain >= kII_Chains || rows <= 0 || band >= bands_of(rows)) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "bad hand-over word");
   ctx->dbg_withhold = (strip * bands_of(rows) + band) * kII_Chains + chain;
   ctx->spin_limit = spin_limit > 0 ? spin_limit : kSpinLimit;
+  return PWN_HIP_OK;
+}
+// Test hook: 0 makes every alignment project both clouds in every iteration, also where a cloud's own index image is known to be that
+// projection's result (the shortcut of align_batch_impl) -- so that tests can hold the shortcut against the projection it replaces.
+int pwn_hip_debug_set_index_shortcut(pwn_hip_ctx* ctx, int enabled) {
+  if (!ctx) return fail(nullptr, PWN_HIP_ERR_INVALID_ARGUMENT, "null ctx");
+  ctx->index_shortcut = enabled ? 1 : 0;
   return PWN_HIP_OK;
 }
 int pwn_hip_set_profiling(pwn_hip_ctx* ctx, int enabled) {
@@ -1188,7 +1206,7 @@ int pwn_hip_integral_image(pwn_hip_ctx* ctx, const int* index_image, const pwn_h
   HIPCHK(ctx, copy_any(ctx->frames_host[0].index, index_image, N * 4, ctx->stream), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipMemcpyAsync(ctx->frames_dev, ctx->frames_host, sizeof(FrameDesc), hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
   hipLaunchKernelGGL(k_integral_rows, dim3((rows + kIR_Rows - 1) / kIR_Rows, 1), dim3(256), 0, ctx->stream, ctx->frames_dev, rows, cols);
-  hipLaunchKernelGGL(k_integral_cols, dim3((cols + kIC_Block - 1) / kIC_Block, kIntegralChannels, 1), dim3(kIC_Block), 0, ctx->stream, ctx->frames_dev, rows, cols);
+  hipLaunchKernelGGL(k_integral_cols, dim3((cols + kIC_Block - 1) / kIC_Block, kIntegralChannels, 1), dim3(kIC_Block), 0, ctx->stream, ctx->frames_dev, rows, cols, (const int*)nullptr, (int*)nullptr);
   HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
   HIPCHK(ctx, copy_any(out, ctx->frames_host[0].integral, N * kIntegralChannels * 4, ctx->stream), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
@@ -1379,7 +1397,8 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
   HIPCHK(ctx, hipEventRecord(ctx->t0, ctx->stream), PWN_HIP_ERR_LAUNCH);
   // Batch calls (the finder's images belong to single alignments) skip the projection of a current cloud whose own index image is that
   // projection's result; the matchClouds score then reads the current depth image off the cloud itself (k_match_score, curOwn).
-  const bool batch_shortcut = n > 1 && is_identity(forced(p->current_sensor_offset));
+  // (single alignments too: the finder's current images are then made on demand, see img_cur_lazy)
+  const bool batch_shortcut = n >= 1 && ctx->index_shortcut && is_identity(forced(p->current_sensor_offset));
   std::vector<char> own_index((size_t)std::max(n, 1), 0), own_ref((size_t)std::max(n, 1), 0);
   const bool ident_ref = is_identity(forced(p->reference_sensor_offset));
   // descriptors + initial states of all pairs; workspace slots are reused round-robin across sub-batches
@@ -1398,6 +1417,7 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
                    c->idx_maxD == p->max_distance && std::memcmp(c->idx_K, p->K, sizeof(c->idx_K)) == 0;
     pd.partials = ctx->partials_ws + (size_t)slot * ctx->nblocks_max * kAccN;
     pd.state = ctx->state_ws + i;
+    pd.state_out = ctx->state_host + i;         // page-locked: k_solve_update writes the pose and the traces there, no copy back at the end
     // initial state: aligner.cpp:60-64,72-73,79,84
     PairState& st = ctx->state_host[i];
     std::memset(&st, 0, sizeof(st));
@@ -1475,7 +1495,7 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
           if (k == 0) launch_corr_linearize<true, false>(ctx, nb, m, st, pr, ap, tag, 0, ownRef);
           else launch_corr_linearize<false, false>(ctx, nb, m, st, pr, ap, tag, 0, ownRef); }
         { StageTimer t(ctx, "solve", st);
-          hipLaunchKernelGGL(k_solve_update, dim3(m), dim3(256), 0, st, pr, ap, nb, lastInner ? 1 : 0); }
+          hipLaunchKernelGGL(k_solve_update, dim3(m), dim3(256), 0, st, pr, ap, nb, lastInner ? 1 : 0, (lastInner && i == p->outer_iterations - 1) ? 1 : 0); }
       }
     }
     if (statistics && p->outer_iterations > 0) {
@@ -1495,7 +1515,8 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
   if (int rc = plan_join(ctx, plan)) return rc;
   if (n > 0 && scores) HIPCHK(ctx, hipMemcpyAsync(ctx->match_host, ctx->match_dev, sizeof(MatchAcc) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
   if (n > 0 && statistics) HIPCHK(ctx, hipMemcpyAsync(ctx->stats_host, ctx->stats_dev, sizeof(SolveOut) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
-  if (n > 0) HIPCHK(ctx, hipMemcpyAsync(ctx->state_host, ctx->state_ws, sizeof(PairState) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
+  // state_host[i]: T, it and the traces were written by the last k_solve_update of each pair (PairDesc::state_out); with no iterations it still
+  // holds the initial state
   HIPCHK(ctx, hipEventRecord(ctx->t1, ctx->stream), PWN_HIP_ERR_LAUNCH);      // before the wait: recording it afterwards costs a second round trip per call
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
   for (int i = 0; i < n; ++i) {
@@ -1522,7 +1543,9 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
   }
   float ms = 0.f; (void)hipEventElapsedTime(&ms, ctx->t0, ctx->t1);
   for (int i = 0; i < n; ++i) results[i].total_time_ms = n > 0 ? ms / n : 0.f;
-  ctx->img_rows = p->rows; ctx->img_cols = p->cols; ctx->img_valid = n > 0 && !any_own;      // no current z-buffer after a skipped projection
+  // batches: no current z-buffer after a skipped projection; a single alignment makes it on demand
+  ctx->img_rows = p->rows; ctx->img_cols = p->cols; ctx->img_valid = n > 0 && (!any_own || n == 1);
+  ctx->img_cur_lazy = n == 1 && any_own; ctx->img_ap = ap; ctx->img_cur_capacity = n == 1 ? curs[0]->d.capacity : 0;
   ctx->img_ref_tag = lastRefTag; ctx->img_cur_tag = tag0;
   collect_stage_times(ctx);
   return PWN_HIP_OK;
@@ -1566,7 +1589,7 @@ int pwn_hip_align_with_priors_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params*
   PairDesc& pd = ctx->pairs_host[0];
   pd.ref = ref->d; pd.cur = cur->d;
   pd.zref = ctx->z32ref_ws; pd.zcur = ctx->z32cur_ws; pd.curidx = ctx->curidx_ws; pd.partials = ctx->partials_ws; pd.state = ctx->state_ws;
-  pd.refidx0 = nullptr;
+  pd.refidx0 = nullptr; pd.state_out = nullptr;
   ctx->img_pair = 0; ctx->img_ref_cloud = ref; ctx->img_cur_cloud = cur;
   PairState& hs = ctx->state_host[0];
   std::memset(&hs, 0, sizeof(hs));
@@ -1644,7 +1667,7 @@ int pwn_hip_align_with_priors_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params*
   result->iterations = it; result->total_time_ms = ms;
   if (it > 0) { result->error = result->chi2[it - 1]; result->inliers = result->iter_inliers[it - 1]; }
   result->n_reference = ref->n_host; result->n_current = cur->n_host;
-  ctx->img_rows = p->rows; ctx->img_cols = p->cols; ctx->img_valid = true;
+  ctx->img_rows = p->rows; ctx->img_cols = p->cols; ctx->img_valid = true; ctx->img_cur_lazy = false;
   ctx->img_ref_tag = lastRefTag; ctx->img_cur_tag = tag0;
   return PWN_HIP_OK;
 }
@@ -1663,7 +1686,7 @@ int pwn_hip_match_score(pwn_hip_ctx* ctx, float threshold, pwn_hip_match_result*
   // the descriptor of the pair in slot 0 is still in pairs_dev (clouds, z-buffers, state with the projection matrices)
   HIPCHK(ctx, hipMemsetAsync(ctx->match_dev, 0, sizeof(MatchAcc), ctx->stream), PWN_HIP_ERR_COPY);
   hipLaunchKernelGGL(k_match_score, dim3(std::min((N + 255) / 256, 256), 1), dim3(256), 0, ctx->stream, ctx->pairs_dev + ctx->img_pair, N, ctx->img_ref_tag,
-                     ctx->img_cur_tag, 1000.0f, threshold, ctx->match_dev, 0);
+                     ctx->img_cur_tag, 1000.0f, threshold, ctx->match_dev, ctx->img_cur_lazy ? 1 : 0);
   HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
   HIPCHK(ctx, hipMemcpyAsync(ctx->match_host, ctx->match_dev, sizeof(MatchAcc), hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
@@ -1679,6 +1702,11 @@ int pwn_hip_align_images(pwn_hip_ctx* ctx, int* ref_index, float* ref_depth, int
   if (!ctx) return fail(nullptr, PWN_HIP_ERR_INVALID_ARGUMENT, "null ctx");
   if (!ctx->img_valid) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "no alignment has run on this context");
   const size_t N = (size_t)ctx->img_rows * ctx->img_cols;
+  if (ctx->img_cur_lazy && (cur_index || cur_depth)) {      // the projection the alignment skipped, with the tag it had reserved for it
+    launch_project(ctx->img_cur_capacity, 1, ctx->stream, ctx->pairs_dev + ctx->img_pair, ctx->img_ap, 1, ctx->img_cur_tag);
+    HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
+    ctx->img_cur_lazy = false;
+  }
   for (int pass = 0; pass < 2; ++pass) {
     int* oi = pass == 0 ? ref_index : cur_index; float* od = pass == 0 ? ref_depth : cur_depth;
     if (!oi && !od) continue;

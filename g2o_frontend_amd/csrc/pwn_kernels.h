@@ -95,6 +95,7 @@ struct FrameDesc {
   unsigned long long* carry; // [strips][bands][160] strip-to-strip hand-over words of k_unproject_integral
   unsigned long long* fsync; // k_convert_fused: [strips] bands stored by the producers, [strips][4 kConsWG] bands finished by the consumer waves, [1] XCC id; each = launch epoch << 32 | value
   CloudDev cloud;
+  int* count_out;    // optional: page-locked host word that receives the point count as well (single-frame calls: no gather kernel, no copy back)
 };
 
 struct ConvertParams {
@@ -139,6 +140,7 @@ struct PairDesc {
                            // initial guess is the identity: that projection returns it), else nullptr
   double* partials;        // [nblocks][kAccN]
   PairState* state;
+  PairState* state_out;    // optional: page-locked host copy that k_solve_update keeps up to date in what the host reads back (T, it, the traces)
 };
 
 struct AlignParams {
@@ -316,7 +318,7 @@ __global__ void __launch_bounds__(1024) k_row_offsets(const FrameDesc* __restric
     if (threadIdx.x == 1023) carry = c0 + incl;
     __syncthreads();
   }
-  if (threadIdx.x == 0) *f.cloud.count = carry;
+  if (threadIdx.x == 0) { *f.cloud.count = carry; if (f.count_out) *f.count_out = carry; }
 }
 // per-frame point counts -> one contiguous array (single D2H copy per batch)
 __global__ void k_gather_counts(const FrameDesc* __restrict__ frames, int n, int* __restrict__ out, const int* __restrict__ fault) {
@@ -887,7 +889,11 @@ __global__ void __launch_bounds__(kII_Threads) k_unproject_integral(const FrameD
 // one thread per (column, channel) chain, lanes along x.  grid = (ceil(cols/64), 10, frames), block = 64: this kernel only runs on the
 // latency path (a few frames), where one-wave workgroups spread a frame's 6400 chains over 100 CUs instead of 30.
 constexpr int kIC_Block = 64;
-__global__ void __launch_bounds__(kIC_Block) k_integral_cols(const FrameDesc* __restrict__ frames, int rows, int cols) {
+// fault / fault_out: the time-out flag of k_unproject_integral_rows (the launch before this one, complete by now) forwarded to a page-locked
+// host word, so that the host reads it without a copy of its own (fault_out may be nullptr).
+__global__ void __launch_bounds__(kIC_Block) k_integral_cols(const FrameDesc* __restrict__ frames, int rows, int cols, const int* __restrict__ fault,
+                                                             int* __restrict__ fault_out) {
+  if (fault_out && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) *fault_out = *fault;
   const FrameDesc& f = frames[blockIdx.z];
   const int c = blockIdx.x * kIC_Block + threadIdx.x;
   if (c >= cols) return;
@@ -2120,7 +2126,9 @@ __device__ __forceinline__ void apply_update(PairState& st, const StateUpdate& u
   if (outerEnd) { st.T = u.T; st.invTcorrPrev = u.invTcorrPrev; st.invTcorr = u.invTcorr; st.KRtLast = u.KRtLast; st.KRt = u.KRt; }
   st.invT = u.invT;
 }
-__global__ void __launch_bounds__(256) k_solve_update(const PairDesc* __restrict__ pairs, AlignParams ap, int nblocks, int outerEnd) {
+// last: this is the alignment's final step -- with pd.state_out set, the pose goes to the host copy as well (the traces go there step by step),
+// and the host needs no copy back of the state.
+__global__ void __launch_bounds__(256) k_solve_update(const PairDesc* __restrict__ pairs, AlignParams ap, int nblocks, int outerEnd, int last) {
   const PairDesc& pd = pairs[blockIdx.x];
   __shared__ double sums[kAccN];
   reduce_partials(pd.partials, (PWN_SOLVE_X & 4) ? 1 : nblocks, sums);
@@ -2129,6 +2137,10 @@ __global__ void __launch_bounds__(256) k_solve_update(const PairDesc* __restrict
   StateUpdate u;
   solve_step(sums, st, ap, outerEnd, u);
   apply_update(st, u, outerEnd && !(PWN_SOLVE_X & 2));
+  if (PairState* so = pd.state_out) {
+    if (u.it < kMaxIter) { so->chi2[u.it] = u.chi2; so->inliers[u.it] = u.inliers; so->ncorr[u.it] = u.ncorr; so->ncand[u.it] = u.ncand; }
+    if (last) { so->T = u.T; so->it = u.it + 1; }
+  }
 }
 // reduction only, one record per pair (Aligner::_computeStatistics' 11th update).  grid = pairs, block = 256
 __global__ void __launch_bounds__(256) k_reduce_pairs(const PairDesc* __restrict__ pairs, int nblocks, SolveOut* __restrict__ out) {

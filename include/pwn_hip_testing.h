@@ -15,6 +15,12 @@ extern "C" {
  * (k_unproject_integral, k_unproject_integral_rows: 10 planes x band rows chains per (strip, band)). */
 int pwn_hip_debug_withhold_carry(pwn_hip_ctx* ctx, int strip, int band, int chain, int rows, int spin_limit);
 
+/* An alignment does not project a cloud where the cloud's own index image (the one DepthImageConverter::compute produced for it) is known
+ * to be what that projection returns: same camera matrix, image size and range, identity pose (the current cloud always; the reference cloud
+ * in the first outer iteration of an identity guess).  enabled = 0 makes every alignment of the context project everything, so that tests can
+ * hold the shortcut against the projection it replaces; 1 (the default) switches it back on. */
+int pwn_hip_debug_set_index_shortcut(pwn_hip_ctx* ctx, int enabled);
+
 #ifdef __cplusplus
 }
 #endif

@@ -257,3 +257,57 @@ def test_pinned_blocks_live_as_long_as_their_views_and_buffers_outlive_their_con
                                      om.ctypes.data_as(C.c_void_p), om.ctypes.data_as(C.c_void_p)))
     assert np.array_equal(c.arrays()["points"][:, :3], pts[:, :3])
     dev.free(); ctx.close()
+
+
+def test_index_shortcut_is_the_projection_it_replaces(world):
+    """An alignment takes a cloud's own index image (the converter's) where projecting the cloud would return it: the current cloud always,
+    the reference cloud in the first iteration of an identity guess -- single alignments too, whose current z-buffer is then filled in only
+    when the finder's images are asked for.  Against the same alignments with the shortcut switched off (pwn_hip_debug_set_index_shortcut:
+    every projection executed): poses, traces and counters bitwise equal, single and batch; the finder's four images bitwise equal; the
+    matchClouds score equal; and the current index image IS the cloud's own index image."""
+    from g2o_frontend_amd import api
+    ctx, aligner, refs, curs = world["ctx"], world["aligner"], world["refs"], world["curs"]
+    rows, cols = world["rows"], world["cols"]
+    keys = ("T", "chi2", "C", "K", "iter_inliers")
+    bits = lambda a: np.ascontiguousarray(a).view(np.uint32) if np.asarray(a).dtype.itemsize == 4 else np.ascontiguousarray(a)
+    finder = aligner.correspondenceFinder()
+
+    def run(enabled):
+        ctx.check(ctx._L.pwn_hip_debug_set_index_shortcut(ctx.h, enabled))
+        out = dict(batch=aligner.alignBatch(refs, curs), single=[], images=[], score=[])
+        for i in (0, 5, 11):
+            aligner.setReferenceCloud(refs[i]); aligner.setCurrentCloud(curs[i])
+            out["single"].append(aligner.align())
+            m = api.MatchResult()
+            ctx.check(ctx._L.pwn_hip_match_score(ctx.h, 50.0, api.C.byref(m)))            # before the images: reads the depths off the cloud when lazy
+            out["score"].append((m.image_non_zeros, m.image_outliers, m.image_inliers, np.float32(m.image_reprojection_distance).view(np.uint32)))
+            aligner.align(images=True)
+            out["images"].append({k: v.copy() for k, v in finder._images.items()})
+            m2 = api.MatchResult()
+            ctx.check(ctx._L.pwn_hip_match_score(ctx.h, 50.0, api.C.byref(m2)))           # after them: from the z-buffer the images call filled in
+            assert (m2.image_non_zeros, m2.image_outliers, m2.image_inliers) == out["score"][-1][:3]
+        return out
+
+    try:
+        off = run(0)
+        on = run(1)
+    finally:
+        ctx.check(ctx._L.pwn_hip_debug_set_index_shortcut(ctx.h, 1))
+    for a, b in zip(on["batch"], off["batch"]):
+        for k in keys:
+            assert np.array_equal(bits(a[k]), bits(b[k])), k
+    for j, (a, b) in enumerate(zip(on["single"], off["single"])):
+        for k in keys:
+            assert np.array_equal(bits(a[k]), bits(b[k])), (j, k)
+        for k in keys:                                                      # and the single alignment is the batch entry
+            assert np.array_equal(bits(a[k]), bits(on["batch"][(0, 5, 11)[j]][k])), (j, k)
+    for j, (a, b) in enumerate(zip(on["images"], off["images"])):
+        for k in ("ref_index", "ref_depth", "cur_index", "cur_depth"):
+            assert np.array_equal(bits(a[k]), bits(b[k])), (j, k)
+        assert (a["cur_index"] >= 0).sum() == curs[(0, 5, 11)[j]].size()
+    assert on["score"] == off["score"]
+    # the current index image of the finder is the converter's index image of that cloud
+    conv = world["converter"]
+    c = api.Cloud(ctx, rows * cols)
+    conv.compute(c, np.asarray(world["pairs"][5][1], np.float32) * np.float32(0.001))
+    assert np.array_equal(conv.indexImage(), on["images"][1]["cur_index"])

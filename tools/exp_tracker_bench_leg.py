@@ -64,3 +64,11 @@ t0 = time.perf_counter()
 for k in range(NF):
     al.align()
 print(f"align alone {(time.perf_counter() - t0) / NF * 1e6:.0f} us", flush=True)
+for enabled in (0, 1, 0, 1):
+    ctx.check(ctx._L.pwn_hip_debug_set_index_shortcut(ctx.h, enabled))
+    al.align()
+    t0 = time.perf_counter()
+    for k in range(NF):
+        al.align()
+    print(f"align alone, index shortcut {'on' if enabled else 'off'}: {(time.perf_counter() - t0) / NF * 1e6:.0f} us", flush=True)
+    loop(pageable, False, f"plain tracker, index shortcut {'on' if enabled else 'off'}")
