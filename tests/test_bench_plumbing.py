@@ -111,3 +111,14 @@ def test_records_crc_gate(tmp_path, monkeypatch):
     r = bench.check_records_crc(bad, 480, 640)
     assert not r["equal"] and r["first_mismatch"] == 2 and r["mismatches"] == 1
     assert bench.check_records_crc(rec, 960, 1280)["checked"] == 0                    # another frame size: not comparable
+
+
+def test_committed_records_crc_file_belongs_to_the_committed_kernels():
+    """profiles/records_crc.json is only a gate for multi-GPU runs while its digest is the one of the sources in the tree: a change under
+    g2o_frontend_amd/csrc/ without `bench.py --total-pairs 1024 --write-records-crc` on a GPU box leaves a stale file, which this test reports here
+    instead of `file_is_for_these_kernels: false` in a scaling run."""
+    import json
+    import bench
+    ref = json.load(open(bench.RECORDS_CRC_FILE))
+    assert ref["kernel_source_digest"] == bench.kernel_source_digest(), "regenerate profiles/records_crc.json (see profiles/README.md)"
+    assert ref["pairs"] == 1024 and len(ref["crc32"]) == 1024 and (ref["rows"], ref["cols"]) == (480, 640)
