@@ -597,6 +597,68 @@ def run_tracker(device, frames_mm, poses, scale=1):
     return out
 
 
+def run_tracker_cpp(frames_mm):
+    """The same stream through the C++ host mirror (tools/pwn_hip_tracker_app: g2o_frontend_amd/host/pwn_hip.hpp over the C-ABI, 16-bit PGM files
+    read before the clock starts, host float frames uploaded inside it): what the host side costs without the Python interpreter."""
+    import re
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from g2o_frontend_amd import build
+    from run_cpp_tracker import CONF
+    build.build_tools()
+    exe = os.path.join(ROOT, "tools", "pwn_hip_tracker_app")
+    with tempfile.TemporaryDirectory(prefix="pwn_trk_") as d:
+        lst = []
+        for k, f in enumerate(frames_mm):
+            fn = os.path.join(d, f"d{k}.pgm")
+            with open(fn, "wb") as fh:
+                fh.write(b"P5\n%d %d\n65535\n" % (f.shape[1], f.shape[0])); fh.write(f.astype(">u2").tobytes())
+            lst.append(f"{k * 0.033:.3f} {fn}")
+        with open(os.path.join(d, "list.txt"), "w") as fh:
+            fh.write("\n".join(lst) + "\n")
+        out, tracks = {}, []
+        for ahead in (0, 1):
+            with open(os.path.join(d, "conf.txt"), "w") as fh:
+                fh.write(CONF + f"lookAhead {ahead}\nwarmUp 1\n")
+            prefix = os.path.join(d, f"run{ahead}")
+            r = subprocess.run([exe, os.path.join(d, "conf.txt"), os.path.join(d, "list.txt"), prefix], capture_output=True, text=True, timeout=600)
+            m = re.search(r"tracking: (\d+) frames, ([0-9.eE+-]+) ms per frame", r.stderr)
+            if r.returncode != 0 or not m:
+                raise RuntimeError("pwn_hip_tracker_app failed: " + r.stderr[-300:])
+            ms = float(m.group(2))
+            out["look_ahead" if ahead else "plain"] = {"frames_per_s": 1e3 / ms, "ms_per_frame": ms}
+            tracks.append(open(prefix + "_track.txt", "rb").read())
+        out["track_files_identical"] = tracks[0] == tracks[1]
+        out["note"] = "tools/pwn_hip_tracker_app (C++ mirror), tracking loop with its track-file output; look_ahead = `lookAhead 1` (PwnTracker::prefetch)"
+        return out
+
+
+def run_single_pair_cpp():
+    """configs[1] through the C++ host mirror (tools/pwn_hip_bench with one pair per step: convert 2 resident frames + align, 300 steps)"""
+    import re
+    import subprocess
+    import tempfile
+    from g2o_frontend_amd import build, synth
+    build.build_tools()
+    r, c, _ = synth.make_pair(0, 480, 640, synth.K_VGA)
+    with tempfile.TemporaryDirectory(prefix="pwn_pair_") as d:
+        names = []
+        for tag, img in (("r", r), ("c", c)):
+            fn = os.path.join(d, tag + ".pgm")
+            with open(fn, "wb") as fh:
+                fh.write(b"P5\n%d %d\n65535\n" % (img.shape[1], img.shape[0])); fh.write(img.astype(">u2").tobytes())
+            names.append(fn)
+        with open(os.path.join(d, "list.txt"), "w") as fh:
+            fh.write("\n".join(names) + "\n")
+        out = subprocess.run([os.path.join(ROOT, "tools", "pwn_hip_bench"), os.path.join(d, "list.txt"), "1", "300", "10", "0", "0"],
+                             capture_output=True, text=True, timeout=300)
+        m = re.search(r"ms_per_step ([0-9.eE+-]+)", out.stdout)
+        if out.returncode != 0 or not m:
+            raise RuntimeError("pwn_hip_bench failed: " + (out.stderr or out.stdout)[-300:])
+        return float(m.group(1))
+
+
 def run_tracker_replicas(device, frames_mm, replicas=4, scale=1):
     """the tracker is serial across frames -- more streams, not more GPUs per stream.  `replicas` independent trackers
     (one context and one host thread each, the same 200 frames) on ONE GPU: a single VGA pair fills 150 of the 256 CUs for a few
@@ -906,6 +968,14 @@ def main():
         try:
             extra["tracker_config2"] = run_tracker(local, frames_trk, poses)
             extra["tracker_config2"]["replicas_on_one_gpu"] = run_tracker_replicas(local, frames_trk, replicas=4)
+            try:
+                extra["single_pair_latency_ms_cpp_mirror"] = run_single_pair_cpp()
+            except Exception as e:
+                extra["single_pair_cpp_error"] = repr(e)[:300]
+            try:
+                extra["tracker_config2"]["cpp_mirror"] = run_tracker_cpp(frames_trk)
+            except Exception as e:
+                extra["tracker_config2"]["cpp_mirror"] = {"error": repr(e)[:300]}
         except Exception as e:
             extra["tracker_error"] = repr(e)[:300]
 

@@ -117,6 +117,11 @@ int main(int argc, char** argv) {
     if (!ft) { std::cerr << "cannot write " << prefix << "_track.txt" << std::endl; return 1; }
     std::vector<int> keyframes; std::vector<Isometry3f> keyPoses;
     const bool lookAhead = get("lookAhead", 0.f) != 0.f;       // hand frame k+1 over before frame k is aligned (PwnTracker::prefetch): same track, bit for bit
+    if (get("warmUp", 0.f) != 0.f && frames.size() > 1) {      // timing runs: first-use costs (code objects, the look-ahead helper) outside the clock
+      tracker.processFrame(frames[0], sensorOffset, cameraMatrix, Isometry3f::Identity(), lookAhead ? &frames[1] : nullptr);
+      tracker.processFrame(frames[1], sensorOffset, cameraMatrix);
+      tracker.init();
+    }
     const auto t0 = std::chrono::steady_clock::now();
     for (size_t k = 0; k < frames.size(); ++k) {
       const DepthImage* next = (lookAhead && k + 1 < frames.size()) ? &frames[k + 1] : nullptr;
