@@ -36,5 +36,33 @@ int main() {
     std::snprintf(nm, sizeof nm, "serial(%d) inside block 0 of the 300-block launch", n);
     run(nm, 1000, [&] { hipLaunchKernelGGL(k_serial_then_wide, dim3(300), dim3(256), 0, s, d, n); });
   }
+  // the same dependent chains as ONE hipGraph launch (30 kernel nodes captured from the stream): does a graph shorten the kernel boundary?
+  for (int blocks : { 1, 300 }) {
+    hipGraph_t g; hipGraphExec_t ge;
+    hipStreamBeginCapture(s, hipStreamCaptureModeGlobal);
+    for (int i = 0; i < 30; ++i) hipLaunchKernelGGL(k_empty, dim3(blocks), dim3(256), 0, s, (int*)nullptr);
+    hipStreamEndCapture(s, &g);
+    hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+    char nm[128];
+    std::snprintf(nm, sizeof nm, "graph of 30 empty kernels, %d block(s): per kernel", blocks);
+    for (int i = 0; i < 5; ++i) hipGraphLaunch(ge, s);
+    hipStreamSynchronize(s);
+    auto t0 = std::chrono::steady_clock::now();
+    const int reps = 200;
+    for (int i = 0; i < reps; ++i) hipGraphLaunch(ge, s);
+    hipStreamSynchronize(s);
+    double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps / 30;
+    std::printf("%-62s %8.2f us\n", nm, us);
+    // one graph launch at a time, waited for (what an alignment does): per kernel
+    t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < reps; ++i) { hipGraphLaunch(ge, s); hipStreamSynchronize(s); }
+    us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+    std::printf("  ... one graph launch + wait: %8.2f us (= %.2f per kernel)\n", us, us / 30);
+    t0 = std::chrono::steady_clock::now();
+    for (int i = 0; i < reps; ++i) { for (int k = 0; k < 30; ++k) hipLaunchKernelGGL(k_empty, dim3(blocks), dim3(256), 0, s, (int*)nullptr); hipStreamSynchronize(s); }
+    us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() / reps;
+    std::printf("  ... 30 stream launches + wait:  %8.2f us (= %.2f per kernel)\n", us, us / 30);
+    hipGraphExecDestroy(ge); hipGraphDestroy(g);
+  }
   return 0;
 }
