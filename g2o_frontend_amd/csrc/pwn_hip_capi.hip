@@ -1401,6 +1401,7 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
   const bool batch_shortcut = n >= 1 && ctx->index_shortcut && is_identity(forced(p->current_sensor_offset));
   std::vector<char> own_index((size_t)std::max(n, 1), 0), own_ref((size_t)std::max(n, 1), 0);
   const bool ident_ref = is_identity(forced(p->reference_sensor_offset));
+  const bool direct_state = n <= 4;
   // descriptors + initial states of all pairs; workspace slots are reused round-robin across sub-batches
   for (int i = 0; i < n; ++i) {
     const pwn_hip_cloud* r = refs[i]; const pwn_hip_cloud* c = curs[i];
@@ -1417,7 +1418,9 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
                    c->idx_maxD == p->max_distance && std::memcmp(c->idx_K, p->K, sizeof(c->idx_K)) == 0;
     pd.partials = ctx->partials_ws + (size_t)slot * ctx->nblocks_max * kAccN;
     pd.state = ctx->state_ws + i;
-    pd.state_out = ctx->state_host + i;         // page-locked: k_solve_update writes the pose and the traces there, no copy back at the end
+    // a few pairs (latency path): k_solve_update writes the pose and the traces into the page-locked host copy itself, no copy back at the end;
+    // batches copy the states back in one transfer (64 workgroups storing across PCIe in every solve launch cost more than that: 16 against 11 us per launch)
+    pd.state_out = direct_state ? ctx->state_host + i : nullptr;
     // initial state: aligner.cpp:60-64,72-73,79,84
     PairState& st = ctx->state_host[i];
     std::memset(&st, 0, sizeof(st));
@@ -1515,8 +1518,9 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
   if (int rc = plan_join(ctx, plan)) return rc;
   if (n > 0 && scores) HIPCHK(ctx, hipMemcpyAsync(ctx->match_host, ctx->match_dev, sizeof(MatchAcc) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
   if (n > 0 && statistics) HIPCHK(ctx, hipMemcpyAsync(ctx->stats_host, ctx->stats_dev, sizeof(SolveOut) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
-  // state_host[i]: T, it and the traces were written by the last k_solve_update of each pair (PairDesc::state_out); with no iterations it still
-  // holds the initial state
+  // direct_state: T, it and the traces of state_host[i] were written by the last k_solve_update of each pair (PairDesc::state_out); with no
+  // iterations it still holds the initial state
+  if (n > 0 && !direct_state) HIPCHK(ctx, hipMemcpyAsync(ctx->state_host, ctx->state_ws, sizeof(PairState) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipEventRecord(ctx->t1, ctx->stream), PWN_HIP_ERR_LAUNCH);      // before the wait: recording it afterwards costs a second round trip per call
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
   for (int i = 0; i < n; ++i) {

@@ -2072,18 +2072,29 @@ __device__ __forceinline__ void assemble_Hb(const double* s, float* H, float* b)
 #ifndef PWN_SOLVE_X
 #define PWN_SOLVE_X 0     // timing experiments only (results wrong): 1 = no LDLT, 2 = no end-of-iteration pose clean-up, 4 = first partial record only
 #endif
-// One Gauss-Newton step from the reduced sums: what k_solve_update stores into the PairState, as a pure function of (sums, the state before the
-// step).  (Round 3 evaluated it redundantly in every workgroup of the next projection -- one launch instead of two on the latency path: 26 us
-// against 9 + 6 us, the serial step is paid by every workgroup; docs/experiments.md.)
-struct StateUpdate {
-  float chi2; int inliers, ncorr, ncand, it;
-  Mat4 T, invTcorrPrev, invTcorr, invT, KRtLast, KRt;
-};
-__device__ __forceinline__ void solve_step(const double* sums, const PairState& st, const AlignParams& ap, const int outerEnd, StateUpdate& u) {
+// The step is written out in the kernel, on registers with constant indices only.  (Round 3 had it as a pure function returning the new state in a
+// struct, for two experiments that evaluated it inside other kernels: the struct cost the kernel 29 VGPRs, 68 bytes of scratch and a 16 KB
+// LDS-promoted array, and a 64-pair launch 18 us instead of 10.5 -- found in the v14 kernel trace and undone.)
+// last: this is the alignment's final step -- with pd.state_out set (a few pairs: latency path), the pose goes to the page-locked host copy of
+// the state as well (the traces go there step by step), and the host needs no copy back of the state.
+__global__ void __launch_bounds__(256) k_solve_update(const PairDesc* __restrict__ pairs, AlignParams ap, int nblocks, int outerEnd, int last) {
+  const PairDesc& pd = pairs[blockIdx.x];
+  __shared__ double sums[kAccN];
+  reduce_partials(pd.partials, (PWN_SOLVE_X & 4) ? 1 : nblocks, sums);
+  if (threadIdx.x != 0) return;
+  PairState& st = *pd.state;
+  PairState* const so = pd.state_out;
   float H[36], b[6];                                                     // registers: every index below is a constant
   assemble_Hb(sums, H, b);
-  u.it = st.it;
-  u.chi2 = (float)sums[33]; u.inliers = (int)sums[34]; u.ncorr = (int)sums[35]; u.ncand = (int)sums[36];
+  const int it = st.it;
+  if (it < kMaxIter) {
+    st.chi2[it] = (float)sums[33];
+    st.inliers[it] = (int)sums[34];
+    st.ncorr[it] = (int)sums[35];
+    st.ncand[it] = (int)sums[36];
+    if (so) { so->chi2[it] = (float)sums[33]; so->inliers[it] = (int)sums[34]; so->ncorr[it] = (int)sums[35]; so->ncand[it] = (int)sums[36]; }
+  }
+  st.it = it + 1;
 #pragma unroll
   for (int d = 0; d < 6; ++d) H[d + 6 * d] = H[d + 6 * d] + 1.0f;        // aligner.cpp:92
 #pragma unroll
@@ -2100,47 +2111,25 @@ __device__ __forceinline__ void solve_step(const double* sums, const PairState& 
   Mat4 invT = st.invT;
   set_last_row(invT);
   invT = iso_mul(v2t(dx), invT);
-  u.T = st.T; u.invTcorrPrev = st.invTcorrPrev; u.invTcorr = st.invTcorr; u.KRtLast = st.KRtLast; u.KRt = st.KRt;
   if (outerEnd && !(PWN_SOLVE_X & 2)) {
     Mat4 T = iso_inverse(invT);
     float v[6];
     t2v(T, v);
     T = v2t(v);
     set_last_row(T);
-    u.T = T;
+    st.T = T;
+    if (so && last) { so->T = T; so->it = it + 1; }
     const Mat4 Tinv = iso_inverse(T);
-    u.invTcorrPrev = st.invTcorr;
-    u.invTcorr = Tinv;
+    st.invTcorrPrev = st.invTcorr;
+    st.invTcorr = Tinv;
     invT = Tinv;
     Mat4 KRt, iKRt; Mat3 iK;
     projector_matrices(ap.K, iso_mul(T, ap.refOffset), KRt, iKRt, iK);
-    u.KRtLast = st.KRt;         // the reference projection of this outer iteration (what the finder's depth image belongs to)
-    u.KRt = KRt;
+    st.KRtLast = st.KRt;        // the reference projection of this outer iteration (what the finder's depth image belongs to)
+    st.KRt = KRt;
   }
   set_last_row(invT);
-  u.invT = invT;
-}
-__device__ __forceinline__ void apply_update(PairState& st, const StateUpdate& u, const int outerEnd) {
-  if (u.it < kMaxIter) { st.chi2[u.it] = u.chi2; st.inliers[u.it] = u.inliers; st.ncorr[u.it] = u.ncorr; st.ncand[u.it] = u.ncand; }
-  st.it = u.it + 1;
-  if (outerEnd) { st.T = u.T; st.invTcorrPrev = u.invTcorrPrev; st.invTcorr = u.invTcorr; st.KRtLast = u.KRtLast; st.KRt = u.KRt; }
-  st.invT = u.invT;
-}
-// last: this is the alignment's final step -- with pd.state_out set, the pose goes to the host copy as well (the traces go there step by step),
-// and the host needs no copy back of the state.
-__global__ void __launch_bounds__(256) k_solve_update(const PairDesc* __restrict__ pairs, AlignParams ap, int nblocks, int outerEnd, int last) {
-  const PairDesc& pd = pairs[blockIdx.x];
-  __shared__ double sums[kAccN];
-  reduce_partials(pd.partials, (PWN_SOLVE_X & 4) ? 1 : nblocks, sums);
-  if (threadIdx.x != 0) return;
-  PairState& st = *pd.state;
-  StateUpdate u;
-  solve_step(sums, st, ap, outerEnd, u);
-  apply_update(st, u, outerEnd && !(PWN_SOLVE_X & 2));
-  if (PairState* so = pd.state_out) {
-    if (u.it < kMaxIter) { so->chi2[u.it] = u.chi2; so->inliers[u.it] = u.inliers; so->ncorr[u.it] = u.ncorr; so->ncand[u.it] = u.ncand; }
-    if (last) { so->T = u.T; so->it = u.it + 1; }
-  }
+  st.invT = invT;
 }
 // reduction only, one record per pair (Aligner::_computeStatistics' 11th update).  grid = pairs, block = 256
 __global__ void __launch_bounds__(256) k_reduce_pairs(const PairDesc* __restrict__ pairs, int nblocks, SolveOut* __restrict__ out) {

@@ -244,3 +244,58 @@ def test_packed_xyz_records_are_accessed_as_12_byte_words():
     assert get(r"7k_statsE", "global_store_dwordx3") >= 4 and get(r"7k_statsE", "global_store_dwordx4") <= 1      # P3 + 3 rows; Nc is the one float4
     assert get(r"20k_unproject_integralE", "global_store_dwordx4") == 0 and get(r"25k_unproject_integral_rowsE", "global_store_dwordx4") == 0
     assert get(r"16k_corr_linearizeI", "global_load_dwordx3") >= 10
+
+
+def _gfx950_code_object():
+    import struct
+    from g2o_frontend_amd import _lib
+    blob = open(_lib.LIB_PATH, "rb").read()
+    i = blob.find(b"__CLANG_OFFLOAD_BUNDLE__")
+    assert i >= 0
+    n = struct.unpack_from("<Q", blob, i + 24)[0]; off = i + 32
+    for _ in range(n):
+        o, sz, tl = struct.unpack_from("<QQQ", blob, off); name = blob[off + 24: off + 24 + tl].decode(); off += 24 + tl
+        if "gfx950" in name:
+            return blob[i + o: i + o + sz]
+    raise AssertionError("no gfx950 code object in the library")
+
+
+def test_kernel_resources_of_the_hot_and_the_serial_kernels():
+    """Register / scratch / LDS budget of the kernels whose speed depends on it, read from the code object's metadata.  Round 3 lost 8 us per
+    64-pair launch of k_solve_update (10.5 -> 18 us) to a refactoring that made the compiler spill 68 bytes and promote an array to 16 KB of LDS;
+    nothing but a kernel trace showed it.  Bars: no scratch anywhere on the path's kernels; k_solve_update's LDS is its reduction buffers only;
+    the fused pass keeps its 5 waves per SIMD (<= 96 VGPRs... 102 is the allocation granule's limit for 5), k_stats its 8 (<= 64)."""
+    import subprocess
+    import tempfile
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("llvm-readelf not installed")
+    with tempfile.NamedTemporaryFile(suffix=".co") as f:
+        f.write(_gfx950_code_object()); f.flush()
+        notes = subprocess.run([readelf, "--notes", f.name], capture_output=True, text=True).stdout
+    kernels, cur = {}, None
+    for line in notes.splitlines():
+        m = re.match(r"\s*-?\s*\.(\w+):\s*(\S+)", line)
+        if not m:
+            continue
+        key, val = m.group(1), m.group(2)
+        if key == "group_segment_fixed_size":
+            cur = {"lds": int(val)}
+        elif cur is not None and key == "name":
+            kernels[val] = cur
+        elif cur is not None and key in ("private_segment_fixed_size", "vgpr_count", "sgpr_count"):
+            cur[{"private_segment_fixed_size": "scratch", "vgpr_count": "vgpr", "sgpr_count": "sgpr"}[key]] = int(val)
+    def one(sub):
+        hits = [(k, v) for k, v in kernels.items() if re.search(sub, k)]
+        assert hits, (sub, sorted(kernels)[:5])
+        return hits
+    for sub in (r"14k_solve_updateE", r"7k_statsE", r"16k_corr_linearizeI", r"20k_corr_linearize_latI", r"9k_projectI", r"20k_unproject_integralE",
+                r"25k_unproject_integral_rowsE", r"15k_integral_colsE", r"13k_strip_countI"):
+        for name, r in one(sub):
+            assert r["scratch"] == 0, (name, r)
+    (name, r), = one(r"14k_solve_updateE")
+    assert r["lds"] <= 4096 and r["vgpr"] <= 96, (name, r)
+    for name, r in one(r"7k_statsE"):
+        assert r["vgpr"] <= 64, (name, r)
+    for name, r in one(r"16k_corr_linearizeILb1ELb0E"):
+        assert r["vgpr"] <= 102, (name, r)
