@@ -56,6 +56,8 @@ def parse(argv=None):
     ap.add_argument("--tracker-frames", type=int, default=200)
     ap.add_argument("--cpu-baseline-only", action="store_true", help="(internal) run only the CPU baseline leg and print its JSON")
     ap.add_argument("--no-profile", action="store_true", help="skip the serial profiled pass (roofline fields become 0)")
+    ap.add_argument("--omega-storage", choices=("exact9", "sym6"), default=os.environ.get("PWN_OMEGA_STORAGE", "sym6"),
+                    help="storage of the clouds' point information matrices in the batch workload (include/pwn_hip.h: pwn_hip_ctx_set_omega_storage)")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the batch calls use in the timed region (1 = serial)")
     ap.add_argument("--render-workers", type=int, default=0,
                     help="processes that render the synthetic frames (0 = automatic; 1 = in this process: required under rocprofv3, whose preloaded "
@@ -281,7 +283,7 @@ class BatchWorkload:
         self.K, self.conv, self.alig = conf(rows, cols)
         self.n_it = self.alig["outer_iterations"] * self.alig["inner_iterations"]
         slots = max(2, args.streams) * max(args.sub_frames, args.sub_pairs, 1)      # room for one sub-batch in flight per stream
-        self.ctx = api.Context(device=device, max_rows=rows, max_cols=cols, max_batch=slots)
+        self.ctx = api.Context(device=device, max_rows=rows, max_cols=cols, max_batch=slots, omega_storage=getattr(args, "omega_storage", "exact9"))
         self.ctx.set_subbatch(args.sub_frames, args.sub_pairs)
         self.converter, self.aligner = build_objects(self.ctx, rows, cols, self.K, self.conv, self.alig)
         self.frames_mm = frames_mm
@@ -783,13 +785,13 @@ def kernel_source_digest():
     return h.hexdigest()[:16]
 
 
-def check_records_crc(allrec, rows, cols, write=False):
+def check_records_crc(allrec, rows, cols, write=False, omega_storage="exact9"):
     crc = records_crc(allrec)
     src = kernel_source_digest()
     if write:
         with open(RECORDS_CRC_FILE, "w") as f:
             json.dump({"made_by": "bench.py --gpus 1 --total-pairs %d --write-records-crc (one MI355X)" % len(crc), "rows": rows, "cols": cols,
-                       "kernel_source_digest": src, "pairs": len(crc), "crc32": crc}, f)
+                       "omega_storage": omega_storage, "kernel_source_digest": src, "pairs": len(crc), "crc32": crc}, f)
     if not os.path.exists(RECORDS_CRC_FILE):
         return {"checked": 0, "note": "no profiles/records_crc.json"}
     try:
@@ -798,6 +800,8 @@ def check_records_crc(allrec, rows, cols, write=False):
         return {"checked": 0, "note": "unreadable: %r" % (e,)}
     if (g.get("rows"), g.get("cols")) != (rows, cols):
         return {"checked": 0, "note": "file is for another frame size"}
+    if g.get("omega_storage", "exact9") != omega_storage:
+        return {"checked": 0, "note": "file is for omega_storage = %s" % g.get("omega_storage", "exact9")}
     n = min(len(crc), g["pairs"])
     bad = [i for i in range(n) if crc[i] != g["crc32"][i]]
     return {"checked": n, "equal": not bad, "first_mismatch": bad[0] if bad else None, "mismatches": len(bad),
@@ -925,7 +929,7 @@ def main():
                        "records_equal_local": bool(np.array_equal(allrec[np.asarray(seeds)].view(np.uint32), mine.view(np.uint32)))}
         # determinism gate of the multi-GPU leg: a pair's record does not depend on which GPU aligned it, in which sub-batch or next to which
         # other pairs (tests/test_gpu_properties.py), so the records any N assembles must equal, bit for bit, those of the one-GPU run
-        gather_info["records_vs_single_gpu_run"] = check_records_crc(allrec, rows, cols, write=args.write_records_crc and world == 1)
+        gather_info["records_vs_single_gpu_run"] = check_records_crc(allrec, rows, cols, write=args.write_records_crc and world == 1, omega_storage=args.omega_storage)
 
     extra = {}
     if not args.no_latency and rank == 0:
@@ -992,7 +996,7 @@ def main():
                                    f"(u16 mm frames resident in HBM; per pair: convert 2 frames + Aligner::align, "
                                    f"{alig['outer_iterations']}x{alig['inner_iterations']} GN iterations); BASELINE configs[3] shard",
                        "pairs_per_gpu": P, "total_pairs": total, "rows": rows, "cols": cols, "sub_frames": args.sub_frames, "sub_pairs": args.sub_pairs,
-                       "streams": args.streams,
+                       "streams": args.streams, "omega_storage": args.omega_storage,
                        "parallelism": f"independent pairs sharded over {n_seen} GPU(s), RCCL all-gather of result records only"},
             "roofline": rep["roofline"],
             "cpu_baseline": cpu,

@@ -72,6 +72,8 @@ PROTOTYPES = {
     "pwn_hip_ctx_synchronize": (_I, [_VP]),
     "pwn_hip_ctx_set_subbatch": (_I, [_VP, _I, _I]),
     "pwn_hip_ctx_set_concurrency": (_I, [_VP, _I]),
+    "pwn_hip_ctx_set_omega_storage": (_I, [_VP, _I]),
+    "pwn_hip_cloud_omega_storage": (_I, [_VP, _VP, C.POINTER(_I)]),
     "pwn_hip_last_error_string": (C.c_char_p, [_VP]),
     "pwn_hip_device_count": (_I, []),
     "pwn_hip_host_alloc": (_I, [C.POINTER(C.c_void_p), C.c_size_t]),

@@ -137,6 +137,9 @@ ALIGN_RESULT_DTYPE = np.dtype([("T", np.float32, 16), ("error", np.float32), ("i
 assert ALIGN_RESULT_DTYPE.itemsize == C.sizeof(AlignResult)
 
 
+OMEGA_STORAGE = {"exact9": 0, "sym6": 1}      # PWN_HIP_OMEGA_EXACT9 / PWN_HIP_OMEGA_SYM6
+
+
 def device_count() -> int:
     return _lib.lib().pwn_hip_device_count()
 
@@ -145,7 +148,7 @@ class Context:
     """One per (GPU, host thread): owns the stream and the device workspaces
     (cf. pwn_cuda createContext, pwn_cuda/cudaaligner.h:59)."""
 
-    def __init__(self, device: int = 0, max_rows: int = 480, max_cols: int = 640, max_batch: int = 1):
+    def __init__(self, device: int = 0, max_rows: int = 480, max_cols: int = 640, max_batch: int = 1, omega_storage: str = "exact9"):
         self._L = _lib.lib()
         h = C.c_void_p()
         rc = self._L.pwn_hip_ctx_create(C.byref(h), device, max_rows, max_cols, max_batch)
@@ -153,6 +156,9 @@ class Context:
             raise PwnHipError(rc, self._L.pwn_hip_last_error_string(None).decode())
         self.h = h
         self.max_rows, self.max_cols, self.max_batch = max_rows, max_cols, max_batch
+        self.omega_storage = "exact9"
+        if omega_storage != "exact9":
+            self.set_omega_storage(omega_storage)
 
     def check(self, rc):
         if rc:
@@ -177,6 +183,14 @@ class Context:
 
     def set_concurrency(self, streams: int):
         self.check(self._L.pwn_hip_ctx_set_concurrency(self.h, streams))
+
+    def set_omega_storage(self, mode: str):
+        """storage of the point information matrices of the clouds created from now on: "exact9" (all nine entries as the reference
+        evaluates them; every converter output bit-identical) or "sym6" (upper triangle, 24 bytes; include/pwn_hip.h)"""
+        if mode not in OMEGA_STORAGE:
+            raise ValueError(f"omega_storage must be one of {sorted(OMEGA_STORAGE)}")
+        self.check(self._L.pwn_hip_ctx_set_omega_storage(self.h, OMEGA_STORAGE[mode]))
+        self.omega_storage = mode
 
     def upload(self, array):
         """DeviceBuffer holding a copy of a host array (pwn_hip_device_alloc + pwn_hip_copy): a frame resident in HBM without torch"""
@@ -248,6 +262,12 @@ class Cloud:
         return n.value
 
     __len__ = size
+
+    def omega_storage(self) -> str:
+        """"exact9" or "sym6": how this cloud keeps its point information matrices (Context.set_omega_storage at its creation)"""
+        m = C.c_int(0)
+        self.ctx.check(self.ctx._L.pwn_hip_cloud_omega_storage(self.ctx.h, self.h, C.byref(m)))
+        return "sym6" if m.value == OMEGA_STORAGE["sym6"] else "exact9"
 
     def upload(self, points, normals, curvature, omega_p, omega_n):
         a = [np.ascontiguousarray(x, dtype=np.float32) for x in (points, normals, curvature, omega_p, omega_n)]

@@ -82,6 +82,7 @@ struct pwn_hip_ctx {
   size_t N = 0;
   int sub_frames = 64, sub_pairs = 64;
   int concurrency = 2;
+  int omega_sym = 0;                       // pwn_hip_ctx_set_omega_storage: storage of the point information matrices of clouds created from now on
   // convert workspaces (per slot)
   float* depth_ws = nullptr; int* index_ws = nullptr; int* interval_ws = nullptr; float* integral_ws = nullptr; int* rowoff_ws = nullptr;
   uint16_t* raw_ws = nullptr;
@@ -140,7 +141,8 @@ struct pwn_hip_ctx {
 namespace {
 
 constexpr size_t kCloudPoolBytes = 1ull << 30;
-size_t cloud_core_bytes(const pwn_hip_cloud* c) { return (size_t)c->d.capacity * (3 * sizeof(float) + sizeof(float4) + 9 * sizeof(float)) + c->idx_cap * sizeof(int); }
+size_t om_floats(const CloudDev& d) { return (size_t)d.capacity * 3 * (size_t)om_planes(d.omSym); }      // floats of the Om planes (9 or 6 per point)
+size_t cloud_core_bytes(const pwn_hip_cloud* c) { return (size_t)c->d.capacity * (3 * sizeof(float) + sizeof(float4)) + om_floats(c->d) * sizeof(float) + c->idx_cap * sizeof(int); }
 void cloud_free(pwn_hip_cloud* c) {
   void* p[] = { c->d.P3, c->d.Nc, c->d.Om, c->d.OmN, c->d.St, c->d.count, c->sb.G, c->sb.Gf,
                 c->back.P3, c->back.Nc, c->back.Om, c->back.OmN, c->back.St, c->sback.G, c->sback.Gf, c->idximg };
@@ -151,10 +153,16 @@ void cloud_free(pwn_hip_cloud* c) {
 // the fused correspondence + linearize pass: the throughput shape, or the latency shape (same sums bit for bit, see k_corr_linearize_lat)
 // when all workgroups of the launch find a CU of their own -- its 1024-thread workgroups fit one per CU, a second round costs more than
 // the shape saves: one VGA pair is 150 workgroups, two pairs or one 1280x960 pair are not worth it on 256 CUs
+// sym: storage of the current clouds' point information matrices (CloudDev::omSym; the same for every pair of the launch)
+template <bool SAME_T, bool FULL_H, bool SYM>
+void launch_corr_linearize_s(const pwn_hip_ctx* ctx, int nb, int m, hipStream_t st, const PairDesc* pr, const AlignParams& ap, unsigned tag, int usePrevTc, int ownRef) {
+  if ((long long)nb * m <= ctx->num_cus) hipLaunchKernelGGL((k_corr_linearize_lat<SAME_T, FULL_H, SYM>), dim3(nb, m), dim3(kLatBlock), 0, st, pr, ap, tag, usePrevTc, ownRef);
+  else hipLaunchKernelGGL((k_corr_linearize<SAME_T, FULL_H, SYM>), dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, tag, usePrevTc, ownRef);
+}
 template <bool SAME_T, bool FULL_H>
-void launch_corr_linearize(const pwn_hip_ctx* ctx, int nb, int m, hipStream_t st, const PairDesc* pr, const AlignParams& ap, unsigned tag, int usePrevTc, int ownRef) {
-  if ((long long)nb * m <= ctx->num_cus) hipLaunchKernelGGL((k_corr_linearize_lat<SAME_T, FULL_H>), dim3(nb, m), dim3(kLatBlock), 0, st, pr, ap, tag, usePrevTc, ownRef);
-  else hipLaunchKernelGGL((k_corr_linearize<SAME_T, FULL_H>), dim3(nb, m), dim3(kAlignBlock), 0, st, pr, ap, tag, usePrevTc, ownRef);
+void launch_corr_linearize(const pwn_hip_ctx* ctx, int sym, int nb, int m, hipStream_t st, const PairDesc* pr, const AlignParams& ap, unsigned tag, int usePrevTc, int ownRef) {
+  if (sym) launch_corr_linearize_s<SAME_T, FULL_H, true>(ctx, nb, m, st, pr, ap, tag, usePrevTc, ownRef);
+  else launch_corr_linearize_s<SAME_T, FULL_H, false>(ctx, nb, m, st, pr, ap, tag, usePrevTc, ownRef);
 }
 
 // projection of one cloud of each of the m pairs (which: 0 = reference, 1 = current): four points per thread when the launch is large
@@ -281,6 +289,7 @@ ConvertParams make_convert_params(const pwn_hip_ctx* ctx, const pwn_hip_converte
   cp.hasOffset = is_identity(cp.offset) ? 0 : 1;
   cp.keepStats = keep_stats;
   cp.lean = 0;
+  cp.omSym = 0;        // set per call from the clouds being written (convert_batch_impl)
   return cp;
 }
 // class matrices of the normal information matrix, after Cloud::transformInPlace (T * Omega * T^t, informationmatrix.h:111-121)
@@ -541,6 +550,8 @@ int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, cons
   for (int i = 0; i < n; ++i) {
     pwn_hip_cloud* c = clouds[i];
     if (!c || !frames[i]) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null frame or cloud");
+    if (i == 0) cp.omSym = c->d.omSym;
+    else if (c->d.omSym != cp.omSym) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "clouds of one convert batch must share one omega storage (exact9 / sym6)");
     cloud_changes(ctx, c);
     if (keep_stats) { if (int rc = ensure_stats(ctx, c)) return rc; }
     c->has_stats = keep_stats != 0;
@@ -842,6 +853,16 @@ int pwn_hip_ctx_set_subbatch(pwn_hip_ctx* ctx, int frames, int pairs) {
   ctx->sub_frames = std::min(frames, ctx->max_batch); ctx->sub_pairs = std::min(pairs, ctx->max_batch);
   return PWN_HIP_OK;
 }
+int pwn_hip_ctx_set_omega_storage(pwn_hip_ctx* ctx, int mode) {
+  if (!ctx || (mode != PWN_HIP_OMEGA_EXACT9 && mode != PWN_HIP_OMEGA_SYM6)) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "omega storage must be PWN_HIP_OMEGA_EXACT9 or PWN_HIP_OMEGA_SYM6");
+  ctx->omega_sym = mode == PWN_HIP_OMEGA_SYM6 ? 1 : 0;
+  return PWN_HIP_OK;
+}
+int pwn_hip_cloud_omega_storage(pwn_hip_ctx* ctx, const pwn_hip_cloud* c, int* mode) {
+  if (!c || !mode) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  *mode = c->d.omSym ? PWN_HIP_OMEGA_SYM6 : PWN_HIP_OMEGA_EXACT9;
+  return PWN_HIP_OK;
+}
 int pwn_hip_ctx_set_concurrency(pwn_hip_ctx* ctx, int streams) {
   if (!ctx || streams < 1 || streams > 4) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "streams must be 1..4");
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
@@ -940,7 +961,7 @@ int pwn_hip_cloud_create(pwn_hip_ctx* ctx, int capacity, pwn_hip_cloud** out) {
   HIPCHK(ctx, hipSetDevice(ctx->device), PWN_HIP_ERR_NO_DEVICE);
   for (size_t k = 0; k < ctx->cloud_pool.size(); ++k) {
     pwn_hip_cloud* r = ctx->cloud_pool[k];
-    if (r->d.capacity != capacity) continue;
+    if (r->d.capacity != capacity || r->d.omSym != ctx->omega_sym) continue;
     ctx->cloud_pool.erase(ctx->cloud_pool.begin() + (long)k);
     ctx->cloud_pool_bytes -= cloud_core_bytes(r);
     HIPCHK(ctx, hipMemsetAsync(r->d.count, 0, sizeof(int), ctx->stream), PWN_HIP_ERR_COPY);      // stream order: after whatever used the retired cloud
@@ -950,10 +971,11 @@ int pwn_hip_cloud_create(pwn_hip_ctx* ctx, int capacity, pwn_hip_cloud** out) {
   pwn_hip_cloud* c = new pwn_hip_cloud();
   std::memset(&c->d, 0, sizeof(c->d));
   c->d.capacity = capacity;
+  c->d.omSym = ctx->omega_sym;
   const size_t cap = (size_t)capacity;
   hipError_t e = hipMalloc((void**)&c->d.P3, cap * 3 * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void**)&c->d.Nc, cap * sizeof(float4));
-  if (e == hipSuccess) e = hipMalloc((void**)&c->d.Om, cap * 9 * sizeof(float));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d.Om, om_floats(c->d) * sizeof(float));
   if (e == hipSuccess) e = hipMalloc((void**)&c->d.count, sizeof(int));
   if (e == hipSuccess) e = hipMemsetAsync(c->d.count, 0, sizeof(int), ctx->stream);
   if (e != hipSuccess) { pwn_hip_cloud_destroy(ctx, c); return fail(ctx, PWN_HIP_ERR_ALLOCATION, std::string("cloud allocation: ") + hipGetErrorString(e)); }
@@ -998,13 +1020,14 @@ int pwn_hip_cloud_upload(pwn_hip_ctx* ctx, pwn_hip_cloud* c, int n, const float*
   HIPCHK(ctx, copy_any(hon.data(), omega_n, hon.size() * 4, ctx->stream), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_COPY);
   const size_t cap = (size_t)c->d.capacity;
-  std::vector<float> P((size_t)n * 4), Nm((size_t)n * 4), Om(cap * 9, 0.f), OmN(cap * 9, 0.f);
+  const int sym = c->d.omSym;
+  std::vector<float> P((size_t)n * 4), Nm((size_t)n * 4), Om(om_floats(c->d), 0.f), OmN(cap * 9, 0.f);
   for (int i = 0; i < n; ++i) {
     P[4 * i] = hp[4 * i]; P[4 * i + 1] = hp[4 * i + 1]; P[4 * i + 2] = hp[4 * i + 2]; P[4 * i + 3] = hc[i];
     Nm[4 * i] = hn[4 * i]; Nm[4 * i + 1] = hn[4 * i + 1]; Nm[4 * i + 2] = hn[4 * i + 2];
     const int one = 1; std::memcpy(&Nm[4 * i + 3], &one, 4);
     for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) {
-      Om[om_at(cap, i, 3 * r + q)] = hop[(size_t)16 * i + r + 4 * q];      // column-major 4x4 -> entry (r,q)
+      if (!(sym && om_is_lower(3 * r + q))) Om[omp_at(cap, i, 3 * r + q, sym)] = hop[(size_t)16 * i + r + 4 * q];      // column-major 4x4 -> entry (r,q); sym6 keeps the upper triangle
       OmN[om_at(cap, i, 3 * r + q)] = hon[(size_t)16 * i + r + 4 * q];
     }
   }
@@ -1027,7 +1050,7 @@ int pwn_hip_cloud_download(pwn_hip_ctx* ctx, const pwn_hip_cloud* c, float* poin
   if (normals) { hn.resize((size_t)n * 4); for (int i = 0; i < n; ++i) { hn[4*i] = Nm[4*i]; hn[4*i+1] = Nm[4*i+1]; hn[4*i+2] = Nm[4*i+2]; hn[4*i+3] = 0.0f; } }
   if (curvature) { hc.resize(n); for (int i = 0; i < n; ++i) hc[i] = P[4*i+3]; }
   if (omega_p || omega_n) {
-    std::vector<float> Om(cap * 9), OmN;
+    std::vector<float> Om(om_floats(c->d)), OmN;
     HIPCHK(ctx, hipMemcpy(Om.data(), c->d.Om, Om.size() * 4, hipMemcpyDeviceToHost), PWN_HIP_ERR_COPY);
     if (c->d.OmN) { OmN.resize(cap * 9); HIPCHK(ctx, hipMemcpy(OmN.data(), c->d.OmN, OmN.size() * 4, hipMemcpyDeviceToHost), PWN_HIP_ERR_COPY); }
     if (omega_p) hop.assign((size_t)n * 16, 0.f);
@@ -1035,7 +1058,7 @@ int pwn_hip_cloud_download(pwn_hip_ctx* ctx, const pwn_hip_cloud* c, float* poin
     for (int i = 0; i < n; ++i) {
       int cls; std::memcpy(&cls, &Nm[4 * i + 3], 4); cls &= kClsMask;
       for (int r = 0; r < 3; ++r) for (int q = 0; q < 3; ++q) {
-        if (omega_p) hop[(size_t)16 * i + r + 4 * q] = Om[om_at(cap, i, 3 * r + q)];
+        if (omega_p) hop[(size_t)16 * i + r + 4 * q] = Om[omp_at(cap, i, 3 * r + q, c->d.omSym)];      // sym6: the stored upper triangle, mirrored
         if (omega_n) {
           float v = 0.f;
           if (c->d.OmN) v = OmN[om_at(cap, i, 3 * r + q)];
@@ -1167,7 +1190,7 @@ int pwn_hip_unproject(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const
   const float* d = nullptr;
   if (int rc = stage_depth(ctx, depth, N, &d)) return rc;
   HIPCHK(ctx, hipMemsetAsync(cloud->d.Nc, 0, sizeof(float4) * (size_t)cloud->d.capacity, ctx->stream), PWN_HIP_ERR_COPY);
-  HIPCHK(ctx, hipMemsetAsync(cloud->d.Om, 0, sizeof(float) * 9 * (size_t)cloud->d.capacity, ctx->stream), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipMemsetAsync(cloud->d.Om, 0, sizeof(float) * om_floats(cloud->d), ctx->stream), PWN_HIP_ERR_COPY);
   fill_frame(ctx, 0, 0, d, cloud->d, rows);
   HIPCHK(ctx, hipMemcpyAsync(ctx->frames_dev, ctx->frames_host, sizeof(FrameDesc), hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
   hipLaunchKernelGGL(k_row_count, dim3(rows, 1), dim3(256), 0, ctx->stream, ctx->frames_dev, cp);
@@ -1402,10 +1425,12 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
   std::vector<char> own_index((size_t)std::max(n, 1), 0), own_ref((size_t)std::max(n, 1), 0);
   const bool ident_ref = is_identity(forced(p->reference_sensor_offset));
   const bool direct_state = n <= 4;
+  const int omSym = (n > 0 && curs[0]) ? curs[0]->d.omSym : 0;      // the linearizer reads the CURRENT cloud's information matrices (linearizer.cpp:52-53)
   // descriptors + initial states of all pairs; workspace slots are reused round-robin across sub-batches
   for (int i = 0; i < n; ++i) {
     const pwn_hip_cloud* r = refs[i]; const pwn_hip_cloud* c = curs[i];
     if (!r || !c) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null cloud in batch");
+    if (c->d.omSym != omSym) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "current clouds of one batch must share one omega storage (exact9 / sym6)");
     const int slot = plan.slot0(i / sub) + i % sub;
     PairDesc& pd = ctx->pairs_host[i];
     pd.ref = r->d; pd.cur = c->d;
@@ -1495,8 +1520,8 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
         const bool lastInner = (k == p->inner_iterations - 1);
         { StageTimer t(ctx, "corr_linearize", st);
           // first inner pass: the linearizer's transform is bitwise the finder's (aligner.cpp:79,84)
-          if (k == 0) launch_corr_linearize<true, false>(ctx, nb, m, st, pr, ap, tag, 0, ownRef);
-          else launch_corr_linearize<false, false>(ctx, nb, m, st, pr, ap, tag, 0, ownRef); }
+          if (k == 0) launch_corr_linearize<true, false>(ctx, omSym, nb, m, st, pr, ap, tag, 0, ownRef);
+          else launch_corr_linearize<false, false>(ctx, omSym, nb, m, st, pr, ap, tag, 0, ownRef); }
         { StageTimer t(ctx, "solve", st);
           hipLaunchKernelGGL(k_solve_update, dim3(m), dim3(256), 0, st, pr, ap, nb, lastInner ? 1 : 0, (lastInner && i == p->outer_iterations - 1) ? 1 : 0); }
       }
@@ -1505,7 +1530,7 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
       // Aligner::_computeStatistics' extra Linearizer::update: the finder's correspondences of the last outer iteration
       // (tests with that iteration's transform) re-linearized at the final transform (aligner.cpp:165-170)
       StageTimer t(ctx, "statistics", st);
-      launch_corr_linearize<false, true>(ctx, nb, m, st, pr, ap, subLastRefTag, 1, 0);   // full H for _computeStatistics
+      launch_corr_linearize<false, true>(ctx, omSym, nb, m, st, pr, ap, subLastRefTag, 1, 0);   // full H for _computeStatistics
       hipLaunchKernelGGL(k_reduce_pairs, dim3(m), dim3(256), 0, st, pr, nb, ctx->stats_dev + base);
     }
     if (scores && p->outer_iterations > 0) {
@@ -1623,8 +1648,8 @@ int pwn_hip_align_with_priors_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params*
       hs.invT = invT;
       HIPCHK(ctx, hipMemcpyAsync(ctx->state_ws, &hs, sizeof(PairState), hipMemcpyHostToDevice, st), PWN_HIP_ERR_COPY);
       if (k == 0) launch_project(ref->d.capacity, 1, st, ctx->pairs_dev, ap, 0, tag);
-      if (k == 0) launch_corr_linearize<true, true>(ctx, nb, 1, st, ctx->pairs_dev, ap, tag, 0, 0);
-      else launch_corr_linearize<false, true>(ctx, nb, 1, st, ctx->pairs_dev, ap, tag, 0, 0);
+      if (k == 0) launch_corr_linearize<true, true>(ctx, cur->d.omSym, nb, 1, st, ctx->pairs_dev, ap, tag, 0, 0);
+      else launch_corr_linearize<false, true>(ctx, cur->d.omSym, nb, 1, st, ctx->pairs_dev, ap, tag, 0, 0);
       hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, st, ctx->pairs_dev, nb, ctx->stats_dev);
       HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
       HIPCHK(ctx, hipMemcpyAsync(ctx->stats_host, ctx->stats_dev, sizeof(SolveOut), hipMemcpyDeviceToHost, st), PWN_HIP_ERR_COPY);
@@ -1653,7 +1678,7 @@ int pwn_hip_align_with_priors_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params*
       hs.invTcorrPrev = hs.invTcorr;
       hs.invT = iso_inverse(T); set_last_row(hs.invT);                                // :165-167
       HIPCHK(ctx, hipMemcpyAsync(ctx->state_ws, &hs, sizeof(PairState), hipMemcpyHostToDevice, st), PWN_HIP_ERR_COPY);
-      launch_corr_linearize<false, true>(ctx, nb, 1, st, ctx->pairs_dev, ap, lastRefTag, 1, 0);
+      launch_corr_linearize<false, true>(ctx, cur->d.omSym, nb, 1, st, ctx->pairs_dev, ap, lastRefTag, 1, 0);
       hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, st, ctx->pairs_dev, nb, ctx->stats_dev);
       HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
       HIPCHK(ctx, hipMemcpyAsync(ctx->stats_host, ctx->stats_dev, sizeof(SolveOut), hipMemcpyDeviceToHost, st), PWN_HIP_ERR_COPY);

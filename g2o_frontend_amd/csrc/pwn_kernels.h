@@ -74,12 +74,22 @@ struct CloudDev {
   int     capacity;
   float   omN[2][9]; // class matrices (row-major 3x3): [0] flat, [1] non-flat
   float   clsThr;    // NormalInformationMatrixCalculator::_curvatureThreshold the cloud was converted with (informationmatrixcalculator.cpp:47-52)
+  int     omSym;     // storage of Om: 0 = exact9 (three planes of 12-byte rows, all nine entries as computed), 1 = sym6 (two planes:
+                     // (xx xy xz) and (yy yz zz), the upper triangle as computed; readers mirror it).  OmN is always nine entries.
 };
 // NormalInformationMatrixCalculator::compute (informationmatrixcalculator.cpp:38-58): zero normal -> zero matrix, else flat / non-flat by
 // the curvature.  The converter decides on the normal before the sensor offset is applied; a rotation does not turn a non-zero normal
 // into the zero vector, and a candidate with a zero normal is rejected before its class is looked at (correspondencefinder.cpp:69).
 // information matrices (Om, OmN): entry k = 3 r + c of point i
 __host__ __device__ __forceinline__ size_t om_at(size_t cap, size_t i, int k) { return ((size_t)(k / 3) * cap + i) * 3 + (size_t)(k % 3); }
+// sym6 storage of the POINT information matrix (PWN_HIP_OMEGA_SYM6): U diag U^t is symmetric up to the rounding of its nine separately
+// evaluated entries (informationmatrixcalculator.cpp:26-30), and SURVEY.md 8(d) counts it as 24 bytes.  Entry k = 3 r + c lives in slot
+// sym_slot(k) of the six stored values (row-major upper triangle), i.e. at om_at(cap, i, sym_slot(k)): slots 0-2 are plane 0, 3-5 plane 1.
+// Writers store the upper triangle only (om_is_lower entries are dropped), readers get the mirrored value.
+__host__ __device__ constexpr int sym_slot(int k) { return k == 0 ? 0 : (k == 1 || k == 3) ? 1 : (k == 2 || k == 6) ? 2 : k == 4 ? 3 : (k == 5 || k == 7) ? 4 : 5; }
+__host__ __device__ constexpr bool om_is_lower(int k) { return k == 3 || k == 6 || k == 7; }
+__host__ __device__ __forceinline__ size_t omp_at(size_t cap, size_t i, int k, int sym) { return om_at(cap, i, sym ? sym_slot(k) : k); }
+__host__ __device__ __forceinline__ int om_planes(int sym) { return sym ? 2 : 3; }
 __host__ __device__ __forceinline__ int normal_class(float nx, float ny, float nz, float curvature, float thr) {
   return (nx != 0.f || ny != 0.f || nz != 0.f) ? ((curvature < thr) ? 1 : 2) : 0;
 }
@@ -111,6 +121,7 @@ struct ConvertParams {
   int keepStats;
   int spinLimit;             // polls of a strip hand-over word before a waiting lane gives up and raises the fault flag (kSpinLimit)
   int dbgWithhold;           // test hook (pwn_hip_debug_withhold_carry): index of one hand-over word that is NOT written, -1 = none
+  int omSym;                 // storage of the clouds' point information matrices (CloudDev::omSym): 1 = k_stats stores the upper triangle as two 12-byte rows
   int lean;                  // 1 = the front end (k_unproject_integral*) stores neither the points nor the interval image and k_stats recomputes
                              // both from the depth (the same expressions, the same bits): 20 bytes per pixel less written and 18 less read back
 };
@@ -1169,6 +1180,12 @@ __device__ __forceinline__ void stats_pixel(const FrameDesc& f, const ConvertPar
     stream_store3(gP + 3u * (unsigned)idx, pv);
     stream_store((gptr<v4f>)(gN + 4u * (unsigned)idx), nv);
   }
+  if (cp.omSym) {                        // sym6: (xx xy xz) (yy yz zz), the upper triangle as computed -- 24 bytes per point instead of 36
+    v3f_raw r0, r1; r0.x = om[0]; r0.y = om[1]; r0.z = om[2]; r1.x = om[4]; r1.y = om[5]; r1.z = om[8];
+    stream_store3(gOm + 3u * (unsigned)idx, r0);
+    stream_store3(gOm + 3u * (size_t)cap + 3u * (unsigned)idx, r1);
+    return;
+  }
 #pragma unroll
   for (int r3 = 0; r3 < 3; ++r3) {      // three 12-byte rows (nine dword stores per point cost k_stats 9 % more time)
     v3f_raw rw; rw.x = om[3 * r3]; rw.y = om[3 * r3 + 1]; rw.z = om[3 * r3 + 2];
@@ -1334,10 +1351,11 @@ __global__ void __launch_bounds__(256) k_cloud_transform(CloudDev cl, Mat4 m) {
     float* base = pass == 0 ? cl.Om : cl.OmN;
     if (!base) continue;
     float om[9], t1[9];
-    for (int k = 0; k < 9; ++k) om[k] = base[om_at(cl.capacity, i, k)];
+    const int sym = pass == 0 ? cl.omSym : 0;
+    for (int k = 0; k < 9; ++k) om[k] = base[omp_at(cl.capacity, i, k, sym)];
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) t1[3 * a + b] = dot3seq(m(a,0), om[0 + b], m(a,1), om[3 + b], m(a,2), om[6 + b]);
     for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) om[3 * a + b] = dot3seq(t1[3 * a], m(b,0), t1[3 * a + 1], m(b,1), t1[3 * a + 2], m(b,2));
-    for (int k = 0; k < 9; ++k) base[om_at(cl.capacity, i, k)] = om[k];
+    for (int k = 0; k < 9; ++k) if (!(sym && om_is_lower(k))) base[omp_at(cl.capacity, i, k, sym)] = om[k];
   }
   cloud_put(cl, i, P, Nm);
 }
@@ -1589,7 +1607,7 @@ __device__ __forceinline__ bool linearize_term(const float3 rp, const float3 rn,
 __device__ __forceinline__ void load_omegas(const CloudDev& cur, int ci, int cls, float* oP, float* oN) {
   const size_t cap = (size_t)cur.capacity;
 #pragma unroll
-  for (int k = 0; k < 9; ++k) oP[k] = cur.Om[om_at(cap, ci, k)];
+  for (int k = 0; k < 9; ++k) oP[k] = cur.Om[omp_at(cap, ci, k, cur.omSym)];
   if (cur.OmN) {
 #pragma unroll
     for (int k = 0; k < 9; ++k) oN[k] = cur.OmN[om_at(cap, ci, k)];
@@ -1721,11 +1739,11 @@ __device__ __forceinline__ void candidate_load(const PairPtrs& q, int ri, int ci
     c.rP.w = c.rN.w; c.cP.w = c.cN.w;
 #if PWN_OMEGA_PREFETCH
 #pragma unroll
-    for (int k = 0; k < 9; ++k) c.oP[k] = q.curOm[om_at(q.cap, (unsigned)ci, k)];
+    for (int k = 0; k < 9; ++k) c.oP[k] = q.curOm[om_at(q.cap, (unsigned)ci, k)];      // experiment switch: exact9 clouds only
 #endif
   }
 }
-template <bool SAME_T, typename ACC>
+template <bool SAME_T, bool SYM, typename ACC>
 __device__ __forceinline__ void candidate_consume(const PairDesc& pd, const PairPtrs& q, const AlignParams& ap, const Mat4& Tc, const Mat4& Tl,
                                                   const Candidate& c, const ACC acc, float* cnt /* K, C, inliers */, const float* omNtab /* LDS [3][9] */) {
   if (!c.valid) return;
@@ -1759,10 +1777,16 @@ __device__ __forceinline__ void candidate_consume(const PairDesc& pd, const Pair
 #pragma unroll
     for (int k = 0; k < 9; ++k) oP[k] = oN[k] * 10.f;
 #else
+    if (SYM) {                            // sym6 storage: two 12-byte loads, the lower triangle mirrored in registers (no extra VALU)
+      const v3f_raw r0 = *(gptr<const v3f>)(q.curOm + 3u * ci);
+      const v3f_raw r1 = *(gptr<const v3f>)(q.curOm + 3u * cap + 3u * ci);
+      oP[0] = r0.x; oP[1] = r0.y; oP[2] = r0.z; oP[3] = r0.y; oP[4] = r1.x; oP[5] = r1.y; oP[6] = r0.z; oP[7] = r1.y; oP[8] = r1.z;
+    } else {
 #pragma unroll
-    for (int r3 = 0; r3 < 3; ++r3) {      // three 12-byte loads
-      const v3f_raw rw = *(gptr<const v3f>)(q.curOm + (size_t)r3 * 3u * cap + 3u * ci);
-      oP[3 * r3] = rw.x; oP[3 * r3 + 1] = rw.y; oP[3 * r3 + 2] = rw.z;
+      for (int r3 = 0; r3 < 3; ++r3) {      // three 12-byte loads
+        const v3f_raw rw = *(gptr<const v3f>)(q.curOm + (size_t)r3 * 3u * cap + 3u * ci);
+        oP[3 * r3] = rw.x; oP[3 * r3 + 1] = rw.y; oP[3 * r3 + 2] = rw.z;
+      }
     }
 #endif
   }
@@ -1772,7 +1796,7 @@ __device__ __forceinline__ void candidate_consume(const PairDesc& pd, const Pair
 }
 // usePrevTc: the acceptance tests run with the previous outer iteration's transform (Aligner::_computeStatistics re-linearizes
 // the finder's existing correspondences at the final transform, aligner.cpp:165-170).
-template <bool SAME_T, bool FULL_H, int PPT = kPixPerThread>
+template <bool SAME_T, bool FULL_H, bool SYM = false, int PPT = kPixPerThread>
 #ifdef PWN_CL_WAVES_EU
 #define PWN_CL_EU_ATTR __attribute__((amdgpu_waves_per_eu(PWN_CL_WAVES_EU, PWN_CL_WAVES_EU)))
 #else
@@ -1825,7 +1849,7 @@ __global__ void PWN_CL_EU_ATTR __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_co
     const Candidate cur = nxt;
     candidate_load(q, ri2, ci2, nref, ncur, nxt);        // gathers of pixel j+1: in flight during the arithmetic below
     load_indices(j + 2, ri2, ci2);                        // indices of pixel j+2
-    candidate_consume<SAME_T>(pd, q, ap, Tc, Tl, cur, sums, cnt, omNtab);
+    candidate_consume<SAME_T, SYM>(pd, q, ap, Tc, Tl, cur, sums, cnt, omNtab);
   }
 #if PWN_LDS_ACC
   float acc[kAccN];
@@ -1846,7 +1870,7 @@ __global__ void PWN_CL_EU_ATTR __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_co
 // needs no barriers but makes every wave walk all eight turns and quarters the gathers' coalescing: measured 19 vs 16 us per launch.)
 // grid = (ceil(N / 2048), pairs), block = 1024.
 constexpr int kLatBlock = 4 * kAlignBlock;
-template <bool SAME_T, bool FULL_H>
+template <bool SAME_T, bool FULL_H, bool SYM = false>
 __global__ void __launch_bounds__(kLatBlock) k_corr_linearize_lat(const PairDesc* __restrict__ pairs, AlignParams ap, unsigned tag, int usePrevTc, int ownRefIndex) {
   static_assert(kPixPerThread == 8, "two rounds of four turns");
   const PairDesc& pd = pairs[blockIdx.y];
@@ -1886,7 +1910,7 @@ __global__ void __launch_bounds__(kLatBlock) k_corr_linearize_lat(const PairDesc
 #pragma unroll
     for (int k = 0; k < kAccN; ++k) t[r][k] = 0.f;
     c3[r][0] = c3[r][1] = c3[r][2] = 0.f;
-    candidate_consume<SAME_T>(pd, pp, ap, Tc, Tl, cand[r], RegAcc{ t[r] }, c3[r], omNtab);
+    candidate_consume<SAME_T, SYM>(pd, pp, ap, Tc, Tl, cand[r], RegAcc{ t[r] }, c3[r], omNtab);
   }
 #pragma unroll
   for (int r = 0; r < 2; ++r) {

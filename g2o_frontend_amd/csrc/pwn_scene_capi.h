@@ -52,10 +52,10 @@ int ensure_scene(pwn_hip_ctx* ctx, pwn_hip_cloud* c, bool with_gauss) {
 int ensure_back(pwn_hip_ctx* ctx, pwn_hip_cloud* c) {
   const size_t cap = (size_t)c->d.capacity;
   c->back.capacity = c->d.capacity; c->back.count = c->d.count;
-  std::memcpy(c->back.omN, c->d.omN, sizeof(c->d.omN)); c->back.clsThr = c->d.clsThr;
+  std::memcpy(c->back.omN, c->d.omN, sizeof(c->d.omN)); c->back.clsThr = c->d.clsThr; c->back.omSym = c->d.omSym;
   if (int rc = scene_alloc(ctx, (void**)&c->back.P3, cap * 3 * sizeof(float))) return rc;
   if (int rc = scene_alloc(ctx, (void**)&c->back.Nc, cap * sizeof(float4))) return rc;
-  if (int rc = scene_alloc(ctx, (void**)&c->back.Om, cap * 9 * sizeof(float))) return rc;
+  if (int rc = scene_alloc(ctx, (void**)&c->back.Om, om_floats(c->d) * sizeof(float))) return rc;
   if (c->d.OmN) { if (int rc = scene_alloc(ctx, (void**)&c->back.OmN, cap * 9 * sizeof(float))) return rc; }
   if (c->d.St) { if (int rc = scene_alloc(ctx, (void**)&c->back.St, cap * 16 * sizeof(float))) return rc; }
   if (c->sb.G) {
@@ -393,7 +393,7 @@ int pwn_hip_cloud_load(pwn_hip_ctx* ctx, pwn_hip_cloud* c, const char* filename,
   if (n > 0) {
     if (int rc = cloud_store_records(ctx, c->d, n, P, Nm)) return rc;
     HIPCHK(ctx, hipMemcpy(c->d.St, St.data(), St.size() * 4, hipMemcpyHostToDevice), PWN_HIP_ERR_COPY);
-    HIPCHK(ctx, hipMemset(c->d.Om, 0, (size_t)c->d.capacity * 9 * sizeof(float)), PWN_HIP_ERR_COPY);
+    HIPCHK(ctx, hipMemset(c->d.Om, 0, om_floats(c->d) * sizeof(float)), PWN_HIP_ERR_COPY);
   }
   HIPCHK(ctx, hipMemset(c->d.OmN, 0, (size_t)c->d.capacity * 9 * sizeof(float)), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipMemcpy(c->d.count, &n, sizeof(int), hipMemcpyHostToDevice), PWN_HIP_ERR_COPY);

@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(256) k_cloud_append(CloudDev dst, SceneBuffers
   float omP[9], omN[9];
   const int cls = __float_as_int(Nm.w) & kClsMask;
 #pragma unroll
-  for (int q = 0; q < 9; ++q) omP[q] = src.Om[om_at(src.capacity, i, q)];
+  for (int q = 0; q < 9; ++q) omP[q] = src.Om[omp_at(src.capacity, i, q, src.omSym)];
   if (src.OmN) {
 #pragma unroll
     for (int q = 0; q < 9; ++q) omN[q] = src.OmN[om_at(src.capacity, i, q)];
@@ -158,7 +158,10 @@ __global__ void __launch_bounds__(256) k_cloud_append(CloudDev dst, SceneBuffers
   }
   cloud_put(dst, o, P, Nm);
 #pragma unroll
-  for (int q = 0; q < 9; ++q) { dst.Om[om_at(dst.capacity, o, q)] = omP[q]; dst.OmN[om_at(dst.capacity, o, q)] = omN[q]; }
+  for (int q = 0; q < 9; ++q) {
+    if (!(dst.omSym && om_is_lower(q))) dst.Om[omp_at(dst.capacity, o, q, dst.omSym)] = omP[q];
+    dst.OmN[om_at(dst.capacity, o, q)] = omN[q];
+  }
   if (dst.St) {
     float st[16];
     if (src.St) {
@@ -292,7 +295,7 @@ __global__ void __launch_bounds__(256) k_merge_compact(CloudDev src, SceneBuffer
   { const float4 p = load_xyz(src.P3, i); store_xyz(dst.P3, o, p.x, p.y, p.z); dst.Nc[o] = src.Nc[i]; }
 #pragma unroll
   for (int q = 0; q < 9; ++q) {
-    dst.Om[om_at(dst.capacity, o, q)] = src.Om[om_at(src.capacity, i, q)];
+    if (!(dst.omSym && om_is_lower(q))) dst.Om[omp_at(dst.capacity, o, q, dst.omSym)] = src.Om[omp_at(src.capacity, i, q, src.omSym)];
     if (src.OmN && dst.OmN) dst.OmN[om_at(dst.capacity, o, q)] = src.OmN[om_at(src.capacity, i, q)];
   }
   if (src.St && dst.St) {
@@ -445,7 +448,7 @@ __global__ void __launch_bounds__(256) k_voxel_gather(CloudDev src, SceneBuffers
   { const float4 p = load_xyz(src.P3, i); store_xyz(dst.P3, o, p.x, p.y, p.z); dst.Nc[o] = src.Nc[i]; }
 #pragma unroll
   for (int q = 0; q < 9; ++q) {
-    dst.Om[om_at(dst.capacity, o, q)] = src.Om[om_at(src.capacity, i, q)];
+    if (!(dst.omSym && om_is_lower(q))) dst.Om[omp_at(dst.capacity, o, q, dst.omSym)] = src.Om[omp_at(src.capacity, i, q, src.omSym)];
     if (src.OmN && dst.OmN) dst.OmN[om_at(dst.capacity, o, q)] = src.OmN[om_at(src.capacity, i, q)];
   }
   if (src.St && dst.St) {

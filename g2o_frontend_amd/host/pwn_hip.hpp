@@ -97,6 +97,8 @@ class Context {
   // batch calls: frames / pairs per kernel launch and the number of HIP streams the sub-batches are dealt over (include/pwn_hip.h)
   void setSubbatch(int frames, int pairs) { check(pwn_hip_ctx_set_subbatch(_ctx, frames, pairs)); }
   void setConcurrency(int streams) { check(pwn_hip_ctx_set_concurrency(_ctx, streams)); }
+  // PWN_HIP_OMEGA_EXACT9 (default) / PWN_HIP_OMEGA_SYM6: storage of the point information matrices of clouds created from now on
+  void setOmegaStorage(int mode) { check(pwn_hip_ctx_set_omega_storage(_ctx, mode)); }
   void synchronize() { check(pwn_hip_ctx_synchronize(_ctx)); }
  private:
   pwn_hip_ctx* _ctx = nullptr;

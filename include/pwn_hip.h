@@ -148,6 +148,20 @@ int pwn_hip_ctx_set_subbatch(pwn_hip_ctx* ctx, int frames, int pairs);
  * other's large ones.  Measured on MI355X: 2 streams +12 % over 1, 3 and 4 no better than 2.  streams = 1: strictly serial launches (use
  * it when profiling per-kernel durations).  Results are identical. */
 int pwn_hip_ctx_set_concurrency(pwn_hip_ctx* ctx, int streams);
+/* Storage of the point information matrices (InformationMatrix, informationmatrix.h:13; PointInformationMatrixCalculator::compute,
+ * informationmatrixcalculator.cpp:9-36) of the clouds created on the context FROM NOW ON (existing clouds keep theirs;
+ * pwn_hip_cloud_omega_storage tells).  The clouds of one convert batch and the current clouds of one align batch must share one.
+ *   PWN_HIP_OMEGA_EXACT9 (default): all nine entries of U diag U^t as the reference evaluates them, 36 bytes per point; every
+ *     converter output is bit-identical to the CPU path.
+ *   PWN_HIP_OMEGA_SYM6: the upper triangle as the reference evaluates it, 24 bytes per point (the size SURVEY.md 8(d) counts);
+ *     readers -- the Linearizer (linearizer.cpp:66-67,84-88), cloud_download, the scene stage -- mirror it.  The reference's nine
+ *     entries are symmetric only up to the rounding of each entry's own products, so the lower triangle differs from it by
+ *     <= 1 ulp of the entry's largest term: Omega_p within 1e-6 |Omega_p|, chi2 / H / b within 1e-5, everything else unchanged.
+ *     12 of the 30 bytes the fused correspondence + linearize pass gathers per correspondence, and 12 of k_stats' 64 stored bytes. */
+#define PWN_HIP_OMEGA_EXACT9 0
+#define PWN_HIP_OMEGA_SYM6 1
+int pwn_hip_ctx_set_omega_storage(pwn_hip_ctx* ctx, int mode);
+int pwn_hip_cloud_omega_storage(pwn_hip_ctx* ctx, const pwn_hip_cloud* cloud, int* mode);
 /* ctx may be NULL (errors of ctx_create). Never returns NULL. cf. AlignerStatus::toString (cudaaligner.h:54) */
 const char* pwn_hip_last_error_string(const pwn_hip_ctx* ctx);
 /* number of HIP devices visible; does not initialise a device */

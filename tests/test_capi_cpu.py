@@ -158,6 +158,8 @@ def test_null_arguments_are_status_codes_not_crashes():
         "pwn_hip_cloud_num_gaussians": (None, None, C.byref(n)),
         "pwn_hip_cloud_transform_in_place": (None, None, T),
         "pwn_hip_ctx_set_concurrency": (None, 2),
+        "pwn_hip_ctx_set_omega_storage": (None, 1),
+        "pwn_hip_cloud_omega_storage": (None, None, C.byref(n)),
         "pwn_hip_ctx_set_subbatch": (None, 64, 64),
         "pwn_hip_align": (None, None, None, None, None),
         "pwn_hip_convert": (None, None, None, 120, 160, None, None, None, 0),

@@ -35,13 +35,16 @@ def _bits(a):
     return a.view(np.uint32) if a.dtype.itemsize == 4 else a
 
 
-def _run_shard(name, seeds, singles, oracle_on, oracle):
+def _run_shard(name, seeds, singles, oracle_on, oracle, omega_storage="exact9"):
     from g2o_frontend_amd import api
     from test_gpu_parity import gpu_objects, oracle_params, _check_teacher_forced, _compare_clouds
+    if omega_storage == "sym6":
+        from test_omega_sym6 import compare_clouds_sym6
+        _compare_clouds = lambda o, g, _name: compare_clouds_sym6(o, g)      # noqa: E731
     rows, cols, K, conv, alig = case_params(name)
     P, N = len(seeds), rows * cols
     pairs = _render(name, seeds)
-    ctx = api.Context(0, rows, cols, 128)                     # 2 streams x 64 slots, as bench.py
+    ctx = api.Context(0, rows, cols, 128, omega_storage=omega_storage)                     # 2 streams x 64 slots, as bench.py
     ctx.set_subbatch(64, 64); ctx.set_concurrency(2)
     _, converter, aligner = gpu_objects(ctx, name)
     frames = [ctx.upload(p[0]) for p in pairs] + [ctx.upload(p[1]) for p in pairs]      # resident uint16 frames, as in the timed region
@@ -82,7 +85,7 @@ def _run_shard(name, seeds, singles, oracle_on, oracle):
         it0 = o["iterations"][0]
         assert (int(res[i]["K"][0]), int(res[i]["C"][0]), int(res[i]["iter_inliers"][0])) == (it0["K"], it0["C"], it0["inliers"]), i
         assert np.abs(res[i]["T"] - o["T"]).max() <= 1e-5, (i, np.abs(res[i]["T"] - o["T"]).max())
-    print(f"{name} shard of {P} pairs: worst |t - t_true| {worst_t:.1e} m; {len(singles)} singles bitwise equal; "
+    print(f"{name} shard of {P} pairs ({omega_storage}): worst |t - t_true| {worst_t:.1e} m; {len(singles)} singles bitwise equal; "
           f"{len(oracle_on)} pairs vs oracle: clouds bit-exact, worst teacher-forced chi2 rel diff {worst_chi2:.1e}")
     for f in frames:
         f.free()

@@ -1,0 +1,218 @@
+"""The sym6 storage of the point information matrices (pwn_hip_ctx_set_omega_storage, include/pwn_hip.h): 24 bytes per point -- the upper
+triangle of U diag U^t exactly as the reference evaluates it (informationmatrixcalculator.cpp:26-30) -- instead of the nine separately
+rounded entries.  What must hold, against the CPU oracle:
+  * everything the converter makes except the LOWER triangle of Omega_p carries the oracle's bits (points, normals, curvature, Omega_n,
+    index image, the upper triangle of Omega_p); the mirrored lower triangle is within 1e-6 * |Omega_p| of the oracle's own entry;
+  * the aligner on such clouds: K_i, C_i, inliers_i exact and chi2_i within 1e-5 from the oracle's iterate (teacher-forced), the
+    same bar as exact9 -- also on disturbed frames (noise, holes, exactly planar / constant patches whose eigenvalue 0 makes
+    1 / lambda infinite) and on the 128-pair VGA shard in the product configuration;
+  * exact9 stays the default and is untouched: a context switched back converts bit-exactly again.
+"""
+import numpy as np
+import pytest
+
+from conftest import case_params, make_depth_pair
+
+pytestmark = pytest.mark.gpu
+
+UPPER = [r + 4 * q for r in range(3) for q in range(3) if r <= q]      # column-major 4x4: entry (r, q) at r + 4 q
+LOWER = [(r + 4 * q, q + 4 * r) for r in range(3) for q in range(3) if r > q]
+
+
+def compare_clouds_sym6(o, g):
+    """o: oracle arrays, g: arrays downloaded from a sym6 cloud"""
+    assert len(o["points"]) == len(g["points"])
+    for k in ("points", "normals", "curvature", "omega_n"):
+        a, b = o[k].reshape(len(o[k]), -1), g[k].reshape(len(g[k]), -1)
+        same = (a.view(np.uint32) == b.view(np.uint32)) | ((a == 0) & (b == 0))
+        assert same.all(), f"{k}: {int((~same).any(1).sum())} points differ"
+    a, b = o["omega_p"], g["omega_p"]
+    au, bu = np.ascontiguousarray(a[:, UPPER]), np.ascontiguousarray(b[:, UPPER])
+    same = (au.view(np.uint32) == bu.view(np.uint32)) | ((au == 0) & (bu == 0))
+    assert same.all(), f"omega_p upper triangle: {int((~same).any(1).sum())} points differ"
+    for lo, up in LOWER:
+        assert np.array_equal(b[:, lo].view(np.uint32), b[:, up].view(np.uint32)), "sym6 download must mirror the stored upper triangle"
+    # the oracle's own lower triangle: another rounding of the same products
+    fin = np.isfinite(a[:, :11]).all(1)
+    scale = np.abs(a[fin][:, :11]).max(1)
+    worst = 0.0
+    for lo, _ in LOWER:
+        d = np.abs(a[fin][:, lo] - b[fin][:, lo])
+        worst = max(worst, float((d / np.maximum(scale, 1e-30)).max()) if len(d) else 0.0)
+        assert (d <= 1e-6 * scale).all(), f"lower triangle differs by {float((d / np.maximum(scale, 1e-30)).max()):.2e} of |Omega_p|"
+    # non-finite matrices (1 / 0 eigenvalue): the same entries are non-finite on both sides
+    assert np.array_equal(np.isnan(a[:, :11]), np.isnan(b[:, :11])) and np.array_equal(np.isinf(a[:, :11]), np.isinf(b[:, :11]))
+    assert np.array_equal(a[:, 11:], b[:, 11:])                       # last column / corner of the 4x4
+    return worst
+
+
+@pytest.fixture(scope="module")
+def rig():
+    from g2o_frontend_amd import api
+    made = {}
+
+    def get(name):
+        if name not in made:
+            from test_gpu_parity import gpu_objects
+            rows, cols, _, _, _ = case_params(name)
+            ctx = api.Context(0, rows, cols, 4, omega_storage="sym6")
+            _, converter, aligner = gpu_objects(ctx, name)
+            made[name] = (ctx, converter, aligner)
+        return made[name]
+    yield get
+    for ctx, _, _ in made.values():
+        ctx.close()
+
+
+@pytest.mark.parametrize("name,seed", [("small", 1), ("vga", 0)])
+def test_sym6_converter_against_oracle(rig, oracle, name, seed):
+    from g2o_frontend_amd import api
+    from test_gpu_parity import oracle_params
+    ctx, converter, _ = rig(name)
+    rows, cols, _, _, _ = case_params(name)
+    depth, _, _, mm, _ = make_depth_pair(name, seed)
+    cp, _ = oracle_params(oracle, name)
+    oc, oidx, _ = oracle.convert(cp, depth)
+    cloud = api.Cloud(ctx, rows * cols)
+    assert cloud.omega_storage() == "sym6"
+    converter.compute(cloud, depth)                           # latency path
+    assert np.array_equal(oidx, converter.indexImage())
+    worst = compare_clouds_sym6(oc.arrays(), cloud.arrays())
+    many = [api.Cloud(ctx, rows * cols) for _ in range(16)]   # throughput path (single-pass front end, raw uint16 frames)
+    ctx.set_subbatch(4, 4)
+    converter.computeBatch(many, [mm] * 16, raw_scale=0.001)
+    ctx.set_subbatch(64, 64)
+    for c in (many[0], many[9], many[15]):
+        compare_clouds_sym6(oc.arrays(), c.arrays())
+    print(f"{name}: sym6 lower triangle within {worst:.1e} of |Omega_p|")
+
+
+def test_sym6_with_sensor_offset(rig, oracle):
+    """Cloud::transformInPlace (T Omega T^t, cloud.cpp:173-186) fused into the converter, on the stored triangle"""
+    from g2o_frontend_amd import api, synth
+    from test_gpu_parity import oracle_params
+    name = "small"
+    ctx, converter, _ = rig(name)
+    rows, cols, _, _, _ = case_params(name)
+    depth, _, _, _, _ = make_depth_pair(name, 3)
+    off = synth.v2t(np.array([0.1, -0.05, 0.2, 0.03, -0.02, 0.05])).astype(np.float32)
+    cp, _ = oracle_params(oracle, name, sensor_offset=off)
+    oc, _, _ = oracle.convert(cp, depth)
+    cloud = api.Cloud(ctx, rows * cols)
+    converter.compute(cloud, depth, sensorOffset=off)
+    compare_clouds_sym6(oc.arrays(), cloud.arrays())
+    # the stand-alone transform of an existing sym6 cloud reads the mirrored matrix: within rounding of the oracle's
+    plain = api.Cloud(ctx, rows * cols)
+    converter.compute(plain, depth)
+    plain.transformInPlace(off)
+    o, g = oc.arrays(), plain.arrays()
+    assert np.array_equal(o["points"].view(np.uint32), g["points"].view(np.uint32))
+    fin = np.isfinite(o["omega_p"]).all(1)
+    s = np.abs(o["omega_p"][fin]).max(1, keepdims=True)
+    assert (np.abs(o["omega_p"][fin] - g["omega_p"][fin]) <= 2e-6 * s).all()
+
+
+def test_sym6_upload_download_round_trip(rig, oracle):
+    from g2o_frontend_amd import api
+    from test_gpu_parity import oracle_params
+    name = "small"
+    ctx, _, _ = rig(name)
+    depth, _, _, _, _ = make_depth_pair(name, 2)
+    cp, _ = oracle_params(oracle, name)
+    oc, _, _ = oracle.convert(cp, depth)
+    a = oc.arrays()
+    c = api.Cloud(ctx, len(oc))
+    c.upload(a["points"], a["normals"], a["curvature"], a["omega_p"], a["omega_n"])
+    compare_clouds_sym6(a, c.arrays())
+
+
+@pytest.mark.parametrize("name,seed", [("small", 1), ("vga", 0)])
+def test_sym6_alignment_teacher_forced(rig, oracle, name, seed):
+    from g2o_frontend_amd import api
+    from test_gpu_parity import oracle_params, _check_teacher_forced, _check_alignment
+    ctx, converter, aligner = rig(name)
+    rows, cols, _, _, _ = case_params(name)
+    ref, cur, _, _, _ = make_depth_pair(name, seed)
+    cp, ap = oracle_params(oracle, name, accumulate_fp64=1)
+    oref, _, _ = oracle.convert(cp, ref); ocur, _, _ = oracle.convert(cp, cur)
+    o = oracle.align(ap, oref, ocur)
+    gref, gcur = api.Cloud(ctx, rows * cols), api.Cloud(ctx, rows * cols)
+    converter.compute(gref, ref); converter.compute(gcur, cur)
+    aligner.setReferenceCloud(gref); aligner.setCurrentCloud(gcur)
+    aligner.setInitialGuess(np.eye(4, dtype=np.float32))
+    g = aligner.align()
+    _check_alignment(o, g)
+    worst = _check_teacher_forced(aligner, o)                 # K_i, C_i, inliers_i exact; chi2_i within 1e-5
+    # the statistics pass (full H) and the list linearizer read the same storage
+    _, _, K, conv, _ = case_params(name)
+    T = np.eye(4, dtype=np.float32)
+    ri, _ = oracle.project(K, T, conv["min_distance"], conv["max_distance"], rows, cols, oref.arrays()["points"])
+    ci, _ = oracle.project(K, T, conv["min_distance"], conv["max_distance"], rows, cols, ocur.arrays()["points"])
+    corr, _ = oracle.correspondences(ap, oref, ocur, ri, ci, T)
+    ol = oracle.linearize(ap, oref, ocur, corr, T)
+    gl = aligner.linearize(corr, T)
+    assert gl["inliers"] == ol["inliers"] and abs(gl["chi2"] - ol["chi2_fp64"]) <= 1e-5 * ol["chi2_fp64"]
+    assert np.abs(gl["H"] - ol["H"]).max() <= 1e-5 * np.abs(ol["H"]).max()
+    print(f"{name}: sym6 worst teacher-forced chi2 rel diff {worst:.1e}")
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_sym6_teacher_forced_on_disturbed_frames(rig, oracle, seed):
+    """noise, holes, exactly planar and exactly constant patches (eigenvalue 0 -> infinite / NaN information matrices)"""
+    from g2o_frontend_amd import api
+    from test_gpu_fuzz import disturbed_pair
+    from test_gpu_parity import oracle_params, _check_teacher_forced
+    name = "small"
+    ctx, converter, aligner = rig(name)
+    rows, cols, _, _, _ = case_params(name)
+    cp, ap = oracle_params(oracle, name, accumulate_fp64=1)
+    ref_mm, cur_mm, _ = disturbed_pair(seed, name)
+    rd, cd = oracle.convert_16u_to_32f(ref_mm), oracle.convert_16u_to_32f(cur_mm)
+    oref, _, _ = oracle.convert(cp, rd); ocur, _, _ = oracle.convert(cp, cd)
+    gref, gcur = api.Cloud(ctx, rows * cols), api.Cloud(ctx, rows * cols)
+    converter.compute(gref, rd); converter.compute(gcur, cd)
+    compare_clouds_sym6(oref.arrays(), gref.arrays()); compare_clouds_sym6(ocur.arrays(), gcur.arrays())
+    o = oracle.align(ap, oref, ocur)
+    aligner.setReferenceCloud(gref); aligner.setCurrentCloud(gcur)
+    _check_teacher_forced(aligner, o)
+
+
+def test_sym6_shard_128_vga_pairs_product_configuration(oracle):
+    """bench.py's shard (128 VGA pairs, two streams, sub-batches of 64) with sym6 clouds: every pair converges to the true pose, the batch
+    is bitwise reproducible and equals single alignments, sampled pairs teacher-forced against the oracle"""
+    import test_gpu_shard_shapes as S
+    seeds = list(range(3000, 3128))
+    S._run_shard("vga", seeds, singles=(0, 63, 64, 127), oracle_on=(5, 64), oracle=oracle, omega_storage="sym6")
+
+
+def test_mixed_storage_is_rejected_and_exact9_is_untouched(oracle):
+    from g2o_frontend_amd import api
+    from g2o_frontend_amd._lib import PwnHipError
+    from test_gpu_parity import gpu_objects, oracle_params, _compare_clouds
+    name = "small"
+    rows, cols, _, _, _ = case_params(name)
+    ctx = api.Context(0, rows, cols, 4)
+    _, converter, aligner = gpu_objects(ctx, name)
+    depth, cur, _, _, _ = make_depth_pair(name, 1)
+    a = api.Cloud(ctx, rows * cols)
+    ctx.set_omega_storage("sym6")
+    b = api.Cloud(ctx, rows * cols)
+    assert (a.omega_storage(), b.omega_storage()) == ("exact9", "sym6")
+    with pytest.raises(PwnHipError):
+        converter.computeBatch([a, b], [depth, cur])
+    converter.compute(a, depth); converter.compute(b, cur)
+    with pytest.raises(PwnHipError):
+        aligner.alignBatch([a, a], [a, b])
+    # a retired sym6 cloud is not handed to an exact9 request of the same capacity
+    del b
+    ctx.set_omega_storage("exact9")
+    c = api.Cloud(ctx, rows * cols)
+    assert c.omega_storage() == "exact9"
+    converter.compute(c, depth)
+    cp, _ = oracle_params(oracle, name)
+    oc, _, _ = oracle.convert(cp, depth)
+    _compare_clouds(oc.arrays(), c.arrays(), name)
+    _compare_clouds(oc.arrays(), a.arrays(), name)
+    with pytest.raises(ValueError):
+        ctx.set_omega_storage("sym5")
+    ctx.close()
