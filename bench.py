@@ -58,6 +58,9 @@ def parse(argv=None):
     ap.add_argument("--no-profile", action="store_true", help="skip the serial profiled pass (roofline fields become 0)")
     ap.add_argument("--omega-storage", choices=("exact9", "sym6"), default=os.environ.get("PWN_OMEGA_STORAGE", "sym6"),
                     help="storage of the clouds' point information matrices in the batch workload (include/pwn_hip.h: pwn_hip_ctx_set_omega_storage)")
+    ap.add_argument("--step-mode", choices=("fused", "split"), default=os.environ.get("PWN_STEP_MODE", "fused"),
+                    help="fused: one submission per step (pwn_hip_convert_align_batch_u16: sub-batch k converts while k-1 aligns); split: convert_batch_u16, then "
+                         "align_batch_records (a host wait between the halves).  Same results bit for bit; the records are packed on the device in both")
     ap.add_argument("--streams", type=int, default=2, help="HIP streams the batch calls use in the timed region (1 = serial)")
     ap.add_argument("--render-workers", type=int, default=0,
                     help="processes that render the synthetic frames (0 = automatic; 1 = in this process: required under rocprofv3, whose preloaded "
@@ -292,24 +295,33 @@ class BatchWorkload:
         self.refs = [api.Cloud(self.ctx, self.N) for _ in range(P)]
         self.curs = [api.Cloud(self.ctx, self.N) for _ in range(P)]
         self.records = torch.empty((P, shard.RECORD_FLOATS), dtype=torch.float32, device="cuda")
-        self.records_host = torch.empty((P, shard.RECORD_FLOATS), dtype=torch.float32).pin_memory()
+        self.ids = np.asarray(self.seeds, np.int32)                                  # global pair ids: word 19 of the records
         self.conv_prep = self.converter.batchHandles(self.refs + self.curs, self.ref_dev + self.cur_dev)
         self.align_prep = ((C.c_void_p * P)(*[c.h for c in self.refs]), (C.c_void_p * P)(*[c.h for c in self.curs]), P)
+        self.step_prep = self.aligner.convertAlignHandles(self.refs, self.curs, self.ref_dev, self.cur_dev)
+        self.fused = getattr(args, "step_mode", "fused") == "fused"
         self.stage_ms = {k: 0.0 for k in STAGES}; self.stage_n = {k: 0 for k in STAGES}
         self.last = {}
 
     def step(self, profile=False):
+        """one pass of the hot path over the rank's pairs; the 256-byte result records are written by a kernel straight into the device tensor the
+        all-gather sends (no trip through the host), the caller's own copy of the results comes back beside them"""
         from g2o_frontend_amd import shard
-        self.converter.computeBatch(self.refs + self.curs, self.ref_dev + self.cur_dev, raw_scale=0.001, prepared=self.conv_prep)
-        if profile:
-            for k in STAGES[:6]:
-                ms, n = self.ctx.stage_ms(k); self.stage_ms[k] += ms; self.stage_n[k] += n
-        res = self.aligner.alignBatch(self.refs, self.curs, raw=True, prepared=self.align_prep)
-        if profile:
-            for k in STAGES[6:]:
-                ms, n = self.ctx.stage_ms(k); self.stage_ms[k] += ms; self.stage_n[k] += n
-        self.records_host.numpy()[:] = shard.pack_results_raw(res, self.seeds)
-        self.records.copy_(self.records_host, non_blocking=False)
+        if self.fused:
+            res = self.aligner.convertAlignBatch(self.converter, None, None, None, None, raw_scale=0.001, records=self.records, pair_ids=self.ids,
+                                                 prepared=self.step_prep)
+            if profile:
+                for k in STAGES:
+                    ms, n = self.ctx.stage_ms(k); self.stage_ms[k] += ms; self.stage_n[k] += n
+        else:
+            self.converter.computeBatch(self.refs + self.curs, self.ref_dev + self.cur_dev, raw_scale=0.001, prepared=self.conv_prep)
+            if profile:
+                for k in STAGES[:6]:
+                    ms, n = self.ctx.stage_ms(k); self.stage_ms[k] += ms; self.stage_n[k] += n
+            res = self.aligner.alignBatchRecords(None, None, self.records, pair_ids=self.ids, prepared=self.align_prep)
+            if profile:
+                for k in STAGES[6:]:
+                    ms, n = self.ctx.stage_ms(k); self.stage_ms[k] += ms; self.stage_n[k] += n
         self.last["gathered"] = shard.gather_records(self.records, self.world, self.Pmax, force=self.use_dist)      # the only collective of the path
         self.last["res"] = res
 
@@ -996,7 +1008,7 @@ def main():
                                    f"(u16 mm frames resident in HBM; per pair: convert 2 frames + Aligner::align, "
                                    f"{alig['outer_iterations']}x{alig['inner_iterations']} GN iterations); BASELINE configs[3] shard",
                        "pairs_per_gpu": P, "total_pairs": total, "rows": rows, "cols": cols, "sub_frames": args.sub_frames, "sub_pairs": args.sub_pairs,
-                       "streams": args.streams, "omega_storage": args.omega_storage,
+                       "streams": args.streams, "omega_storage": args.omega_storage, "step_mode": args.step_mode,
                        "parallelism": f"independent pairs sharded over {n_seen} GPU(s), RCCL all-gather of result records only"},
             "roofline": rep["roofline"],
             "cpu_baseline": cpu,

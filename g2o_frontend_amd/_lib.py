@@ -112,6 +112,8 @@ PROTOTYPES = {
     "pwn_hip_align_with_priors": (_I, [_VP, _VP, _VP, _VP, _I, _VP, _VP]),
     "pwn_hip_align_with_priors_ex": (_I, [_VP, _VP, _VP, _VP, _I, _VP, _VP, _VP]),
     "pwn_hip_align_batch_ex": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _F, _VP, _VP]),
+    "pwn_hip_align_batch_records": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _I, _VP, _VP]),
+    "pwn_hip_convert_align_batch_u16": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _F, _I, _I, _VP, _VP, _VP, _VP, _I, _VP, _VP]),
     "pwn_hip_compute_statistics": (None, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "pwn_hip_match_score": (_I, [_VP, _F, _VP]),
     "pwn_hip_match_batch": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _F, _VP, _VP]),

@@ -763,6 +763,43 @@ class Aligner:
             return np.frombuffer(res, dtype=ALIGN_RESULT_DTYPE, count=n)
         return [self._unpack(r) for r in res]
 
+    def alignBatchRecords(self, references, currents, records, pair_ids=None, first_pair_id=0, initialGuesses=None, want_results=True, prepared=None):
+        """alignBatch whose results also (or only) leave as fixed-size records written on the device (include/pwn_hip.h: PWN_HIP_RECORD_FLOATS):
+        records = a float32 [n, 64] CUDA tensor (e.g. what an all-gather sends) or numpy array; returns the structured result array or None."""
+        p = self.params()
+        refs, curs, n = prepared if prepared is not None else ((C.c_void_p * len(references))(*[c.h for c in references]),
+                                                               (C.c_void_p * len(currents))(*[c.h for c in currents]), len(references))
+        res = (AlignResult * n)() if want_results else None
+        g = None
+        if initialGuesses is not None:
+            g = np.ascontiguousarray(np.stack([_colmajor(self._iso(T), 4) for T in initialGuesses]), np.float32)
+        ids = None if pair_ids is None else np.ascontiguousarray(pair_ids, np.int32)
+        self.ctx.check(self.ctx._L.pwn_hip_align_batch_records(self.ctx.h, C.byref(p), n, refs, curs, _ptr(g), _ptr(ids), int(first_pair_id), res, _ptr(records)))
+        return np.frombuffer(res, dtype=ALIGN_RESULT_DTYPE, count=n) if want_results else None
+
+    def convertAlignBatch(self, converter, references, currents, refFrames, curFrames, raw_scale=0.001, records=None, pair_ids=None, first_pair_id=0,
+                          initialGuesses=None, want_results=True, prepared=None):
+        """One candidate batch from raw uint16 frames as one submission (pwn_hip_convert_align_batch_u16): per pair makeCloud of both frames, then
+        align; sub-batch k converts while sub-batch k-1 aligns.  prepared = (refs, curs, ref frame ptrs, cur frame ptrs, n, (rows, cols))."""
+        cp, p = converter.params(None), self.params()
+        if prepared is None:
+            prepared = self.convertAlignHandles(references, currents, refFrames, curFrames)
+        refs, curs, rf, cf, n, (rows, cols) = prepared
+        res = (AlignResult * n)() if want_results else None
+        g = None
+        if initialGuesses is not None:
+            g = np.ascontiguousarray(np.stack([_colmajor(self._iso(T), 4) for T in initialGuesses]), np.float32)
+        ids = None if pair_ids is None else np.ascontiguousarray(pair_ids, np.int32)
+        self.ctx.check(self.ctx._L.pwn_hip_convert_align_batch_u16(self.ctx.h, C.byref(cp), C.byref(p), n, rf, cf, raw_scale, rows, cols, refs, curs, _ptr(g),
+                                                                   _ptr(ids), int(first_pair_id), res, _ptr(records)))
+        return np.frombuffer(res, dtype=ALIGN_RESULT_DTYPE, count=n) if want_results else None
+
+    @staticmethod
+    def convertAlignHandles(references, currents, refFrames, curFrames):
+        n = len(references)
+        return ((C.c_void_p * n)(*[c.h for c in references]), (C.c_void_p * n)(*[c.h for c in currents]),
+                (C.c_void_p * n)(*[_ptr(d) for d in refFrames]), (C.c_void_p * n)(*[_ptr(d) for d in curFrames]), n, tuple(refFrames[0].shape))
+
     # stage-level entry points (CorrespondenceFinder::compute / Linearizer::update with explicit inputs)
     def computeCorrespondences(self, referenceIndexImage, currentIndexImage, T):
         """correspondencefinder.cpp:20-118 -> (correspondences [C,2], K)"""

@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <functional>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -136,6 +137,8 @@ struct pwn_hip_ctx {
   // conversion of a frame.  Bounded by kCloudPoolBytes.
   std::vector<pwn_hip_cloud*> cloud_pool; size_t cloud_pool_bytes = 0;
   AsyncConvert* async = nullptr;           // pwn_hip_convert_scaled_begin: created on first use
+  float* records_ws = nullptr; int records_cap = 0;      // result records of a batch on their way to host memory (k_pack_records)
+  int* ids_dev = nullptr; int ids_cap = 0;               // the caller's pair ids of those records
 };
 
 namespace {
@@ -506,14 +509,22 @@ int ensure_stats(pwn_hip_ctx* ctx, pwn_hip_cloud* c) {
   return PWN_HIP_OK;
 }
 // direct: the kernels of the call have written counts and fault flag into counts_host themselves (FrameDesc::count_out, launch_convert's fault_out)
+// the two halves of sync_and_counts for callers that wait for the stream themselves: queue the copy back of counts + fault flag; digest them
+int counts_enqueue(pwn_hip_ctx* ctx, int n) {
+  if (n <= 0) return PWN_HIP_OK;
+  hipLaunchKernelGGL(k_gather_counts, dim3((n + 256) / 256), dim3(256), 0, ctx->stream, ctx->frames_dev, n, ctx->counts_dev, ctx->fault_dev);
+  HIPCHK(ctx, hipMemcpyAsync(ctx->counts_host, ctx->counts_dev, sizeof(int) * (n + 1), hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
+  return PWN_HIP_OK;
+}
+int counts_apply(pwn_hip_ctx* ctx, pwn_hip_cloud* const* clouds, int n);
 int sync_and_counts(pwn_hip_ctx* ctx, pwn_hip_cloud* const* clouds, int n, bool direct = false) {
   // frames_dev[0..n) must describe clouds[0..n)
-  if (n > 0 && !direct) {
-    hipLaunchKernelGGL(k_gather_counts, dim3((n + 256) / 256), dim3(256), 0, ctx->stream, ctx->frames_dev, n, ctx->counts_dev, ctx->fault_dev);
-    HIPCHK(ctx, hipMemcpyAsync(ctx->counts_host, ctx->counts_dev, sizeof(int) * (n + 1), hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
-  }
+  if (n > 0 && !direct) { if (int rc = counts_enqueue(ctx, n)) return rc; }
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
   collect_stage_times(ctx);
+  return counts_apply(ctx, clouds, n);
+}
+int counts_apply(pwn_hip_ctx* ctx, pwn_hip_cloud* const* clouds, int n) {
   if (n > 0 && ctx->counts_host[n] != 0) {
     const int code = ctx->counts_host[n];
     (void)hipMemset(ctx->fault_dev, 0, sizeof(int));
@@ -529,23 +540,32 @@ int sync_and_counts(pwn_hip_ctx* ctx, pwn_hip_cloud* const* clouds, int n, bool 
   return PWN_HIP_OK;
 }
 
+// One converter call, cut into the pieces a caller can interleave with other work on the same streams: convert_prepare (descriptors of all
+// frames, uploaded on ctx->stream), convert_enqueue (the kernels of frames [base, base + m) on one stream) and convert_finish (counts and
+// fault flag back, clouds' host-side sizes).  slot[i] = workspace slot of frame i: frames that are in flight at the same time on different
+// streams must not share one; a stream reuses its slots from launch to launch (stream order serialises the reuse).
+struct ConvertJob {
+  ConvertParams cp;
+  int n = 0, rows = 0, cols = 0;
+  size_t N = 0;
+  bool raw = false, host_input = false, direct = false;
+  float depth_scale = 0.f;
+  std::vector<const void*> src;          // the caller's frame pointers (host frames are staged by convert_enqueue)
+  std::vector<int> slot;
+};
 template <typename SRC>
-int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const SRC* const* frames, float depth_scale, int n,
-                       int rows, int cols, pwn_hip_cloud* const* clouds, int keep_stats, bool want_interval = false) {
-  if (!ctx || !p || !frames || !clouds || n < 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
-  if (int rc = check_image(ctx, rows, cols)) return rc;
-  if (int rc = absorb_copies(ctx)) return rc;
+int convert_prepare(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const SRC* const* frames, float depth_scale, int n, int rows, int cols,
+                    pwn_hip_cloud* const* clouds, int keep_stats, bool want_interval, const std::vector<int>& slot, bool direct, ConvertJob& job) {
   const size_t N = (size_t)rows * cols;
-  ctx->stages.clear();
 #ifndef PWN_LEAN
 #define PWN_LEAN 1      // 0: the front end always stores points and intervals (A/B experiments)
 #endif
   ConvertParams cp = make_convert_params(ctx, p, nullptr, rows, cols, keep_stats);
   cp.lean = (PWN_LEAN && !want_interval) ? 1 : 0;      // the interval image leaves the converter only through pwn_hip_convert(..., interval_image)
-  const StreamPlan plan = make_plan(ctx, ctx->sub_frames, n);
-  const int sub = plan.sub;
   if (int rc = ensure_desc(ctx, n)) return rc;
   const bool raw = std::is_same<SRC, uint16_t>::value;
+  job.n = n; job.rows = rows; job.cols = cols; job.N = N; job.raw = raw; job.depth_scale = depth_scale; job.slot = slot; job.direct = direct;
+  job.src.assign(n, nullptr);
   // every frame gets a descriptor; workspace slots are reused round-robin (stream order serialises the reuse)
   for (int i = 0; i < n; ++i) {
     pwn_hip_cloud* c = clouds[i];
@@ -558,10 +578,10 @@ int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, cons
     c->n_gauss = 0;                              // the cloud's Gaussians (if any) belonged to its previous content
     if (c->d.OmN) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH); (void)hipFree(c->d.OmN); c->d.OmN = nullptr; }
     make_omega_n_classes(p, c->d);
-    const int slot = plan.slot0(i / sub) + i % sub;
+    job.src[i] = frames[i];
     const float* depth_dev = nullptr;
     if (!raw) depth_dev = reinterpret_cast<const float*>(frames[i]);         // patched below if it is a host pointer
-    fill_frame(ctx, i, slot, depth_dev, c->d, rows);
+    fill_frame(ctx, i, slot[i], depth_dev, c->d, rows);
     if (c->idx_cap < N) {
       HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
       if (c->idximg) (void)hipFree(c->idximg);
@@ -577,26 +597,60 @@ int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, cons
       ctx->frames_host[i].raw_scale = depth_scale;
     }
   }
-  // host inputs are staged per sub-batch; device inputs are used in place
-  const bool host_input = !is_device_ptr(frames[0]);
-  if (host_input) {
+  // host inputs are staged per launch; device inputs are used in place
+  job.host_input = n > 0 && !is_device_ptr(frames[0]);
+  if (job.host_input) {
     for (int i = 0; i < n; ++i) {
-      const int slot = plan.slot0(i / sub) + i % sub;
-      if (raw) ctx->frames_host[i].raw = ctx->raw_ws + (size_t)slot * ctx->N;
-      else ctx->frames_host[i].depth = ctx->depth_ws + (size_t)slot * ctx->N;
+      if (raw) ctx->frames_host[i].raw = ctx->raw_ws + (size_t)slot[i] * ctx->N;
+      else ctx->frames_host[i].depth = ctx->depth_ws + (size_t)slot[i] * ctx->N;
     }
   }
-  // a call of a few frames (latency path, one sub-batch): counts and fault flag land in page-locked host words straight from the kernels
-  const bool direct = n > 0 && n < PWN_SINGLE_PASS_MIN_FRAMES && n <= sub;
+  // a call of a few frames (latency path, one launch): counts and fault flag land in page-locked host words straight from the kernels
   if (direct) for (int i = 0; i < n; ++i) ctx->frames_host[i].count_out = ctx->counts_host + i;
   HIPCHK(ctx, hipMemcpyAsync(ctx->frames_dev, ctx->frames_host, sizeof(FrameDesc) * n, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
+  job.cp = cp;
+  return PWN_HIP_OK;
+}
+// frames [base, base + m) of the job: their host frames (if any) copied on `cs`, their kernels launched on `st`.  The frames' slots must be
+// consecutive (slot[base + i] = slot[base] + i).
+int convert_stage_frames(pwn_hip_ctx* ctx, const ConvertJob& job, int base, int m, hipStream_t cs) {
+  // frames that follow each other in host memory (a ring buffer, one block for the batch) go in one transfer -- only when the frame
+  // fills its staging slot (N == ctx->N), so that the slots are contiguous too
+  const size_t fbytes = job.N * (job.raw ? sizeof(uint16_t) : sizeof(float));
+  const int s0 = job.slot[base];
+  for (int i = 0; i < m;) {
+    int run = 1;
+    if (job.N == ctx->N)
+      while (i + run < m && (const char*)job.src[base + i + run] == (const char*)job.src[base + i] + (size_t)run * fbytes) ++run;
+    void* dst = job.raw ? (void*)(ctx->raw_ws + (size_t)(s0 + i) * ctx->N) : (void*)(ctx->depth_ws + (size_t)(s0 + i) * ctx->N);
+    HIPCHK(ctx, hipMemcpyAsync(dst, job.src[base + i], fbytes * run, hipMemcpyHostToDevice, cs), PWN_HIP_ERR_COPY);
+    i += run;
+  }
+  return PWN_HIP_OK;
+}
+int convert_finish(pwn_hip_ctx* ctx, const ConvertJob& job, pwn_hip_cloud* const* clouds) { return sync_and_counts(ctx, clouds, job.n, job.direct); }
+
+template <typename SRC>
+int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const SRC* const* frames, float depth_scale, int n,
+                       int rows, int cols, pwn_hip_cloud* const* clouds, int keep_stats, bool want_interval = false) {
+  if (!ctx || !p || !frames || !clouds || n < 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (int rc = check_image(ctx, rows, cols)) return rc;
+  if (int rc = absorb_copies(ctx)) return rc;
+  ctx->stages.clear();
+  const StreamPlan plan = make_plan(ctx, ctx->sub_frames, n);
+  const int sub = plan.sub;
+  std::vector<int> slot((size_t)std::max(n, 0));
+  for (int i = 0; i < n; ++i) slot[i] = plan.slot0(i / sub) + i % sub;
+  const bool direct = n > 0 && n < PWN_SINGLE_PASS_MIN_FRAMES && n <= sub;
+  ConvertJob job;
+  if (int rc = convert_prepare<SRC>(ctx, p, frames, depth_scale, n, rows, cols, clouds, keep_stats, want_interval, slot, direct, job)) return rc;
   if (int rc = plan_fork(ctx, plan)) return rc;
   // Host frames travel on the copy stream, ahead of the kernels: the frames of sub-batch k are copied while sub-batches k-1, k-2 ... are
   // being converted (with the copies on the sub-batch's own stream the two streams copy at the same time and then compute at the same
   // time: 7.5 ms per 256 VGA frames against 5).  copied[k] orders convert k after its copies; converted[k] orders the copies into a
   // staging block after the kernels that read its previous content.
   const int nsub = (n + sub - 1) / sub;
-  const bool ahead = host_input && ctx->copy_stream && plan.dual();
+  const bool ahead = job.host_input && ctx->copy_stream && plan.dual();
   if (ahead) {
     while ((int)ctx->sync_events.size() < 2 * nsub) {
       hipEvent_t e = nullptr;
@@ -608,31 +662,20 @@ int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, cons
   for (int base = 0, k = 0; base < n; base += sub, ++k) {
     const int m = std::min(sub, n - base);
     hipStream_t st = plan.stream(k);
-    const int s0 = plan.slot0(k);
-    if (host_input) {
+    if (job.host_input) {
       hipStream_t cs = ahead ? ctx->copy_stream : st;
       if (ahead && k >= plan.ns) HIPCHK(ctx, hipStreamWaitEvent(cs, ctx->sync_events[2 * (k - plan.ns) + 1], 0), PWN_HIP_ERR_LAUNCH);
-      // frames that follow each other in host memory (a ring buffer, one block for the batch) go in one transfer -- only when the frame
-      // fills its staging slot (N == ctx->N), so that the slots are contiguous too
-      const size_t fbytes = N * (raw ? sizeof(uint16_t) : sizeof(float));
-      for (int i = 0; i < m;) {
-        int run = 1;
-        if (N == ctx->N)
-          while (i + run < m && (const char*)frames[base + i + run] == (const char*)frames[base + i] + (size_t)run * fbytes) ++run;
-        void* dst = raw ? (void*)(ctx->raw_ws + (size_t)(s0 + i) * ctx->N) : (void*)(ctx->depth_ws + (size_t)(s0 + i) * ctx->N);
-        HIPCHK(ctx, hipMemcpyAsync(dst, frames[base + i], fbytes * run, hipMemcpyHostToDevice, cs), PWN_HIP_ERR_COPY);
-        i += run;
-      }
+      if (int rc = convert_stage_frames(ctx, job, base, m, cs)) return rc;
       if (ahead) {
         HIPCHK(ctx, hipEventRecord(ctx->sync_events[2 * k], cs), PWN_HIP_ERR_LAUNCH);
         HIPCHK(ctx, hipStreamWaitEvent(st, ctx->sync_events[2 * k], 0), PWN_HIP_ERR_LAUNCH);
       }
     }
-    if (int rc = launch_convert(ctx, cp, base, m, st, direct ? ctx->counts_host + n : nullptr)) return rc;
+    if (int rc = launch_convert(ctx, job.cp, base, m, st, direct ? ctx->counts_host + n : nullptr)) return rc;
     if (ahead) HIPCHK(ctx, hipEventRecord(ctx->sync_events[2 * k + 1], st), PWN_HIP_ERR_LAUNCH);
   }
   if (int rc = plan_join(ctx, plan)) return rc;
-  const int rc = sync_and_counts(ctx, clouds, n, direct);
+  const int rc = convert_finish(ctx, job, clouds);
   if (rc != PWN_HIP_OK && (ctx->last_convert_fault & 2) && ctx->fused_convert) {
     // the fused kernel found its workgroups on different XCDs (the round-robin placement it is built on did not hold on this device /
     // partition mode): never use it again on this context and convert the batch again with the two-kernel path
@@ -824,6 +867,8 @@ int pwn_hip_ctx_destroy(pwn_hip_ctx* ctx) {
   for (int k = 0; k < 8; ++k) if (ctx->scene_i[k]) (void)hipFree(ctx->scene_i[k]);
   for (int k = 0; k < 3; ++k) if (ctx->scene_k[k]) (void)hipFree(ctx->scene_k[k]);
   if (ctx->scene_total) (void)hipFree(ctx->scene_total);
+  if (ctx->records_ws) (void)hipFree(ctx->records_ws);
+  if (ctx->ids_dev) (void)hipFree(ctx->ids_dev);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   for (int k = 0; k < 2; ++k) { if (ctx->extra[k]) (void)hipStreamDestroy(ctx->extra[k]); if (ctx->join_extra[k]) (void)hipEventDestroy(ctx->join_extra[k]); }
@@ -1401,10 +1446,20 @@ static void finish_match(const MatchAcc& a, pwn_hip_match_result* r) {
   const double sum = a.sum64 ? (double)a.sum64 / 64.0 : (double)a.tiny * 1e-37;
   r->image_reprojection_distance = (float)sum / (float)(int)a.nonZeros;          // pwn_matcher_base.cpp:179 (0/0 = NaN like the reference)
 }
+// What a caller may weave into a batch alignment (pwn_hip_convert_align_batch_u16: the conversion of a sub-batch's frames goes in front of its
+// alignment on the same stream, so that one sub-batch converts while the other aligns and nothing waits for the host in between).
+struct AlignHooks {
+  std::function<int(int base, int m, int k, hipStream_t st)> pre_sub;      // before the kernels of pairs [base, base + m) (sub-batch k) are enqueued on st
+  std::function<int()> before_sync;                                        // on ctx->stream, after the streams have joined
+  std::function<int()> after_sync;                                         // after the final wait, before the results are filled in
+};
+// records (optional): n * PWN_HIP_RECORD_FLOATS floats, device or host, written by k_pack_records; pair_ids (optional, host): the id in
+// record word 19 (else first_pair_id + i).  results may be NULL when records are asked for.
 static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* refs, pwn_hip_cloud* const* curs,
                             const float* guesses, pwn_hip_align_result* results, pwn_hip_match_result* scores, float match_threshold,
-                            pwn_hip_align_statistics* statistics = nullptr) {
-  if (!ctx || !p || !refs || !curs || !results || n < 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+                            pwn_hip_align_statistics* statistics = nullptr, const AlignHooks* hooks = nullptr, float* records = nullptr,
+                            const int* pair_ids = nullptr, int first_pair_id = 0) {
+  if (!ctx || !p || !refs || !curs || (!results && !records) || n < 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if (int rc = check_image(ctx, p->rows, p->cols)) return rc;
   if (p->min_distance < 0.f) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "min_distance must be >= 0");
   const int nit = p->outer_iterations * p->inner_iterations;
@@ -1507,6 +1562,7 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
       ctx->img_ref_cloud = refs[base]; ctx->img_cur_cloud = curs[base];
     }
     const unsigned subLastRefTag = subTag0 - (tagsPerSub - 1);
+    if (hooks && hooks->pre_sub) { if (int rc = hooks->pre_sub(base, m, kk, st)) return rc; }
     if (!sub_own[kk]) {
       StageTimer t(ctx, "project_cur", st);
       launch_project(maxcap_cur, m, st, pr, ap, 1, subTag0);
@@ -1541,14 +1597,39 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
     HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
   }
   if (int rc = plan_join(ctx, plan)) return rc;
+  if (n > 0 && records) {
+    // the records leave the device as the kernel wrote them: straight into the caller's device buffer (what an all-gather sends), or through the
+    // context's own buffer into host memory
+    const bool dev = is_device_ptr(records);
+    if (!dev && ctx->records_cap < n) {
+      if (ctx->records_ws) (void)hipFree(ctx->records_ws);
+      ctx->records_ws = nullptr; ctx->records_cap = 0;
+      HIPCHK(ctx, hipMalloc((void**)&ctx->records_ws, (size_t)std::max(n, 64) * kRecordFloats * sizeof(float)), PWN_HIP_ERR_ALLOCATION);
+      ctx->records_cap = std::max(n, 64);
+    }
+    if (pair_ids) {
+      if (ctx->ids_cap < n) {
+        if (ctx->ids_dev) (void)hipFree(ctx->ids_dev);
+        ctx->ids_dev = nullptr; ctx->ids_cap = 0;
+        HIPCHK(ctx, hipMalloc((void**)&ctx->ids_dev, (size_t)std::max(n, 64) * sizeof(int)), PWN_HIP_ERR_ALLOCATION);
+        ctx->ids_cap = std::max(n, 64);
+      }
+      HIPCHK(ctx, copy_any(ctx->ids_dev, pair_ids, sizeof(int) * n, ctx->stream), PWN_HIP_ERR_COPY);
+    }
+    float* dst = dev ? records : ctx->records_ws;
+    hipLaunchKernelGGL(k_pack_records, dim3(n), dim3(64), 0, ctx->stream, ctx->pairs_dev, pair_ids ? (const int*)ctx->ids_dev : nullptr, first_pair_id, dst);
+    if (!dev) HIPCHK(ctx, hipMemcpyAsync(records, ctx->records_ws, sizeof(float) * kRecordFloats * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
+  }
+  if (hooks && hooks->before_sync) { if (int rc = hooks->before_sync()) return rc; }
   if (n > 0 && scores) HIPCHK(ctx, hipMemcpyAsync(ctx->match_host, ctx->match_dev, sizeof(MatchAcc) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
   if (n > 0 && statistics) HIPCHK(ctx, hipMemcpyAsync(ctx->stats_host, ctx->stats_dev, sizeof(SolveOut) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
   // direct_state: T, it and the traces of state_host[i] were written by the last k_solve_update of each pair (PairDesc::state_out); with no
   // iterations it still holds the initial state
-  if (n > 0 && !direct_state) HIPCHK(ctx, hipMemcpyAsync(ctx->state_host, ctx->state_ws, sizeof(PairState) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
+  if (n > 0 && !direct_state && results) HIPCHK(ctx, hipMemcpyAsync(ctx->state_host, ctx->state_ws, sizeof(PairState) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipEventRecord(ctx->t1, ctx->stream), PWN_HIP_ERR_LAUNCH);      // before the wait: recording it afterwards costs a second round trip per call
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
-  for (int i = 0; i < n; ++i) {
+  if (hooks && hooks->after_sync) { if (int rc = hooks->after_sync()) return rc; }
+  for (int i = 0; i < n && results; ++i) {
     const PairState& st = ctx->state_host[i];
     pwn_hip_align_result& r = results[i];
     std::memset(&r, 0, sizeof(r));
@@ -1571,7 +1652,7 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
     }
   }
   float ms = 0.f; (void)hipEventElapsedTime(&ms, ctx->t0, ctx->t1);
-  for (int i = 0; i < n; ++i) results[i].total_time_ms = n > 0 ? ms / n : 0.f;
+  for (int i = 0; i < n && results; ++i) results[i].total_time_ms = n > 0 ? ms / n : 0.f;
   // batches: no current z-buffer after a skipped projection; a single alignment makes it on demand
   ctx->img_rows = p->rows; ctx->img_cols = p->cols; ctx->img_valid = n > 0 && (!any_own || n == 1);
   ctx->img_cur_lazy = n == 1 && any_own; ctx->img_ap = ap; ctx->img_cur_capacity = n == 1 ? curs[0]->d.capacity : 0;
@@ -1704,6 +1785,52 @@ int pwn_hip_align_batch_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, in
                            const float* guesses, pwn_hip_align_result* results, float threshold, pwn_hip_match_result* scores,
                            pwn_hip_align_statistics* statistics) {
   return align_batch_impl(ctx, p, n, refs, curs, guesses, results, scores, threshold, statistics);
+}
+int pwn_hip_align_batch_records(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* refs, pwn_hip_cloud* const* curs,
+                                const float* guesses, const int* pair_ids, int first_pair_id, pwn_hip_align_result* results, float* records) {
+  if (!records) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null records");
+  return align_batch_impl(ctx, p, n, refs, curs, guesses, results, nullptr, 0.f, nullptr, nullptr, records, pair_ids, first_pair_id);
+}
+int pwn_hip_convert_align_batch_u16(pwn_hip_ctx* ctx, const pwn_hip_converter_params* cp, const pwn_hip_aligner_params* ap, int n,
+                                    const uint16_t* const* ref_frames, const uint16_t* const* cur_frames, float depth_scale, int rows, int cols,
+                                    pwn_hip_cloud* const* refs, pwn_hip_cloud* const* curs, const float* guesses, const int* pair_ids, int first_pair_id,
+                                    pwn_hip_align_result* results, float* records) {
+  if (!ctx || !cp || !ap || !ref_frames || !cur_frames || !refs || !curs || (!results && !records) || n < 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (int rc = check_image(ctx, rows, cols)) return rc;
+  if (ap->rows != rows || ap->cols != cols) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "aligner image size differs from the frames'");
+  if (int rc = absorb_copies(ctx)) return rc;
+  if (int rc = ensure_desc(ctx, 2 * n)) return rc;       // once, before anything is queued: growing the descriptor arrays waits for the stream
+  // the sub-batches and streams the alignment will use (align_batch_impl makes the same plan); the frames of sub-batch k -- its reference
+  // frames, then its current frames -- are converted on k's stream in front of k's alignment, in launches of at most sub_frames frames that
+  // reuse the stream's own block of frame slots
+  const StreamPlan plan = make_plan(ctx, ctx->sub_pairs, n);
+  const int sub = plan.sub;
+  const int fslots = std::max(1, std::min(ctx->sub_frames, ctx->max_batch / plan.ns));
+  std::vector<const uint16_t*> frames((size_t)2 * std::max(n, 0));
+  std::vector<pwn_hip_cloud*> clouds((size_t)2 * std::max(n, 0));
+  std::vector<int> slot((size_t)2 * std::max(n, 0));
+  for (int base = 0, k = 0; base < n; base += sub, ++k) {
+    const int m = std::min(sub, n - base);
+    for (int j = 0; j < m; ++j) {
+      frames[2 * base + j] = ref_frames[base + j]; clouds[2 * base + j] = refs[base + j];
+      frames[2 * base + m + j] = cur_frames[base + j]; clouds[2 * base + m + j] = curs[base + j];
+    }
+    for (int f = 0; f < 2 * m; ++f) slot[2 * base + f] = (k % plan.ns) * fslots + f % fslots;
+  }
+  ConvertJob job;
+  if (int rc = convert_prepare<uint16_t>(ctx, cp, frames.data(), depth_scale, 2 * n, rows, cols, clouds.data(), 0, false, slot, false, job)) return rc;
+  AlignHooks hooks;
+  hooks.pre_sub = [&](int base, int m, int, hipStream_t st) -> int {
+    for (int f = 0; f < 2 * m; f += fslots) {
+      const int cnt = std::min(fslots, 2 * m - f);
+      if (job.host_input) { if (int rc = convert_stage_frames(ctx, job, 2 * base + f, cnt, st)) return rc; }
+      if (int rc = launch_convert(ctx, job.cp, 2 * base + f, cnt, st)) return rc;
+    }
+    return PWN_HIP_OK;
+  };
+  hooks.before_sync = [&]() -> int { return counts_enqueue(ctx, 2 * n); };
+  hooks.after_sync = [&]() -> int { return counts_apply(ctx, clouds.data(), 2 * n); };
+  return align_batch_impl(ctx, ap, n, refs, curs, guesses, results, nullptr, 0.f, nullptr, &hooks, records, pair_ids, first_pair_id);
 }
 void pwn_hip_compute_statistics(const float H[36], const float T[16], float mean[6], float omega[36], float* tr, float* rr) {
   compute_statistics(H, mat4_from(T), mean, omega, tr, rr);

@@ -2155,6 +2155,31 @@ __global__ void __launch_bounds__(256) k_solve_update(const PairDesc* __restrict
   set_last_row(invT);
   st.invT = invT;
 }
+// The result record of a pair as it travels between ranks (include/pwn_hip.h: PWN_HIP_RECORD_FLOATS): 64 floats =
+//   [0:16] T column-major  [16] chi2 of the last iteration  [17] its inliers  [18] iterations  [19] the caller's pair id
+//   [20:30] chi2_i  [30:40] inliers_i  [40:50] C_i  [50:60] K_i (first 10 iterations)  [60] M_ref  [61] M_cur  [62] iterations in the traces  [63] 0
+// written on the device from the pair's state, so that a gather of records needs no trip through the host.  Counts travel as float
+// (exact below 2^24).  grid = pairs, block = 64
+constexpr int kRecordFloats = 64, kRecordTrace = 10;
+__global__ void __launch_bounds__(64) k_pack_records(const PairDesc* __restrict__ pairs, const int* __restrict__ pair_ids, int first_id, float* __restrict__ out) {
+  const PairDesc& pd = pairs[blockIdx.x];
+  const PairState& st = *pd.state;
+  const int t = threadIdx.x, it = st.it, m = it < kRecordTrace ? it : kRecordTrace;
+  float v = 0.f;
+  if (t < 16) v = st.T.m[t];
+  else if (t == 16) v = it > 0 ? st.chi2[it - 1] : 0.f;
+  else if (t == 17) v = it > 0 ? (float)st.inliers[it - 1] : 0.f;
+  else if (t == 18) v = (float)it;
+  else if (t == 19) v = (float)(pair_ids ? pair_ids[blockIdx.x] : first_id + (int)blockIdx.x);
+  else if (t < 30) v = (t - 20 < m) ? st.chi2[t - 20] : 0.f;
+  else if (t < 40) v = (t - 30 < m) ? (float)st.inliers[t - 30] : 0.f;
+  else if (t < 50) v = (t - 40 < m) ? (float)st.ncorr[t - 40] : 0.f;
+  else if (t < 60) v = (t - 50 < m) ? (float)st.ncand[t - 50] : 0.f;
+  else if (t == 60) v = (float)*pd.ref.count;
+  else if (t == 61) v = (float)*pd.cur.count;
+  else if (t == 62) v = (float)m;
+  out[(size_t)blockIdx.x * kRecordFloats + t] = v;
+}
 // reduction only, one record per pair (Aligner::_computeStatistics' 11th update).  grid = pairs, block = 256
 __global__ void __launch_bounds__(256) k_reduce_pairs(const PairDesc* __restrict__ pairs, int nblocks, SolveOut* __restrict__ out) {
   __shared__ double sums[kAccN];

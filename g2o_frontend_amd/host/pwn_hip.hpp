@@ -476,6 +476,27 @@ class Aligner {
                                        frameInlierDepthThreshold, scores ? scores->data() : nullptr, nullptr));
     return results;
   }
+  // One candidate batch from raw uint16 frames as one submission (pwn_hip_convert_align_batch_u16): per pair PwnMatcherBase::makeCloud of both
+  // frames (pwn_matcher_base.cpp:77-85), then align; `records` (optional): device or host buffer of n * PWN_HIP_RECORD_FLOATS floats that
+  // receives the fixed-size result records (pair id = firstPairId + i) straight from the device.
+  std::vector<pwn_hip_align_result> convertAlignBatch(DepthImageConverter& converter, const std::vector<Cloud*>& references, const std::vector<Cloud*>& currents,
+                                                      const std::vector<const uint16_t*>& refFrames, const std::vector<const uint16_t*>& curFrames,
+                                                      float depthScale, int rows, int cols, float* records = nullptr, int firstPairId = 0) {
+    const size_t n = references.size();
+    if (currents.size() != n || refFrames.size() != n || curFrames.size() != n) throw Error(PWN_HIP_ERR_INVALID_ARGUMENT, "Aligner::convertAlignBatch: list sizes differ");
+    std::vector<pwn_hip_align_result> results(n);
+    if (n == 0) return results;
+    const pwn_hip_converter_params cp = converter.params(Isometry3f::Identity());
+    const pwn_hip_aligner_params p = params();
+    std::vector<pwn_hip_cloud*> r(n), c(n);
+    for (size_t i = 0; i < n; ++i) {
+      if (!references[i] || !currents[i]) throw Error(PWN_HIP_ERR_INVALID_ARGUMENT, "Aligner::convertAlignBatch: null cloud");
+      r[i] = references[i]->handle(); c[i] = currents[i]->handle();
+    }
+    _ctx->check(pwn_hip_convert_align_batch_u16(_ctx->handle(), &cp, &p, (int)n, refFrames.data(), curFrames.data(), depthScale, rows, cols, r.data(), c.data(),
+                                                nullptr, nullptr, firstPairId, results.data(), records));
+    return results;
+  }
   // stage-level entry points with explicit inputs: CorrespondenceFinder::compute(reference, current, T) on two index images
   // (correspondencefinder.cpp:20-118) and Linearizer::update() with _T = T on the finder's correspondences (linearizer.cpp:17-115)
   void computeCorrespondences(const IntImage& referenceIndexImage, const IntImage& currentIndexImage, const Isometry3f& T) {

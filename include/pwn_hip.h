@@ -311,6 +311,28 @@ int pwn_hip_match_batch(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n
 int pwn_hip_align_batch_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* references,
                            pwn_hip_cloud* const* currents, const float* initial_guesses, pwn_hip_align_result* results,
                            float frame_inlier_depth_threshold, pwn_hip_match_result* scores, pwn_hip_align_statistics* statistics);
+/* The result of a pair as ONE fixed-size record of PWN_HIP_RECORD_FLOATS floats (256 bytes) -- what the ranks of a sharded candidate batch
+ * exchange (the reference runs the candidates of PwnCloser::process one after the other on one Aligner and keeps MatcherResult per pair,
+ * pwn_tracker/pwn_closer.cpp:92-111):
+ *   [0:16] T (column-major)   [16] chi2 of the last iteration   [17] its inliers   [18] iterations   [19] pair id
+ *   [20:30] chi2_i   [30:40] inliers_i   [40:50] correspondences C_i   [50:60] candidates K_i   (first 10 iterations; 0 beyond the last)
+ *   [60] points of the reference cloud   [61] of the current cloud   [62] iterations carried in the traces   [63] 0
+ * Counts travel as float (exact below 2^24).  The records are written by a kernel from the pairs' device state: `records` may be a DEVICE
+ * buffer (n * PWN_HIP_RECORD_FLOATS floats; e.g. the tensor an all-gather sends -- no trip through the host) or host memory.
+ * pair_ids (host, may be NULL: then record i carries first_pair_id + i).  results may be NULL when only the records are wanted. */
+#define PWN_HIP_RECORD_FLOATS 64
+int pwn_hip_align_batch_records(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* references,
+                                pwn_hip_cloud* const* currents, const float* initial_guesses, const int* pair_ids, int first_pair_id,
+                                pwn_hip_align_result* results, float* records);
+/* One candidate batch from raw frames as ONE submission: per pair i, DepthImageConverter::compute of ref_frames[i] -> references[i] and
+ * cur_frames[i] -> currents[i] (PwnMatcherBase::makeCloud, pwn_matcher_base.cpp:77-85), then Aligner::align of the pair
+ * (pwn_matcher_base.cpp:120-128).  The conversion of a sub-batch's frames is queued in front of its alignment on the same stream, so one
+ * sub-batch converts while the other aligns and nothing waits for the host between the two halves.  Results are bit for bit those of
+ * pwn_hip_convert_batch_u16 followed by pwn_hip_align_batch.  The 2 n clouds must be distinct; frames: uint16 millimetres, host or device. */
+int pwn_hip_convert_align_batch_u16(pwn_hip_ctx* ctx, const pwn_hip_converter_params* converter, const pwn_hip_aligner_params* aligner, int n,
+                                    const uint16_t* const* ref_frames, const uint16_t* const* cur_frames, float depth_scale, int rows, int cols,
+                                    pwn_hip_cloud* const* references, pwn_hip_cloud* const* currents, const float* initial_guesses,
+                                    const int* pair_ids, int first_pair_id, pwn_hip_align_result* results, float* records);
 /* Aligner::align with priors (aligner.cpp:96-108).  The prior terms (numeric Jacobians, se3_prior.cpp:8-52) are 6x6 host math
  * that changes the normal equations of every iteration, so this entry point keeps the reference's host-driven loop: per
  * iteration the GPU projects, finds correspondences and reduces H, b; the host adds damping + priors, solves and updates.

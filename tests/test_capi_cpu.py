@@ -162,6 +162,8 @@ def test_null_arguments_are_status_codes_not_crashes():
         "pwn_hip_cloud_omega_storage": (None, None, C.byref(n)),
         "pwn_hip_ctx_set_subbatch": (None, 64, 64),
         "pwn_hip_align": (None, None, None, None, None),
+        "pwn_hip_align_batch_records": (None, None, 1, None, None, None, None, 0, None, None),
+        "pwn_hip_convert_align_batch_u16": (None, None, None, 1, None, None, 0.001, 120, 160, None, None, None, None, 0, None, None),
         "pwn_hip_convert": (None, None, None, 120, 160, None, None, None, 0),
     }
     for name, args in cases.items():

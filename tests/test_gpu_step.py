@@ -1,0 +1,139 @@
+"""One candidate batch as ONE submission (pwn_hip_convert_align_batch_u16) and the result records packed on the device
+(pwn_hip_align_batch_records; include/pwn_hip.h: PWN_HIP_RECORD_FLOATS).  The reference converts and aligns the candidates of a closure one
+after the other (pwn_tracker/pwn_closer.cpp:92-111, pwn_matcher_base.cpp:77-85,120-128); here the conversion of a sub-batch is queued in
+front of its alignment on the sub-batch's stream.  What must hold:
+  * results bit for bit those of convert_batch_u16 followed by align_batch (any sub-batch size, one or two streams, host or device frames),
+    and therefore the oracle's (teacher-forced chi2 1e-5, exact counters: checked on a sampled pair);
+  * the records the kernel writes == shard.pack_results_raw of the host results, bit for bit, in a device buffer and in host memory;
+  * clouds keep their sizes / index images: a later single alignment of a pair equals its batch result.
+"""
+import numpy as np
+import pytest
+
+from conftest import case_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _rig(name, n, max_batch, omega="exact9"):
+    from g2o_frontend_amd import api, synth
+    from test_gpu_parity import gpu_objects
+    rows, cols, K, _, _ = case_params(name)
+    ctx = api.Context(0, rows, cols, max_batch, omega_storage=omega)
+    _, converter, aligner = gpu_objects(ctx, name)
+    pairs = [synth.make_pair(7000 + s, rows, cols, K) for s in range(n)]
+    refs = [api.Cloud(ctx, rows * cols) for _ in range(n)]; curs = [api.Cloud(ctx, rows * cols) for _ in range(n)]
+    return ctx, converter, aligner, pairs, refs, curs
+
+
+@pytest.mark.parametrize("sub_frames,sub_pairs,streams,device_frames", [(64, 64, 2, True), (4, 3, 2, True), (5, 4, 1, False), (16, 8, 2, False), (3, 5, 2, True)])
+def test_fused_step_equals_convert_then_align(sub_frames, sub_pairs, streams, device_frames):
+    from g2o_frontend_amd import shard
+    n = 11
+    ctx, converter, aligner, pairs, refs, curs = _rig("small", n, 32)
+    rf = [p[0] for p in pairs]; cf = [p[1] for p in pairs]
+    # reference sequence: two calls with a host wait between them
+    ctx.set_subbatch(64, 64); ctx.set_concurrency(2)
+    converter.computeBatch(refs + curs, rf + cf, raw_scale=0.001)
+    want = aligner.alignBatch(refs, curs, raw=True).copy()
+    sizes = [(r.size(), c.size()) for r, c in zip(refs, curs)]
+    # one submission, other clouds
+    from g2o_frontend_amd import api
+    rows, cols, _, _, _ = case_params("small")
+    refs2 = [api.Cloud(ctx, rows * cols) for _ in range(n)]; curs2 = [api.Cloud(ctx, rows * cols) for _ in range(n)]
+    ctx.set_subbatch(sub_frames, sub_pairs); ctx.set_concurrency(streams)
+    bufs = [ctx.upload(f) for f in rf + cf] if device_frames else None
+    frames = bufs if device_frames else rf + cf
+    rec = np.full((n, shard.RECORD_FLOATS), -7.0, np.float32)
+    ids = np.arange(100, 100 + n, dtype=np.int32)
+    got = aligner.convertAlignBatch(converter, refs2, curs2, frames[:n], frames[n:], raw_scale=0.001, records=rec, pair_ids=ids)
+    for k in ("T", "chi2", "iter_inliers", "iter_correspondences", "iter_candidates", "error", "inliers", "iterations", "n_reference", "n_current"):
+        assert np.array_equal(_bits(got[k]) if got[k].dtype == np.float32 else got[k], _bits(want[k]) if want[k].dtype == np.float32 else want[k]), k
+    assert [(r.size(), c.size()) for r, c in zip(refs2, curs2)] == sizes
+    assert np.array_equal(_bits(rec), _bits(shard.pack_results_raw(got, ids)))
+    # the clouds are complete: a later single alignment of a pair is its batch result
+    aligner.setReferenceCloud(refs2[7]); aligner.setCurrentCloud(curs2[7])
+    g = aligner.align()
+    assert np.array_equal(_bits(g["chi2"]), _bits(got["chi2"][7][:10])) and np.array_equal(_bits(np.asarray(g["T"], np.float32).T.reshape(-1)), _bits(got["T"][7]))
+    a, b = refs[3].arrays(), refs2[3].arrays()
+    for k in a:
+        assert np.array_equal(_bits(a[k]), _bits(b[k])), k
+    if bufs:
+        for f in bufs:
+            f.free()
+    ctx.close()
+
+
+def test_records_on_the_device_and_without_results():
+    from g2o_frontend_amd import shard
+    n = 6
+    ctx, converter, aligner, pairs, refs, curs = _rig("small", n, 16)
+    converter.computeBatch(refs + curs, [p[0] for p in pairs] + [p[1] for p in pairs], raw_scale=0.001)
+    want = aligner.alignBatch(refs, curs, raw=True).copy()
+    rec = ctx.upload(np.full((n, shard.RECORD_FLOATS), -3.0, np.float32))            # a device buffer, as the tensor an all-gather sends
+    got = aligner.alignBatchRecords(refs, curs, rec, first_pair_id=40)
+    assert np.array_equal(_bits(got["chi2"]), _bits(want["chi2"]))
+    assert np.array_equal(_bits(rec.numpy()), _bits(shard.pack_results_raw(want, np.arange(40, 40 + n))))
+    assert aligner.alignBatchRecords(refs, curs, rec, pair_ids=np.arange(n)[::-1].copy(), want_results=False) is None      # records only
+    assert np.array_equal(_bits(rec.numpy()), _bits(shard.pack_results_raw(want, np.arange(n)[::-1])))
+    # fewer iterations than trace slots, and none: the words past the last iteration stay 0
+    aligner.setOuterIterations(3)
+    h = np.zeros((n, shard.RECORD_FLOATS), np.float32)
+    r3 = aligner.alignBatchRecords(refs, curs, h)
+    assert np.array_equal(_bits(h), _bits(shard.pack_results_raw(r3, np.arange(n)))) and (h[:, 23:30] == 0).all() and (h[:, 62] == 3).all()
+    aligner.setOuterIterations(0)
+    r0 = aligner.alignBatchRecords(refs, curs, h)
+    assert np.array_equal(_bits(h), _bits(shard.pack_results_raw(r0, np.arange(n)))) and (h[:, 16:19] == 0).all()
+    rec.free()
+    ctx.close()
+
+
+def test_fused_step_vga_against_oracle_sym6(oracle):
+    """40 VGA pairs in the bench configuration (sub-batches of 16 on two streams, sym6 clouds, device frames): equal to the two-call
+    sequence; a sampled pair teacher-forced against the oracle"""
+    from g2o_frontend_amd import api
+    from test_gpu_parity import oracle_params, _check_teacher_forced
+    from test_omega_sym6 import compare_clouds_sym6
+    n = 40
+    ctx, converter, aligner, pairs, refs, curs = _rig("vga", n, 64, omega="sym6")
+    rows, cols, _, _, _ = case_params("vga")
+    ctx.set_subbatch(32, 16); ctx.set_concurrency(2)
+    bufs = [ctx.upload(p[0]) for p in pairs] + [ctx.upload(p[1]) for p in pairs]
+    got = aligner.convertAlignBatch(converter, refs, curs, bufs[:n], bufs[n:], raw_scale=0.001).copy()
+    again = aligner.convertAlignBatch(converter, refs, curs, bufs[:n], bufs[n:], raw_scale=0.001)
+    assert np.array_equal(_bits(got["chi2"]), _bits(again["chi2"])) and np.array_equal(_bits(got["T"]), _bits(again["T"]))
+    refs2 = [api.Cloud(ctx, rows * cols) for _ in range(n)]; curs2 = [api.Cloud(ctx, rows * cols) for _ in range(n)]
+    converter.computeBatch(refs2 + curs2, bufs, raw_scale=0.001)
+    want = aligner.alignBatch(refs2, curs2, raw=True)
+    for k in ("T", "chi2"):
+        assert np.array_equal(_bits(got[k]), _bits(want[k])), k
+    for k in ("iter_inliers", "iter_correspondences", "iter_candidates", "n_reference", "n_current"):
+        assert np.array_equal(got[k], want[k]), k
+    i = 23
+    cp, ap = oracle_params(oracle, "vga", accumulate_fp64=1)
+    oref, _, _ = oracle.convert(cp, oracle.convert_16u_to_32f(pairs[i][0])); ocur, _, _ = oracle.convert(cp, oracle.convert_16u_to_32f(pairs[i][1]))
+    compare_clouds_sym6(oref.arrays(), refs[i].arrays()); compare_clouds_sym6(ocur.arrays(), curs[i].arrays())
+    o = oracle.align(ap, oref, ocur)
+    aligner.setReferenceCloud(refs[i]); aligner.setCurrentCloud(curs[i])
+    worst = _check_teacher_forced(aligner, o)
+    print(f"fused step, pair {i}: worst teacher-forced chi2 rel diff {worst:.1e}")
+    for f in bufs:
+        f.free()
+    ctx.close()
+
+
+def test_fused_step_error_paths():
+    from g2o_frontend_amd._lib import PwnHipError
+    ctx, converter, aligner, pairs, refs, curs = _rig("small", 2, 8)
+    big = np.zeros((240, 320), np.uint16)
+    with pytest.raises(PwnHipError):                      # frames larger than the context
+        aligner.convertAlignBatch(converter, refs, curs, [big, big], [big, big])
+    with pytest.raises(PwnHipError):                      # neither results nor records
+        aligner.convertAlignBatch(converter, refs, curs, [p[0] for p in pairs], [p[1] for p in pairs], want_results=False)
+    r = aligner.convertAlignBatch(converter, refs, curs, [p[0] for p in pairs], [p[1] for p in pairs])      # the context still works
+    assert (r["iterations"] == 10).all()
+    ctx.close()
