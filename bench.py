@@ -25,6 +25,7 @@ import os
 import subprocess
 import sys
 import time
+import zlib
 
 import numpy as np
 
@@ -114,6 +115,49 @@ def _free_port():
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
     return p
+
+
+def cpu_topology():
+    """{package id: sorted cpus} of the cpus this process may run on (sysfs; one package when sysfs does not say)"""
+    pk = {}
+    for c in sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else range(os.cpu_count() or 1):
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/physical_package_id") as f:
+                k = int(f.read().strip())
+        except Exception:
+            k = 0
+        pk.setdefault(k, []).append(c)
+    return pk
+
+
+def rank_cpus(local_rank: int, n_local: int, topo=None):
+    """The cpus of one rank: the ranks of a node get DISJOINT, contiguous blocks, the first half of the ranks on the first socket and so on (GPUs
+    0..n/2-1 hang off socket 0 on the 8-GPU nodes), so that a rank's render pool and runtime threads neither migrate across sockets nor fight the
+    other ranks' for cores.  [] = leave the affinity alone (fewer cpus than ranks)."""
+    topo = cpu_topology() if topo is None else topo
+    packs = [sorted(topo[k]) for k in sorted(topo)]
+    if n_local <= 1 or sum(len(p) for p in packs) < n_local:
+        return []
+    if len(packs) > 1 and n_local % len(packs) == 0 and all(len(p) >= n_local // len(packs) for p in packs):
+        per = n_local // len(packs)
+        cpus, r, m = packs[local_rank // per], local_rank % per, per
+    else:
+        cpus, r, m = [c for p in packs for c in p], local_rank, n_local
+    lo, hi = (r * len(cpus)) // m, ((r + 1) * len(cpus)) // m
+    return cpus[lo:hi]
+
+
+def pin_rank(local_rank: int, n_local: int):
+    """called first thing in a rank, before anything touches the GPU (no wrapper process, no exec)"""
+    if os.environ.get("PWN_BENCH_NO_AFFINITY") == "1" or not hasattr(os, "sched_setaffinity"):
+        return None
+    cpus = rank_cpus(local_rank, n_local)
+    if cpus:
+        try:
+            os.sched_setaffinity(0, cpus)
+        except OSError:
+            return None
+    return cpus
 
 
 def launch_ranks(n: int, argv) -> int:
@@ -850,7 +894,8 @@ def dry_run_cpu(args, rank, world):
                  for p in range(total))
         print(json.dumps({"dry_run": True, "n_gpus": world, "records": int(allrec.shape[0]), "records_ok": bool(ok), "max_rank_seen": int(t.item()),
                           "pairs_per_gpu": P, "scaling": "strong" if args.total_pairs > 0 else "weak", "total_pairs": total,
-                          "records_crc": records_crc(allrec)[:4]}))
+                          "records_crc": records_crc(allrec)[:4], "records_crc_all": int(zlib.crc32(np.asarray(records_crc(allrec), np.uint32).tobytes())),
+                          "rank0_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -864,6 +909,7 @@ def main():
         # `python bench.py --gpus N`: become the launcher; the ranks are children started before any GPU call (this process makes none)
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
+    pinned = pin_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if world > 1 else None      # before the render pool and before any GPU call
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a number for a different GPU count", file=sys.stderr)
         sys.exit(2)
@@ -1009,7 +1055,8 @@ def main():
                                    f"{alig['outer_iterations']}x{alig['inner_iterations']} GN iterations); BASELINE configs[3] shard",
                        "pairs_per_gpu": P, "total_pairs": total, "rows": rows, "cols": cols, "sub_frames": args.sub_frames, "sub_pairs": args.sub_pairs,
                        "streams": args.streams, "omega_storage": args.omega_storage, "step_mode": args.step_mode,
-                       "parallelism": f"independent pairs sharded over {n_seen} GPU(s), RCCL all-gather of result records only"},
+                       "parallelism": f"independent pairs sharded over {n_seen} GPU(s), RCCL all-gather of result records only",
+                       "cpus_of_rank0": (len(pinned) if pinned else None)},
             "roofline": rep["roofline"],
             "cpu_baseline": cpu,
             "path_roofline": rep["path_roofline"],

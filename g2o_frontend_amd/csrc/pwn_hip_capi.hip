@@ -1002,7 +1002,7 @@ int pwn_hip_last_stage_ms(pwn_hip_ctx* ctx, const char* stage, float* ms, int* l
 // ---------------------------------------------------------------------------------------------------- clouds
 int pwn_hip_cloud_create(pwn_hip_ctx* ctx, int capacity, pwn_hip_cloud** out) {
   if (!ctx || !out || capacity <= 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "bad cloud_create argument");
-  if (capacity > kMaxCloudPoints) return fail(ctx, PWN_HIP_ERR_CAPACITY, "a cloud holds at most 2^21 points (z-buffer word layout)");
+  if (capacity > kMaxCloudPoints) return fail(ctx, PWN_HIP_ERR_CAPACITY, "a cloud holds at most 2^25 points (index field of the scene stage's z-buffer word)");
   HIPCHK(ctx, hipSetDevice(ctx->device), PWN_HIP_ERR_NO_DEVICE);
   for (size_t k = 0; k < ctx->cloud_pool.size(); ++k) {
     pwn_hip_cloud* r = ctx->cloud_pool[k];
@@ -1486,6 +1486,9 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
     const pwn_hip_cloud* r = refs[i]; const pwn_hip_cloud* c = curs[i];
     if (!r || !c) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null cloud in batch");
     if (c->d.omSym != omSym) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "current clouds of one batch must share one omega storage (exact9 / sym6)");
+    // the aligner's 32-bit z-buffer word indexes 2^21 points (every frame up to 1448 x 1448 pixels); larger clouds are scenes (merge, voxelize)
+    if (std::min(r->n_host, r->d.capacity) > kMaxAlignerPoints || std::min(c->n_host, c->d.capacity) > kMaxAlignerPoints)
+      return fail(ctx, PWN_HIP_ERR_CAPACITY, "Aligner::align: a cloud holds more than 2^21 points (index field of the aligner's z-buffer word)");
     const int slot = plan.slot0(i / sub) + i % sub;
     PairDesc& pd = ctx->pairs_host[i];
     pd.ref = r->d; pd.cur = c->d;
@@ -1692,6 +1695,8 @@ int pwn_hip_align_with_priors_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params*
     pr[i].invReference = priors[i].kind == 1 ? iso_inverse(mat4_from(priors[i].reference_transform)) : mat4_identity();
     std::memcpy(pr[i].information, priors[i].information, sizeof(pr[i].information));
   }
+  if (std::min(ref->n_host, ref->d.capacity) > kMaxAlignerPoints || std::min(cur->n_host, cur->d.capacity) > kMaxAlignerPoints)
+    return fail(ctx, PWN_HIP_ERR_CAPACITY, "Aligner::align: a cloud holds more than 2^21 points (index field of the aligner's z-buffer word)");
   const int N = p->rows * p->cols;
   const AlignParams ap = make_align_params(p);
   const int nb = align_nblocks(N);

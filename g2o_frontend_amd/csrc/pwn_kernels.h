@@ -14,7 +14,7 @@
 //   images: row-major int32 / float32, lanes along image x (row-coalesced loads)
 //   integral image: 10 planes [ch][rows][cols] (x y z n xx xy xz yy yz zz)
 //   z-buffer of the aligner: uint32 per pixel = epoch tag (11 b) | point index (21 b), empty = ~0 (kZ32Tag0);
-//   z-buffer of the stand-alone projection / Merger: uint64 = epoch tag (12 b) | float_bits(depth) (31 b) | point index (21 b)
+//   z-buffer of the stand-alone projection / Merger: uint64 = epoch tag (8 b) | float_bits(depth) (31 b) | point index (25 b)
 // Arithmetic follows the reference's evaluation order (left-to-right inner products, no FMA:
 // compiled with -ffp-contract=off) so integer outputs are bit-exact and fp32 outputs differ from
 // the CPU path only through libm-vs-ocml trig and summation order of the H/b reduction.
@@ -33,20 +33,24 @@ constexpr int kAccN = 37;              // Htt9 Htr9 Hrr9 bt3 br3 chi2 inliers C 
 constexpr int kPixPerThread = 8;
 constexpr int kAlignBlock = 256;
 constexpr unsigned long long kZEmpty = ~0ull;
-// z-buffer word = epoch tag (12 bits) | depth bits (31, depth >= 0) | point index (21 bits).  Projection number j of an
-// alignment uses tag kZTag0 - j: a smaller tag wins atomicMin, so words left by earlier projections behave as "empty"
-// and the buffer needs neither a clear pass nor a reset store between Gauss-Newton iterations.
-constexpr unsigned kZTag0 = 0xFFEu;
-constexpr int kZIndexBits = 21;
-constexpr int kMaxCloudPoints = 1 << kZIndexBits;
+// 64-bit z-buffer word (stand-alone projection, Merger::merge: the scene stage) = epoch tag (8 bits) | depth bits (31, depth >= 0) |
+// point index (25 bits).  Call number j uses tag kZTag0 - j: a smaller tag wins atomicMin, so words left by earlier projections behave
+// as "empty" and the buffer is cleared only when the tag space is used up (take_tags).  The reference's clouds have no size limit; a scene
+// grows by a frame per step (pwn_aligner.cpp:205-208: 1.2 M points per 1280x960 frame), so the index field is 25 bits wide here -- until
+// round 4 it was 21 (tag 12), the width the ALIGNER's 32-bit word still has (kZIndexBits below).
+constexpr unsigned kZTag0 = 0xFEu;
+constexpr int kZ64IndexBits = 25, kZ64TagShift = 56;
+constexpr int kMaxCloudPoints = 1 << kZ64IndexBits;      // 33 554 432 points per cloud
+constexpr int kZIndexBits = 21;                           // index field of the aligner's 32-bit word (kZ32Tag0)
+constexpr int kMaxAlignerPoints = 1 << kZIndexBits;       // 2 097 152: what a cloud handed to Aligner::align may hold
 __host__ __device__ __forceinline__ unsigned long long zkey(unsigned tag, float d, int i) {
-  return ((unsigned long long)tag << 52) | ((unsigned long long)(__builtin_bit_cast(unsigned, d) & 0x7fffffffu) << kZIndexBits) | (unsigned)i;
+  return ((unsigned long long)tag << kZ64TagShift) | ((unsigned long long)(__builtin_bit_cast(unsigned, d) & 0x7fffffffu) << kZ64IndexBits) | (unsigned)i;
 }
 __host__ __device__ __forceinline__ int zkey_index(unsigned long long k, unsigned tag) {
-  return ((unsigned)(k >> 52) == tag) ? (int)(k & ((1u << kZIndexBits) - 1u)) : -1;
+  return ((unsigned)(k >> kZ64TagShift) == tag) ? (int)(k & ((1u << kZ64IndexBits) - 1u)) : -1;
 }
 __host__ __device__ __forceinline__ float zkey_depth(unsigned long long k, unsigned tag) {
-  return ((unsigned)(k >> 52) == tag) ? __builtin_bit_cast(float, (unsigned)((k >> kZIndexBits) & 0x7fffffffu)) : FLT_MAX;
+  return ((unsigned)(k >> kZ64TagShift) == tag) ? __builtin_bit_cast(float, (unsigned)((k >> kZ64IndexBits) & 0x7fffffffu)) : FLT_MAX;
 }
 
 // Z-buffer of the ALIGNER (round 2): 32 bits per pixel = epoch tag (11 b) | point index (21 b), empty = ~0.  The depth is not stored:

@@ -192,7 +192,7 @@ int pwn_hip_merge(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud, const float K[9], cons
   if (min_distance < 0.f) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "min_distance must be >= 0");
   cloud_changes(ctx, cloud);
   const int n = cloud->n_host;
-  if (n > kMaxCloudPoints) return fail(ctx, PWN_HIP_ERR_CAPACITY, "cloud has more points than the z-buffer index field holds (2^21)");
+  if (n > kMaxCloudPoints) return fail(ctx, PWN_HIP_ERR_CAPACITY, "cloud has more points than the z-buffer index field holds (2^25)");
   if (!cloud->sb.G || cloud->n_gauss < n) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "Merger::merge needs the cloud's Gaussians (pwn_hip_cloud_gaussians)");
   if (n == 0) { if (new_size) *new_size = 0; return PWN_HIP_OK; }
   if (int rc = ensure_back(ctx, cloud)) return rc;

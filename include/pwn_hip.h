@@ -193,8 +193,11 @@ void pwn_hip_default_converter_params(pwn_hip_converter_params* p);
 void pwn_hip_default_aligner_params(pwn_hip_aligner_params* p);
 
 /* ------------------------------------------------------------------ clouds ------------------- */
-/* capacity = maximum number of points (rows*cols of the images it will be converted from); at most 2^21 = 2 097 152
- * (the z-buffers keep the point index in 21 bits of their words) */
+/* capacity = maximum number of points (rows*cols of the images it will be converted from; for a scene that grows by Cloud::add,
+ * pwn_aligner.cpp:205-208, the sum of its frames): at most 2^25 = 33 554 432 (index field of the scene stage's 64-bit z-buffer word).
+ * The clouds handed to the align / match calls may hold at most 2^21 = 2 097 152 points (index field of the aligner's 32-bit z-buffer
+ * word: every frame up to 1448 x 1448 pixels) -- PWN_HIP_ERR_CAPACITY beyond that; merge, voxelize, cloud_add, save / load,
+ * transform_in_place and project take the large ones. */
 int pwn_hip_cloud_create(pwn_hip_ctx* ctx, int capacity, pwn_hip_cloud** cloud);
 int pwn_hip_cloud_destroy(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud);
 int pwn_hip_cloud_size(pwn_hip_ctx* ctx, const pwn_hip_cloud* cloud, int* n);    /* Cloud::points().size() */

@@ -98,6 +98,42 @@ def test_strong_scaling_mode_shards_one_pair_list_and_assembles_the_same_records
     assert runs[1]["records_crc"] == runs[2]["records_crc"]
 
 
+def test_world_8_dry_runs_weak_and_strong_assemble_the_records_of_the_single_rank_run():
+    """the driver's N = 8 launch rehearsed on the CPU (gloo): weak scaling = BASELINE configs[3] (8 x 128 pair ids) and strong scaling
+    (--total-pairs 1024 over 8 ranks) both assemble, on rank 0, exactly the 1024 records of the one-rank run; every rank pinned to its
+    own block of cores when the box has enough of them"""
+    runs = {}
+    for key, argv in (("n1", ["--gpus", "1", "--total-pairs", "1024"]), ("weak8", ["--gpus", "8", "--pairs", "128"]), ("strong8", ["--gpus", "8", "--total-pairs", "1024"]),
+                      ("strong4", ["--gpus", "4", "--total-pairs", "1024"])):
+        out = subprocess.run([sys.executable, BENCH, "--dry-run-cpu"] + argv, capture_output=True, text=True, timeout=600, env=_clean_env())
+        assert out.returncode == 0, out.stderr[-2000:]
+        lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out.stdout
+        runs[key] = json.loads(lines[0])
+        assert runs[key]["records"] == 1024 and runs[key]["records_ok"] and runs[key]["total_pairs"] == 1024
+    assert runs["weak8"]["n_gpus"] == 8 and runs["weak8"]["pairs_per_gpu"] == 128 and runs["weak8"]["scaling"] == "weak" and runs["weak8"]["max_rank_seen"] == 7
+    assert runs["strong8"]["scaling"] == "strong" and runs["strong8"]["pairs_per_gpu"] == 128 and runs["strong4"]["pairs_per_gpu"] == 256
+    assert runs["n1"]["records_crc_all"] == runs["weak8"]["records_crc_all"] == runs["strong8"]["records_crc_all"] == runs["strong4"]["records_crc_all"]
+    ncpu = len(os.sched_getaffinity(0))
+    if ncpu >= 8:
+        assert runs["strong8"]["rank0_cpus"] == ncpu // 8 and runs["n1"]["rank0_cpus"] == ncpu
+
+
+def test_rank_cpu_blocks_are_disjoint_and_follow_the_sockets():
+    sys.path.insert(0, ROOT)
+    import bench
+    two = {0: list(range(0, 64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}      # 2 sockets, hyper-threads numbered after the cores
+    blocks = [bench.rank_cpus(r, 8, two) for r in range(8)]
+    assert all(len(b) == 32 for b in blocks) and len(set(c for b in blocks for c in b)) == 256
+    assert all(set(blocks[r]) <= set(two[0]) for r in range(4)) and all(set(blocks[r]) <= set(two[1]) for r in range(4, 8))
+    one = {0: list(range(10))}
+    b3 = [bench.rank_cpus(r, 3, one) for r in range(3)]
+    assert sorted(c for b in b3 for c in b) == list(range(10)) and all(b for b in b3)
+    assert bench.rank_cpus(0, 1, two) == [] and bench.rank_cpus(0, 16, {0: list(range(8))}) == []                   # one rank / fewer cpus than ranks: left alone
+    odd = {0: list(range(6)), 1: list(range(6, 12))}
+    assert [len(bench.rank_cpus(r, 3, odd)) for r in range(3)] == [4, 4, 4]                                          # ranks not divisible by sockets: flat split
+
+
 def test_records_crc_gate(tmp_path, monkeypatch):
     sys.path.insert(0, ROOT)
     import bench

@@ -125,3 +125,24 @@ def test_result_gather_through_rccl_world_size_1():
     assert line["n_gpus"] == 1 and line["gather"]["backend"].startswith("nccl") and line["gather"]["forced"] is True
     assert line["gather"]["records_equal_local"] is True and line["gather"]["records"] == 6
     assert line["value"] > 0
+
+
+def test_strong_mode_at_configs3_size_on_one_gpu_matches_the_committed_record_digests():
+    """BASELINE configs[3] literally -- the 1024-pair list -- on ONE GPU in strong-scaling mode (`bench.py --gpus 1 --total-pairs 1024`): the
+    records equal, CRC by CRC, those committed in profiles/records_crc.json (written by the same command with --write-records-crc for the
+    kernel sources in the tree).  This is the gate a multi-GPU run is held to (`gather.records_vs_single_gpu_run`): a pair's record is the
+    same bits whatever rank, sub-batch or position aligned it."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--total-pairs", "1024", "--steps", "1", "--warmup", "0",
+                          "--no-cpu-baseline", "--no-latency", "--no-extras", "--no-profile"], env=env, capture_output=True, text=True, timeout=1100)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    g = line["gather"]["records_vs_single_gpu_run"]
+    assert line["scaling"] == "strong" and line["config"]["total_pairs"] == 1024 and line["config"]["pairs_per_gpu"] == 1024
+    assert g["checked"] == 1024 and g["file_is_for_these_kernels"] is True, g
+    assert g["equal"] is True and g["mismatches"] == 0, g
+    assert line["gather"]["records_equal_local"] is True

@@ -371,3 +371,59 @@ def test_scene_edge_cases_and_error_paths(gctx, oracle):
     # unreadable / foreign files
     with pytest.raises(PwnHipError):
         api.Cloud(gctx, 8).load("/nonexistent/file.pwn")
+
+
+@pytest.mark.gpu
+def test_scene_above_two_million_points_1280x960(oracle):
+    """The mapping loop of pwn_aligner.cpp:205-208 at BASELINE configs[4]'s frame size: three 1280x960 frames added to one scene
+    (3.6 M points: above the 2^21 the z-buffer words could index until round 4), Merger::merge from the last pose, then the voxel grid --
+    every array bit-exact against the oracle, collapsed / kept indices equal.  The aligner itself keeps its 2^21-point word: handing it
+    the scene is refused with PWN_HIP_ERR_CAPACITY."""
+    from g2o_frontend_amd import api, synth
+    from g2o_frontend_amd._lib import PwnHipError
+    from test_gpu_parity import gpu_objects
+    name = "k2"
+    rows, cols, K, conv, _ = case_params(name)
+    N = rows * cols
+    poses = [np.eye(4, dtype=np.float32), synth.pair_pose(11).astype(np.float32), synth.pair_pose(12).astype(np.float32)]
+    depths = [oracle.convert_16u_to_32f(synth.render_depth_mm(11, np.asarray(p, np.float64), rows, cols, K)) for p in poses]
+    oracle.set_gaussians(True)
+    try:
+        cp = oracle.converter_params(K=K, **conv)
+        oclouds = [oracle.convert(cp, d)[0] for d in depths]
+    finally:
+        oracle.set_gaussians(False)
+    ctx = api.Context(0, rows, cols, 2)
+    proj, converter, aligner = gpu_objects(ctx, name)
+    gclouds = []
+    for d in depths:
+        c = api.Cloud(ctx, N)
+        converter.compute(c, d, keep_stats=True, gaussians=True)
+        gclouds.append(c)
+    oscene = oracle.Cloud(); gscene = api.Cloud(ctx, 3 * N)
+    for oc, gc, T in zip(oclouds, gclouds, poses):
+        oscene.add(oc, T); gscene.add(gc, T)
+    n0 = len(oscene)
+    assert n0 == gscene.size() and n0 > (1 << 21), n0
+    _same_cloud(oscene, gscene)
+    # the projection of the large scene as an image (stand-alone projector: the same 64-bit words as the merger's)
+    oi, od = oracle.project(K, poses[1], conv["min_distance"], conv["max_distance"], rows, cols, oscene.arrays()["points"])
+    proj.setTransform(poses[1]); proj.setImageSize(rows, cols)
+    gi, gd = proj.project(gscene)
+    assert np.array_equal(oi, gi) and np.array_equal(od.view(np.uint32), gd.view(np.uint32)) and gi.max() >= (1 << 21)
+    with pytest.raises(PwnHipError) as e:
+        aligner.setReferenceCloud(gscene); aligner.setCurrentCloud(gclouds[0]); aligner.align()
+    assert e.value.code == 6
+    merger = api.Merger(); merger.setDepthImageConverter(converter); merger.setImageSize(rows, cols)
+    ok, ocol = oracle.merge(oscene, K, poses[2], conv["min_distance"], conv["max_distance"], rows, cols)
+    gk = merger.merge(gscene, poses[2])
+    assert gk == ok and np.array_equal(merger.collapsedIndices(), ocol)
+    assert ((ocol >= 0) & (ocol != np.arange(len(ocol)))).sum() > 100000 and ocol.max() >= (1 << 21)      # targets beyond the old index field took part
+    _same_cloud(oscene, gscene)
+    vox = api.VoxelCalculator()
+    ok, okept = oracle.voxelize(oscene, 0.02, literal=False)
+    gk = vox.compute(gscene, 0.02)
+    assert gk == ok and np.array_equal(vox.keptIndices(), okept)
+    _same_cloud(oscene, gscene, gauss=False)
+    print(f"scene of {n0} points: merge -> {len(ocol) - int(((ocol >= 0) & (ocol != np.arange(len(ocol)))).sum())}, voxel grid (2 cm) -> {ok}")
+    ctx.close()
