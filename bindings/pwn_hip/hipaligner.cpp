@@ -124,7 +124,8 @@ void HipAligner::alignBatch(const std::vector<Cloud*>& references, const std::ve
   for (size_t i = 0; i < initialGuesses.size(); ++i) {
     Eigen::Isometry3f T = initialGuesses[i];
     T.matrix().row(3) << 0.0f, 0.0f, 0.0f, 1.0f;                                               // aligner.h:130-133
-    Eigen::Map<Eigen::Matrix4f>(&g[16 * i]) = T.matrix();
+    Eigen::Map<Eigen::Matrix4f> dst(&g[16 * i]);      // (a temporary `Map<..>(&g[..]) = ..` would parse as a declaration)
+    dst = T.matrix();
   }
   const int rc = pwn_hip_align_batch_ex(ctx, &p, (int)n, &r[0], &c[0], g.empty() ? 0 : &g[0], &results[0], frameInlierDepthThreshold,
                                         scores ? &(*scores)[0] : 0, 0);

@@ -24,8 +24,10 @@ def test_traffic_json_is_what_the_newest_pmc_summary_gives(tmp_path):
     # the gfx950 FETCH_SIZE correction holds in these very passes: the 2 GiB streaming probe reads back as 2 GiB (+- 0.1 %)
     chk = t["k_probe_read_check"]
     assert abs(chk["bytes_from_counters"] / chk["bytes_streamed"] - 1.0) < 1e-3
-    # the dominant kernel's traffic is within 15 % of its algorithmic bytes (1.09 x): the roofline fraction is not an artefact of re-reads
-    assert 1.0 < t["k_corr_linearize_bytes_per_pair_iteration"] / 27.6e6 < 1.15
+    # the dominant kernel's traffic is within 15 % of its algorithmic bytes: the roofline fraction is not an artefact of re-reads.  Since the sym6
+    # storage (round 4) the counters read slightly BELOW SURVEY 8(d)'s formula (0.97 x): it counts 72 bytes per candidate and 28 per correspondence
+    # (16-byte points, a 4-byte class word of the normal information matrix), the kernel gathers 56 + 24 (12-byte points, the class derived)
+    assert 0.90 < t["k_corr_linearize_bytes_per_pair_iteration"] / 27.6e6 < 1.15
 
 
 def test_bench_line_of_the_round_is_committed_and_self_consistent():
