@@ -342,7 +342,7 @@ class BatchWorkload:
         self.ids = np.asarray(self.seeds, np.int32)                                  # global pair ids: word 19 of the records
         self.conv_prep = self.converter.batchHandles(self.refs + self.curs, self.ref_dev + self.cur_dev)
         self.align_prep = ((C.c_void_p * P)(*[c.h for c in self.refs]), (C.c_void_p * P)(*[c.h for c in self.curs]), P)
-        self.step_prep = self.aligner.convertAlignHandles(self.refs, self.curs, self.ref_dev, self.cur_dev)
+        self.step_prep = self.aligner.convertAlignHandles(self.refs, self.curs, self.ref_dev, self.cur_dev, converter=self.converter)
         self.fused = getattr(args, "step_mode", "fused") == "fused"
         self.stage_ms = {k: 0.0 for k in STAGES}; self.stage_n = {k: 0 for k in STAGES}
         self.last = {}
@@ -945,7 +945,8 @@ def main():
     if extras_on and not args.no_tracker and (rows, cols) == (480, 640):
         poses = synth.trajectory_sweep(9, args.tracker_frames)
         jobs += [("frame", 9, poses[k].tolist(), 480, 640, synth.K_VGA, k) for k in range(args.tracker_frames)]
-    rendered = render_all(jobs, world, args.render_workers)
+    # a pinned rank owns its cores: the pool takes all of them; unpinned ranks share the box (cores // world each)
+    rendered = render_all(jobs, 1 if pinned else world, args.render_workers)
     frames_mm = rendered[:P]; frames5 = rendered[P:P + n5]; frames_trk = rendered[P + n5:]
 
     import torch

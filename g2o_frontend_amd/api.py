@@ -781,10 +781,11 @@ class Aligner:
                           initialGuesses=None, want_results=True, prepared=None):
         """One candidate batch from raw uint16 frames as one submission (pwn_hip_convert_align_batch_u16): per pair makeCloud of both frames, then
         align; sub-batch k converts while sub-batch k-1 aligns.  prepared = (refs, curs, ref frame ptrs, cur frame ptrs, n, (rows, cols))."""
-        cp, p = converter.params(None), self.params()
         if prepared is None:
             prepared = self.convertAlignHandles(references, currents, refFrames, curFrames)
-        refs, curs, rf, cf, n, (rows, cols) = prepared
+        refs, curs, rf, cf, n, (rows, cols) = prepared[:6]
+        # the two parameter structs cost ~35 us of Python per call: a caller that repeats a call with unchanged objects passes them along
+        cp, p = prepared[6] if len(prepared) > 6 else (converter.params(None), self.params())
         res = (AlignResult * n)() if want_results else None
         g = None
         if initialGuesses is not None:
@@ -794,11 +795,13 @@ class Aligner:
                                                                    _ptr(ids), int(first_pair_id), res, _ptr(records)))
         return np.frombuffer(res, dtype=ALIGN_RESULT_DTYPE, count=n) if want_results else None
 
-    @staticmethod
-    def convertAlignHandles(references, currents, refFrames, curFrames):
+    def convertAlignHandles(self, references, currents, refFrames, curFrames, converter=None):
+        """handle / pointer arrays for convertAlignBatch(..., prepared=...); with `converter`, the parameter structs of both objects as they
+        are NOW ride along (rebuild after changing a parameter)"""
         n = len(references)
-        return ((C.c_void_p * n)(*[c.h for c in references]), (C.c_void_p * n)(*[c.h for c in currents]),
-                (C.c_void_p * n)(*[_ptr(d) for d in refFrames]), (C.c_void_p * n)(*[_ptr(d) for d in curFrames]), n, tuple(refFrames[0].shape))
+        out = ((C.c_void_p * n)(*[c.h for c in references]), (C.c_void_p * n)(*[c.h for c in currents]),
+               (C.c_void_p * n)(*[_ptr(d) for d in refFrames]), (C.c_void_p * n)(*[_ptr(d) for d in curFrames]), n, tuple(refFrames[0].shape))
+        return out + ((converter.params(None), self.params()),) if converter is not None else out
 
     # stage-level entry points (CorrespondenceFinder::compute / Linearizer::update with explicit inputs)
     def computeCorrespondences(self, referenceIndexImage, currentIndexImage, T):
