@@ -134,6 +134,9 @@ def test_fused_step_error_paths():
         aligner.convertAlignBatch(converter, refs, curs, [big, big], [big, big])
     with pytest.raises(PwnHipError):                      # neither results nor records
         aligner.convertAlignBatch(converter, refs, curs, [p[0] for p in pairs], [p[1] for p in pairs], want_results=False)
+    import ctypes as C
+    empty = ((C.c_void_p * 0)(), (C.c_void_p * 0)(), (C.c_void_p * 0)(), (C.c_void_p * 0)(), 0, (120, 160))
+    assert len(aligner.convertAlignBatch(converter, None, None, None, None, prepared=empty)) == 0             # an empty batch is a no-op
     r = aligner.convertAlignBatch(converter, refs, curs, [p[0] for p in pairs], [p[1] for p in pairs])      # the context still works
     assert (r["iterations"] == 10).all()
     ctx.close()
