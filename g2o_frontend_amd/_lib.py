@@ -135,6 +135,7 @@ PROTOTYPES = {
     "pwn_hip_set_profiling": (_I, [_VP, _I]),
     "pwn_hip_debug_withhold_carry": (_I, [_VP, _I, _I, _I, _I, _I]),
     "pwn_hip_debug_set_index_shortcut": (_I, [_VP, _I]),
+    "pwn_hip_debug_convert_retries": (_I, [_VP, C.POINTER(_I)]),
     "pwn_hip_measure_hbm": (_I, [_VP, C.c_size_t, _VP, _VP]),
 }
 

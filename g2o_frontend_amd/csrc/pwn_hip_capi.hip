@@ -96,6 +96,9 @@ struct pwn_hip_ctx {
                                            // frames: see k_convert_fused), so it is off unless asked for; switched off for the context when a launch
                                            // reports that its workgroups were not placed as the kernel needs
   int spin_limit = kSpinLimit; int dbg_withhold = -1;        // pwn_hip_debug_withhold_carry (test hook)
+  int dbg_withhold_once = 0;                                 // the hook switches itself off after the first launch that timed out
+  int convert_retries = 0;                                   // conversions repeated after a hand-over time-out (pwn_hip_debug_convert_retries)
+  bool in_step_retry = false;
   // align workspaces (per slot)
   unsigned long long* zref_ws = nullptr;        // 64-bit z-buffer of the stand-alone projection and of Merger::merge (one image)
   unsigned* z32ref_ws = nullptr; unsigned* z32cur_ws = nullptr;      // the aligner's 32-bit z-buffers (tag | index), one image per slot
@@ -529,6 +532,7 @@ int counts_apply(pwn_hip_ctx* ctx, pwn_hip_cloud* const* clouds, int n) {
     const int code = ctx->counts_host[n];
     (void)hipMemset(ctx->fault_dev, 0, sizeof(int));
     ctx->last_convert_fault = code;
+    if (ctx->dbg_withhold_once) { ctx->dbg_withhold = -1; ctx->spin_limit = kSpinLimit; ctx->dbg_withhold_once = 0; }
     if (code & 2) return fail(ctx, PWN_HIP_ERR_LAUNCH, "fused converter: the workgroups of a frame were not placed on one XCD (results invalid)");
     return fail(ctx, PWN_HIP_ERR_LAUNCH, "integral image: strip hand-over timed out (results invalid)");
   }
@@ -632,7 +636,7 @@ int convert_finish(pwn_hip_ctx* ctx, const ConvertJob& job, pwn_hip_cloud* const
 
 template <typename SRC>
 int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const SRC* const* frames, float depth_scale, int n,
-                       int rows, int cols, pwn_hip_cloud* const* clouds, int keep_stats, bool want_interval = false) {
+                       int rows, int cols, pwn_hip_cloud* const* clouds, int keep_stats, bool want_interval = false, bool retried = false) {
   if (!ctx || !p || !frames || !clouds || n < 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if (int rc = check_image(ctx, rows, cols)) return rc;
   if (int rc = absorb_copies(ctx)) return rc;
@@ -676,11 +680,18 @@ int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, cons
   }
   if (int rc = plan_join(ctx, plan)) return rc;
   const int rc = convert_finish(ctx, job, clouds);
+  if (rc != PWN_HIP_OK && ctx->last_convert_fault == 1 && !retried) {
+    // A strip waited for its left neighbour longer than the poll bound (~1 s): the neighbour's workgroup was not dispatched in time -- a device
+    // shared with another process's long kernels -- and the planes of this call are invalid.  Nothing is left behind (epoch-tagged words), so
+    // the call is simply made again, once; a second time-out is reported.
+    ++ctx->convert_retries;
+    return convert_batch_impl<SRC>(ctx, p, frames, depth_scale, n, rows, cols, clouds, keep_stats, want_interval, true);
+  }
   if (rc != PWN_HIP_OK && (ctx->last_convert_fault & 2) && ctx->fused_convert) {
     // the fused kernel found its workgroups on different XCDs (the round-robin placement it is built on did not hold on this device /
     // partition mode): never use it again on this context and convert the batch again with the two-kernel path
     ctx->fused_convert = 0;
-    return convert_batch_impl<SRC>(ctx, p, frames, depth_scale, n, rows, cols, clouds, keep_stats, want_interval);
+    return convert_batch_impl<SRC>(ctx, p, frames, depth_scale, n, rows, cols, clouds, keep_stats, want_interval, retried);
   }
   return rc;
 }
@@ -919,10 +930,16 @@ int pwn_hip_ctx_set_concurrency(pwn_hip_ctx* ctx, int streams) {
 // its fault flag and the convert call returns PWN_HIP_ERR_LAUNCH instead of hanging.  strip < 0 switches the hook off.
 int pwn_hip_debug_withhold_carry(pwn_hip_ctx* ctx, int strip, int band, int chain, int rows, int spin_limit) {
   if (!ctx) return fail(nullptr, PWN_HIP_ERR_INVALID_ARGUMENT, "null ctx");
-  if (strip < 0) { ctx->dbg_withhold = -1; ctx->spin_limit = kSpinLimit; return PWN_HIP_OK; }
+  if (strip < 0) { ctx->dbg_withhold = -1; ctx->spin_limit = kSpinLimit; ctx->dbg_withhold_once = 0; return PWN_HIP_OK; }
   if (band < 0 || chain < 0 || chain >= kII_Chains || rows <= 0 || band >= bands_of(rows)) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "bad hand-over word");
   ctx->dbg_withhold = (strip * bands_of(rows) + band) * kII_Chains + chain;
-  ctx->spin_limit = spin_limit > 0 ? spin_limit : kSpinLimit;
+  ctx->dbg_withhold_once = spin_limit < 0 ? 1 : 0;                  // negative: |spin_limit| polls, and only the next launch is disturbed
+  ctx->spin_limit = spin_limit > 0 ? spin_limit : (spin_limit < 0 ? -spin_limit : kSpinLimit);
+  return PWN_HIP_OK;
+}
+int pwn_hip_debug_convert_retries(pwn_hip_ctx* ctx, int* retries) {
+  if (!ctx || !retries) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  *retries = ctx->convert_retries;
   return PWN_HIP_OK;
 }
 // Test hook: 0 makes every alignment project both clouds in every iteration, also where a cloud's own index image is known to be that
@@ -1835,7 +1852,15 @@ int pwn_hip_convert_align_batch_u16(pwn_hip_ctx* ctx, const pwn_hip_converter_pa
   };
   hooks.before_sync = [&]() -> int { return counts_enqueue(ctx, 2 * n); };
   hooks.after_sync = [&]() -> int { return counts_apply(ctx, clouds.data(), 2 * n); };
-  return align_batch_impl(ctx, ap, n, refs, curs, guesses, results, nullptr, 0.f, nullptr, &hooks, records, pair_ids, first_pair_id);
+  const int rc = align_batch_impl(ctx, ap, n, refs, curs, guesses, results, nullptr, 0.f, nullptr, &hooks, records, pair_ids, first_pair_id);
+  if (rc != PWN_HIP_OK && ctx->last_convert_fault == 1 && !ctx->in_step_retry) {      // a hand-over time-out (see convert_batch_impl): the step once more
+    ++ctx->convert_retries;
+    ctx->in_step_retry = true;
+    const int rc2 = pwn_hip_convert_align_batch_u16(ctx, cp, ap, n, ref_frames, cur_frames, depth_scale, rows, cols, refs, curs, guesses, pair_ids, first_pair_id, results, records);
+    ctx->in_step_retry = false;
+    return rc2;
+  }
+  return rc;
 }
 void pwn_hip_compute_statistics(const float H[36], const float T[16], float mean[6], float omega[36], float* tr, float* rr) {
   compute_statistics(H, mat4_from(T), mean, omega, tr, rr);

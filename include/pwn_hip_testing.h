@@ -14,6 +14,10 @@ extern "C" {
  * While the hook is on every convert call of the context fails; the word index is the same in both kernels that hand over
  * (k_unproject_integral, k_unproject_integral_rows: 10 planes x band rows chains per (strip, band)). */
 int pwn_hip_debug_withhold_carry(pwn_hip_ctx* ctx, int strip, int band, int chain, int rows, int spin_limit);
+/* spin_limit < 0: |spin_limit| polls and ONE disturbed launch only -- the hook switches itself off when that launch has timed out, so
+ * that the library's own recovery can be watched: a convert call (and the one-submission step) whose launch timed out is made again, once,
+ * before an error is reported (the words are epoch-tagged: a failed launch leaves nothing behind).  Number of such repeats so far: */
+int pwn_hip_debug_convert_retries(pwn_hip_ctx* ctx, int* retries);
 
 /* An alignment does not project a cloud where the cloud's own index image (the one DepthImageConverter::compute produced for it) is known
  * to be what that projection returns: same camera matrix, image size and range, identity pose (the current cloud always; the reference cloud

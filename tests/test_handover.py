@@ -51,6 +51,38 @@ def test_withheld_handover_word_is_an_error_not_a_hang(oracle, n_frames):
     ctx.close()
 
 
+@pytest.mark.parametrize("n_frames", [2, 20])
+def test_a_single_timed_out_launch_is_repeated_and_the_call_succeeds(n_frames):
+    """a launch whose hand-over timed out (a neighbour strip's workgroup not dispatched in time on a device shared with foreign kernels) leaves
+    nothing behind -- the words are epoch-tagged --, so the library repeats the call once on its own: with a ONE-SHOT withheld word the convert
+    call and the one-submission step return normally with the right results, and the repeat is counted"""
+    import ctypes as C
+    from g2o_frontend_amd import api, synth
+    rows, cols, K, conv, _ = case_params("small")
+    ctx = api.Context(0, rows, cols, 64)
+    _, converter, aligner = _objects(ctx, "small")
+    frames = [synth.render_depth_mm(50 + k, np.eye(4), rows, cols, K) for k in range(n_frames)]
+    clouds = [api.Cloud(ctx, rows * cols) for _ in range(n_frames)]
+    converter.computeBatch(clouds, frames, raw_scale=0.001)
+    good = [_digest(c) for c in clouds]
+    n = C.c_int(-1)
+    ctx.check(ctx._L.pwn_hip_debug_convert_retries(ctx.h, C.byref(n))); assert n.value == 0
+    ctx.check(ctx._L.pwn_hip_debug_withhold_carry(ctx.h, 0, 2, 37, rows, -4096))          # one disturbed launch
+    converter.computeBatch(clouds, frames, raw_scale=0.001)                                # no exception
+    assert [_digest(c) for c in clouds] == good
+    ctx.check(ctx._L.pwn_hip_debug_convert_retries(ctx.h, C.byref(n))); assert n.value == 1
+    # the one-submission step: same recovery
+    h = n_frames // 2
+    want = aligner.alignBatch(clouds[:h], clouds[h:], raw=True).copy()
+    ctx.check(ctx._L.pwn_hip_debug_withhold_carry(ctx.h, 0, 1, 5, rows, -4096))
+    got = aligner.convertAlignBatch(converter, clouds[:h], clouds[h:], frames[:h], frames[h:], raw_scale=0.001)
+    assert np.array_equal(got["chi2"].view(np.uint32), want["chi2"].view(np.uint32)) and np.array_equal(got["T"].view(np.uint32), want["T"].view(np.uint32))
+    ctx.check(ctx._L.pwn_hip_debug_convert_retries(ctx.h, C.byref(n))); assert n.value == 2
+    converter.computeBatch(clouds, frames, raw_scale=0.001)                                # undisturbed again
+    ctx.check(ctx._L.pwn_hip_debug_convert_retries(ctx.h, C.byref(n))); assert n.value == 2
+    ctx.close()
+
+
 def test_two_converting_contexts_and_an_aligner_soak(oracle):
     """40 rounds x (2 x 24-frame single-pass conversions on two contexts / host threads) next to a thread that keeps aligning on a third
     context: every conversion bit-identical to the first one, no hand-over time-out, the alignments unchanged."""
