@@ -487,6 +487,7 @@ class Aligner {
     std::vector<pwn_hip_align_result> results(n);
     if (n == 0) return results;
     const pwn_hip_converter_params cp = converter.params(Isometry3f::Identity());
+    converter.projector()->setImageSize(rows, cols); converter.projector()->setTransform(Isometry3f::Identity());      // side effects of compute() (depthimageconverterintegralimage.cpp:30,38)
     const pwn_hip_aligner_params p = params();
     std::vector<pwn_hip_cloud*> r(n), c(n);
     for (size_t i = 0; i < n; ++i) {

@@ -379,6 +379,9 @@ def test_cpp_bench_matches_python_mirror(tmp_path):
     assert head[0] == "pairs" and int(head[1]) == 32 and float(head[7]) > 100.0, out[0]
     rows = [np.array(l.split()[1:], np.float64) for l in out[1:] if l.startswith("pair")]
     assert len(rows) == npairs
+    # mode 3: the same step as ONE submission (Aligner::convertAlignBatch of the C++ mirror): the same lines, character for character
+    one = subprocess.check_output([exe, str(tmp_path / "list.txt"), "32", "2", "1", "0", "3"], timeout=300).decode().splitlines()
+    assert [l for l in one[1:] if l.startswith("pair")] == [l for l in out[1:] if l.startswith("pair")] and one[0].split()[-1] == "3"
     ctx = api.Context(0, 480, 640, 8)
     try:
         _, converter, aligner = gpu_objects(ctx, "vga")

@@ -38,7 +38,7 @@ static bool readPGM16(const std::string& fn, RawDepthImage& img) {
 }
 
 int main(int argc, char** argv) {
-  if (argc < 2) { std::cout << "USAGE: pwn_hip_bench depthImageList.txt [pairs=128] [steps=5] [warmup=1] [device=0] [mode=0]" << std::endl; return 0; }
+  if (argc < 2) { std::cout << "USAGE: pwn_hip_bench depthImageList.txt [pairs=128] [steps=5] [warmup=1] [device=0] [mode=0: frames resident, convert then align | 1: host frames | 2: double-buffered uploads | 3: resident, one submission]" << std::endl; return 0; }
   const int P = argc > 2 ? atoi(argv[2]) : 128, steps = argc > 3 ? atoi(argv[3]) : 5, warmup = argc > 4 ? atoi(argv[4]) : 1, device = argc > 5 ? atoi(argv[5]) : 0;
   const int mode = argc > 6 ? atoi(argv[6]) : 0;
   std::vector<RawDepthImage> frames;
@@ -77,8 +77,8 @@ int main(int argc, char** argv) {
     check(pwn_hip_host_alloc((void**)&host, nfr * fbytes), "pwn_hip_host_alloc");
     for (size_t i = 0; i < nfr; ++i) std::memcpy(host + i * fpix, frames[i % frames.size()].data.data(), fbytes);
     uint16_t* dev[2] = { nullptr, nullptr };
-    for (int b = 0; b < (mode == 2 ? 2 : (mode == 0 ? 1 : 0)); ++b) check(pwn_hip_device_alloc(ctx.handle(), (void**)&dev[b], nfr * fbytes), "pwn_hip_device_alloc");
-    if (mode == 0) check(pwn_hip_copy(ctx.handle(), dev[0], host, nfr * fbytes), "pwn_hip_copy");
+    for (int b = 0; b < (mode == 2 ? 2 : ((mode == 0 || mode == 3) ? 1 : 0)); ++b) check(pwn_hip_device_alloc(ctx.handle(), (void**)&dev[b], nfr * fbytes), "pwn_hip_device_alloc");
+    if (mode == 0 || mode == 3) check(pwn_hip_copy(ctx.handle(), dev[0], host, nfr * fbytes), "pwn_hip_copy");
     std::vector<Cloud*> clouds(nfr), refs(P), curs(P);
     std::vector<const uint16_t*> raw(nfr);
     for (size_t i = 0; i < nfr; ++i) clouds[i] = new Cloud(ctx, rows * cols);
@@ -86,9 +86,16 @@ int main(int argc, char** argv) {
     std::vector<pwn_hip_align_result> results;
     int flip = 0;
     if (mode == 2) check(pwn_hip_copy_async(ctx.handle(), dev[0], host, nfr * fbytes), "pwn_hip_copy_async");      // prime the first block
+    std::vector<const uint16_t*> rawRef(P), rawCur(P);
     auto step = [&]() {
       const uint16_t* base = mode == 1 ? host : dev[mode == 2 ? flip : 0];
       for (size_t i = 0; i < nfr; ++i) raw[i] = base + i * fpix;
+      if (mode == 3) {      // the whole step as ONE submission (pwn_hip_convert_align_batch_u16): frames resident, same bits as mode 0
+        for (int i = 0; i < P; ++i) { rawRef[i] = raw[2 * i]; rawCur[i] = raw[2 * i + 1]; }
+        projector.setImageSize(rows, cols);
+        results = aligner.convertAlignBatch(converter, refs, curs, rawRef, rawCur, 0.001f, rows, cols);
+        return;
+      }
       converter.computeBatchRaw(clouds, raw, 0.001f, rows, cols);                       // waits for the copies queued into `base`
       if (mode == 2) { flip ^= 1; check(pwn_hip_copy_async(ctx.handle(), dev[flip], host, nfr * fbytes), "pwn_hip_copy_async"); }   // the next step's frames travel during the alignment
       projector.setImageSize(rows, cols);
