@@ -119,6 +119,24 @@ def test_world_8_dry_runs_weak_and_strong_assemble_the_records_of_the_single_ran
         assert runs["strong8"]["rank0_cpus"] == ncpu // 8 and runs["n1"]["rank0_cpus"] == ncpu
 
 
+def test_the_drivers_launch_line_through_torch_distributed_run():
+    """the N > 1 launch exactly as the driver issues it: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...: ranks read RANK / LOCAL_RANK / WORLD_SIZE / LOCAL_WORLD_SIZE from the env, pin themselves, rank 0 prints
+    the one line"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+                          BENCH, "--gpus", "2", "--dry-run-cpu", "--pairs", "128"], capture_output=True, text=True, timeout=600, env=_clean_env())
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    j = json.loads(lines[0])
+    assert j["n_gpus"] == 2 and j["records"] == 256 and j["records_ok"] and j["max_rank_seen"] == 1 and j["scaling"] == "weak"
+    ncpu = len(os.sched_getaffinity(0))
+    if ncpu >= 2:
+        assert j["rank0_cpus"] == ncpu // 2
+
+
 def test_rank_cpu_blocks_are_disjoint_and_follow_the_sockets():
     sys.path.insert(0, ROOT)
     import bench
