@@ -31,7 +31,9 @@ def test_traffic_json_is_what_the_newest_pmc_summary_gives(tmp_path):
 
 
 def test_bench_line_of_the_round_is_committed_and_self_consistent():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r03_bench_line_b.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_line_a.json")))
+    assert d["config"]["omega_storage"] == "sym6" and d["config"]["step_mode"] == "fused" and d["config"]["workload"].startswith("loop-closure batch: 128 independent 640x480")
+    assert d["gather"]["records_vs_single_gpu_run"]["equal"] and d["gather"]["records_vs_single_gpu_run"]["checked"] == 128
     r = d["roofline"]
     assert d["unit"] == "alignments/s" and d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["bound"] == "hbm"
