@@ -230,6 +230,16 @@ struct StreamPlan {
 StreamPlan make_plan(pwn_hip_ctx* ctx, int want_sub, int n) {
   StreamPlan p;
   p.sub = std::max(1, std::min(want_sub, ctx->max_batch));
+  // A batch is cut into a multiple of `streams` sub-batches of equal size (not larger than asked for), so that no stream idles while the other
+  // works: the short dependent kernels of one sub-batch (projection, 6x6 step) fill the gaps of the other's large ones.  Measured on MI355X
+  // (one-submission step, two streams): 64 VGA pairs as 2 x 32 instead of 1 x 64: 11 340 -> 12 170 alignments/s; 32 pairs as 2 x 16: 10 620 ->
+  // 11 440; 32 pairs of 1280x960 as 2 x 16: 2 900 -> 3 090 (docs/experiments.md, round 4).  A call is only cut when every part keeps at least 16
+  // items (the converter's single-pass kernels start there: PWN_SINGLE_PASS_MIN_FRAMES); smaller calls stay one launch sequence.
+  if (ctx->stream == ctx->own_stream && ctx->stream2 && ctx->concurrency >= 2) {
+    const int k = std::min(std::min(ctx->concurrency, 4), (!ctx->extra[0] ? 2 : (!ctx->extra[1] ? 3 : 4)));
+    const int nsub_even = k * ((n + k * p.sub - 1) / (k * p.sub));
+    if (nsub_even > 0 && n / nsub_even >= 16) p.sub = (n + nsub_even - 1) / nsub_even;
+  }
   const int nsub = (n + p.sub - 1) / p.sub;
   int ns = 1;
   if (ctx->stream == ctx->own_stream && ctx->stream2)

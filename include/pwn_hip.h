@@ -141,7 +141,9 @@ int pwn_hip_ctx_set_stream(pwn_hip_ctx* ctx, void* hip_stream);
 int pwn_hip_ctx_synchronize(pwn_hip_ctx* ctx);
 /* Batch calls are executed in sub-batches of at most this many frames / pairs (default 64, capped by
  * max_batch), which bounds the workspace the temporaries (integral images, z-buffers) need.  Measured on
- * MI355X: larger sub-batches are faster (fewer, fuller launches).  Results do not depend on it. */
+ * MI355X: larger sub-batches are faster (fewer, fuller launches) -- as long as every stream has one: a call of
+ * 32 items or more is cut into a multiple of `streams` (below) equal sub-batches of at least 16 and no more than this many items (64 pairs
+ * run as 2 x 32 on two streams: +7 % over 1 x 64).  Results do not depend on it. */
 int pwn_hip_ctx_set_subbatch(pwn_hip_ctx* ctx, int frames, int pairs);
 /* streams = 2 (default): batch calls deal their sub-batches round-robin over up to `streams` (1..4) HIP streams of the context when the
  * workspaces hold one sub-batch per stream: the short dependent kernels of one sub-batch (projection, 6x6 solve) fill the gaps of the
