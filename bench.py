@@ -62,7 +62,7 @@ def parse(argv=None):
     ap.add_argument("--step-mode", choices=("fused", "split"), default=os.environ.get("PWN_STEP_MODE", "fused"),
                     help="fused: one submission per step (pwn_hip_convert_align_batch_u16: sub-batch k converts while k-1 aligns); split: convert_batch_u16, then "
                          "align_batch_records (a host wait between the halves).  Same results bit for bit; the records are packed on the device in both")
-    ap.add_argument("--streams", type=int, default=2, help="HIP streams the batch calls use in the timed region (1 = serial)")
+    ap.add_argument("--streams", type=int, default=4, help="HIP streams the batch calls use in the timed region (1 = serial)")
     ap.add_argument("--render-workers", type=int, default=0,
                     help="processes that render the synthetic frames (0 = automatic; 1 = in this process: required under rocprofv3, whose preloaded "
                          "library has initialised the GPU before Python starts -- no child process may be started from such a process)")

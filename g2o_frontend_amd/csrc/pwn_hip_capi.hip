@@ -82,7 +82,7 @@ struct pwn_hip_ctx {
   int num_cus = 256;                       // compute units of the device (hipDeviceAttributeMultiprocessorCount)
   size_t N = 0;
   int sub_frames = 64, sub_pairs = 64;
-  int concurrency = 2;
+  int concurrency = 4;
   int omega_sym = 0;                       // pwn_hip_ctx_set_omega_storage: storage of the point information matrices of clouds created from now on
   // convert workspaces (per slot)
   float* depth_ws = nullptr; int* index_ws = nullptr; int* interval_ws = nullptr; float* integral_ws = nullptr; int* rowoff_ws = nullptr;
@@ -236,9 +236,11 @@ StreamPlan make_plan(pwn_hip_ctx* ctx, int want_sub, int n) {
   // 11 440; 32 pairs of 1280x960 as 2 x 16: 2 900 -> 3 090 (docs/experiments.md, round 4).  A call is only cut when every part keeps at least 16
   // items (the converter's single-pass kernels start there: PWN_SINGLE_PASS_MIN_FRAMES); smaller calls stay one launch sequence.
   if (ctx->stream == ctx->own_stream && ctx->stream2 && ctx->concurrency >= 2) {
-    const int k = std::min(std::min(ctx->concurrency, 4), (!ctx->extra[0] ? 2 : (!ctx->extra[1] ? 3 : 4)));
-    const int nsub_even = k * ((n + k * p.sub - 1) / (k * p.sub));
-    if (nsub_even > 0 && n / nsub_even >= 16) p.sub = (n + nsub_even - 1) / nsub_even;
+    const int kmax = std::min(std::min(ctx->concurrency, 4), (!ctx->extra[0] ? 2 : (!ctx->extra[1] ? 3 : 4)));
+    for (int k = kmax; k >= 2; --k) {      // as many streams as leave every part 16 items
+      const int nsub_even = k * ((n + k * p.sub - 1) / (k * p.sub));
+      if (nsub_even > 0 && n / nsub_even >= 16) { p.sub = (n + nsub_even - 1) / nsub_even; break; }
+    }
   }
   const int nsub = (n + p.sub - 1) / p.sub;
   int ns = 1;

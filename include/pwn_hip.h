@@ -145,10 +145,12 @@ int pwn_hip_ctx_synchronize(pwn_hip_ctx* ctx);
  * 32 items or more is cut into a multiple of `streams` (below) equal sub-batches of at least 16 and no more than this many items (64 pairs
  * run as 2 x 32 on two streams: +7 % over 1 x 64).  Results do not depend on it. */
 int pwn_hip_ctx_set_subbatch(pwn_hip_ctx* ctx, int frames, int pairs);
-/* streams = 2 (default): batch calls deal their sub-batches round-robin over up to `streams` (1..4) HIP streams of the context when the
+/* streams = 4 (default): batch calls deal their sub-batches round-robin over up to `streams` (1..4) HIP streams of the context when the
  * workspaces hold one sub-batch per stream: the short dependent kernels of one sub-batch (projection, 6x6 solve) fill the gaps of the
- * other's large ones.  Measured on MI355X: 2 streams +12 % over 1, 3 and 4 no better than 2.  streams = 1: strictly serial launches (use
- * it when profiling per-kernel durations).  Results are identical. */
+ * others' large ones.  Measured on MI355X, 128 VGA pairs per call: 2 streams +12 % over 1; with the one-submission step
+ * (pwn_hip_convert_align_batch_u16) 4 streams x 32 pairs another +2 % over 2 x 64 (10.04-10.09 against 10.19-10.35 ms; round 2 had measured
+ * 3 and 4 no better than 2 on the two-call sequence).  streams = 1: strictly serial launches (use it when profiling per-kernel durations).
+ * Results are identical. */
 int pwn_hip_ctx_set_concurrency(pwn_hip_ctx* ctx, int streams);
 /* Storage of the point information matrices (InformationMatrix, informationmatrix.h:13; PointInformationMatrixCalculator::compute,
  * informationmatrixcalculator.cpp:9-36) of the clouds created on the context FROM NOW ON (existing clouds keep theirs;
