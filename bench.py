@@ -416,7 +416,8 @@ class BatchWorkload:
 
     def report(self, steps, dt, dt_serial, world):
         res = self.last["res"]; P = self.P
-        nsub = (P + self.args.sub_pairs - 1) // self.args.sub_pairs
+        # sub-batches a step was executed in (the library balances them over the streams): every sub-batch launches the fused pass n_it times
+        nsub = max(1.0, self.stage_n["corr_linearize"] / max(steps, 1) / max(self.n_it, 1)) if dt_serial else 1.0
         pc = self.stage_n["project_cur"] / max(steps, 1) / nsub if dt_serial else 1.0
         pr = self.stage_n["project_ref"] / max(steps, 1) / nsub if dt_serial else float(self.n_it)
         b = self.bytes_per_pair(res, pc, pr)
@@ -529,7 +530,7 @@ def run_extras_vga(w: BatchWorkload, args):
     L = ctx._L
 
     def stage_counts():
-        return {k: ctx.stage_ms(k)[1] for k in ("project_cur", "project_ref")}
+        return {k: ctx.stage_ms(k)[1] for k in ("project_cur", "project_ref", "corr_linearize")}
 
     # (1) align only, identity guess (warm cloud cache; the batch path takes the converter's own index images for the current cloud
     #     and for the first reference projection)
@@ -540,7 +541,7 @@ def run_extras_vga(w: BatchWorkload, args):
         ctx.check(L.pwn_hip_align_batch(ctx.h, C.byref(p), P, refs, curs, None, res))
     w.barrier(); dt = time.perf_counter() - a
     ctx.set_profiling(True); ctx.check(L.pwn_hip_align_batch(ctx.h, C.byref(p), P, refs, curs, None, res)); sc = stage_counts(); ctx.set_profiling(False)
-    nsub = (P + args.sub_pairs - 1) // args.sub_pairs
+    nsub = max(1.0, sc["corr_linearize"] / max(w.n_it, 1))       # sub-batches the call was executed in (balanced over the streams by the library)
     r = np.frombuffer(res, dtype=api.ALIGN_RESULT_DTYPE, count=P)
     b = w.bytes_per_pair(r, sc["project_cur"] / nsub, sc["project_ref"] / nsub)
     out["align_only"] = {"alignments_per_s": P * steps / dt, "ms_per_step": dt / steps * 1e3, "guess": "identity",
@@ -557,6 +558,7 @@ def run_extras_vga(w: BatchWorkload, args):
         ctx.check(L.pwn_hip_match_batch(ctx.h, C.byref(p), P, refs, curs, gp, 50.0, res, scores))
     w.barrier(); dt = time.perf_counter() - a
     ctx.set_profiling(True); ctx.check(L.pwn_hip_match_batch(ctx.h, C.byref(p), P, refs, curs, gp, 50.0, res, scores)); sc = stage_counts(); ctx.set_profiling(False)
+    nsub = max(1.0, sc["corr_linearize"] / max(w.n_it, 1))
     r = np.frombuffer(res, dtype=api.ALIGN_RESULT_DTYPE, count=P)
     b = w.bytes_per_pair(r, sc["project_cur"] / nsub, sc["project_ref"] / nsub)
     acc = api.PwnCloserAcceptance()
