@@ -31,7 +31,7 @@ def test_traffic_json_is_what_the_newest_pmc_summary_gives(tmp_path):
 
 
 def test_bench_line_of_the_round_is_committed_and_self_consistent():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_line_a.json")))
+    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_line_e.json")))
     assert d["config"]["omega_storage"] == "sym6" and d["config"]["step_mode"] == "fused" and d["config"]["workload"].startswith("loop-closure batch: 128 independent 640x480")
     assert d["gather"]["records_vs_single_gpu_run"]["equal"] and d["gather"]["records_vs_single_gpu_run"]["checked"] == 128
     r = d["roofline"]
