@@ -71,6 +71,12 @@ def parse(argv=None):
     ap.add_argument("--write-records-crc", action="store_true",
                     help="N = 1 only: write profiles/records_crc.json (per-pair CRC32 of the result records) -- multi-GPU runs check their assembled records against it")
     ap.add_argument("--check-gather", action="store_true", help="kept for scripts: the `gather` object (backend, records, equality with the local records) is always in the line")
+    ap.add_argument("--mode", choices=("pairs", "partition"), default="pairs",
+                    help="pairs (default, the headline): independent fresh pairs, convert 2 frames + align each.  partition: PwnCloser::processPartition "
+                         "(pwn_tracker/pwn_closer.cpp:85-111; SURVEY.md 8(e)) -- ONE `current` frame against the cached clouds of the other partition: every rank "
+                         "converts and caches its shard of --pairs keyframes per GPU once (untimed); a step = rank 0 converts `current`, its cloud is replicated "
+                         "to every GPU by one broadcast (RCCL), every rank runs matchClouds (align from an odometry guess + depth-agreement score) of `current` "
+                         "against its shard, 288-byte records all-gathered")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="launcher / sharding / gather plumbing only, on the CPU with the gloo backend (no GPU, no kernels): used by tests")
     return ap.parse_args(argv)
@@ -316,6 +322,18 @@ def cpu_baseline_child(args):
 STAGES = ["u16_to_f32", "unproject", "integral", "integral_rows", "integral_cols", "stats", "project_cur", "project_ref", "corr_linearize", "solve"]
 
 
+def align_bytes(N, n_it, res, proj_cur_per_pair, proj_ref_per_pair):
+    """algorithmic bytes per pair from the counters the kernels emit; res: structured result array"""
+    N = float(N)
+    Mr = res["n_reference"].astype(np.float64); Mc = res["n_current"].astype(np.float64)
+    Ks = res["iter_candidates"].sum(1).astype(np.float64); Cs = res["iter_correspondences"].sum(1).astype(np.float64)
+    convert = 2 * 8.0 * N + 64.0 * (Mr + Mc)                                   # two frames: 8N + 64M each
+    fused = n_it * 8.0 * N + 72.0 * Ks + 28.0 * Cs                             # all iterations
+    project = proj_cur_per_pair * (16.0 * Mc + 4.0 * N) + proj_ref_per_pair * (16.0 * Mr + 4.0 * N)      # EXECUTED projections only
+    align = project + fused + 8.0 * N
+    return dict(convert=convert, fused=fused, project=project, align=align, Mr=Mr, Mc=Mc, Ks=Ks, Cs=Cs)
+
+
 class BatchWorkload:
     """`P` pairs of one frame size on one context: convert 2P frames + align P pairs per step."""
 
@@ -351,6 +369,10 @@ class BatchWorkload:
         """one pass of the hot path over the rank's pairs; the 256-byte result records are written by a kernel straight into the device tensor the
         all-gather sends (no trip through the host), the caller's own copy of the results comes back beside them"""
         from g2o_frontend_amd import shard
+        if self.use_dist:
+            # k_pack_records writes self.records on the library's own stream; the all-gather of the previous step read it on torch's: the
+            # context's work of this step is ordered after what torch's current stream holds (pwn_hip_ctx_wait_stream)
+            self.ctx.wait_stream()
         if self.fused:
             res = self.aligner.convertAlignBatch(self.converter, None, None, None, None, raw_scale=0.001, records=self.records, pair_ids=self.ids,
                                                  prepared=self.step_prep)
@@ -403,16 +425,21 @@ class BatchWorkload:
             ctx.set_profiling(False); ctx.set_concurrency(self.args.streams)
         return dt, dt_serial
 
+    def time_collectives(self, n=20):
+        """the all-gather of the records alone (no compute): ms per call"""
+        import torch
+        from g2o_frontend_amd import shard
+        if not self.use_dist:
+            return {}
+        self.barrier(); t0 = time.perf_counter()
+        for _ in range(n):
+            shard.gather_records(self.records, self.world, self.Pmax, force=True)
+        torch.cuda.synchronize()
+        return {"gather_ms": (time.perf_counter() - t0) / n * 1e3}
+
     # ---- algorithmic bytes of SURVEY.md §8(d) from the measured counters
     def bytes_per_pair(self, res, proj_cur_per_pair, proj_ref_per_pair):
-        N, n_it = float(self.N), self.n_it
-        Mr = res["n_reference"].astype(np.float64); Mc = res["n_current"].astype(np.float64)
-        Ks = res["iter_candidates"].sum(1).astype(np.float64); Cs = res["iter_correspondences"].sum(1).astype(np.float64)
-        convert = 2 * 8.0 * N + 64.0 * (Mr + Mc)                                   # two frames: 8N + 64M each
-        fused = n_it * 8.0 * N + 72.0 * Ks + 28.0 * Cs                             # all iterations
-        project = proj_cur_per_pair * (16.0 * Mc + 4.0 * N) + proj_ref_per_pair * (16.0 * Mr + 4.0 * N)      # EXECUTED projections only
-        align = project + fused + 8.0 * N
-        return dict(convert=convert, fused=fused, project=project, align=align, Mr=Mr, Mc=Mc, Ks=Ks, Cs=Cs)
+        return align_bytes(self.N, self.n_it, res, proj_cur_per_pair, proj_ref_per_pair)
 
     def report(self, steps, dt, dt_serial, world):
         res = self.last["res"]; P = self.P
@@ -463,12 +490,8 @@ class BatchWorkload:
                                 "bytes_per_launch_algorithmic": alg, "traffic": tr,
                                 "traffic_over_algorithmic": (tr / alg) if tr else None,
                                 "traffic_GBps": (tr / (ms * 1e-3) / 1e9) if tr else None, "algorithmic_bytes": note}
-        fused_conv = self.stage_n.get("convert_fused", 0) > 0
-        if fused_conv:
-            kernel_entry("k_convert_fused", "convert_fused", 8.0 * self.N * F + 64.0 * Msum, F, "8N + 64M per frame (the whole converter: SURVEY.md 8(d))")
-        else:
-            kernel_entry("k_stats", "stats", 6.0 * self.N * F + 64.0 * Msum, F, "2N depth + 4N index in, 64M cloud out per frame (the 40N integral planes are a temporary)")
-            kernel_entry("k_unproject_integral", "integral", 6.0 * self.N * F, F, "2N depth in, 4N index out per frame (the 40N integral planes are a temporary)")
+        kernel_entry("k_stats", "stats", 6.0 * self.N * F + 64.0 * Msum, F, "2N depth + 4N index in, 64M cloud out per frame (the 40N integral planes are a temporary)")
+        kernel_entry("k_unproject_integral", "integral", 6.0 * self.N * F, F, "2N depth in, 4N index out per frame (the 40N integral planes are a temporary)")
         npj = self.stage_n["project_cur"] + self.stage_n["project_ref"]
         if npj:
             self.stage_ms["project"] = self.stage_ms["project_cur"] + self.stage_ms["project_ref"]; self.stage_n["project"] = npj
@@ -500,6 +523,162 @@ class BatchWorkload:
 
     def close(self):
         self.refs = self.curs = None
+        self.ctx.close()
+
+
+# ------------------------------------------------------------------------------------------------ processPartition workload (--mode partition)
+PARTITION_SCENE = 7          # seed of the scene every frame of the partition workload looks at
+PARTITION_POSE0 = 5000       # other frame k: camera pose synth.pair_pose(PARTITION_POSE0 + k) relative to `current` (<= 5 cm, ~2.3 deg per axis)
+
+
+def partition_jobs(ids, rows, cols, K):
+    """render jobs of the `other` frames with global ids `ids` (views of one scene from poses around `current`'s)"""
+    from g2o_frontend_amd import synth
+    return [("frame", PARTITION_SCENE, synth.pair_pose(PARTITION_POSE0 + k).tolist(), rows, cols, K, 1 + k) for k in ids]
+
+
+def partition_guesses(ids, t_noise=0.01, q_noise=0.004):
+    """iT * other.T of PwnCloser::processPartition (pwn_tracker/pwn_closer.cpp:101): the odometry's estimate of the pose of `other` in `current`'s
+    frame = the true relative pose disturbed by a seeded error of <= 1 cm / ~0.5 deg per axis.  [n, 4, 4] float64 (matchClouds zeroes the z translation)."""
+    from g2o_frontend_amd import synth
+    out = []
+    for k in ids:
+        u = synth._uniform(PARTITION_POSE0 + k, 7, 6)
+        dv = np.concatenate([(2 * u[0:3] - 1) * t_noise, (2 * u[3:6] - 1) * q_noise])
+        out.append(synth.pair_pose(PARTITION_POSE0 + k) @ synth.v2t(dv))
+    return out
+
+
+class PartitionWorkload:
+    """PwnCloser::processPartition (pwn_tracker/pwn_closer.cpp:85-111) sharded over the GPUs of a node (SURVEY.md 8(e), Partitioning): the clouds of the
+    other partition stay on the GPU that converted them (PwnCache: pwn_tracker_cache.cpp:24-51), the cloud of `current` is converted on rank 0 and
+    replicated with ONE broadcast of its flat form (pwn_hip_cloud_export / _import), every rank runs matchFrames' data path (matchClouds:
+    align from the odometry guess with the z translation zeroed + depth-agreement score, pwn_matcher_base.cpp:88-183) of `current` against its
+    shard, and the 288-byte match records are all-gathered.  `current` is the aligner's REFERENCE cloud of every pair (matchFrames(current, other):
+    from = current, pwn_closer.cpp:102,128-133)."""
+
+    def __init__(self, args, device, rows, cols, ids, other_frames_mm, current_mm, use_dist, world, rank, total):
+        import torch
+        from g2o_frontend_amd import api
+        self.args, self.rows, self.cols, self.ids, self.use_dist, self.world, self.rank, self.total = args, rows, cols, list(ids), use_dist, world, rank, total
+        self.P = len(self.ids); self.Pmax = (total + world - 1) // world
+        self.N = rows * cols
+        self.K, self.conv, self.alig = conf(rows, cols)
+        self.n_it = self.alig["outer_iterations"] * self.alig["inner_iterations"]
+        slots = max(2, args.streams) * max(args.sub_frames, args.sub_pairs, 1)
+        self.ctx = api.Context(device=device, max_rows=rows, max_cols=cols, max_batch=slots, omega_storage=args.omega_storage)
+        self.ctx.set_subbatch(args.sub_frames, args.sub_pairs)
+        self.converter, self.aligner = build_objects(self.ctx, rows, cols, self.K, self.conv, self.alig)
+        alproj = api.PinholePointProjector(); alproj.setMinDistance(self.alig["min_distance"]); alproj.setMaxDistance(self.alig["max_distance"])
+        self.aligner.setProjector(alproj)                 # matchClouds re-configures the aligner's projector on every call (pwn_matcher_base.cpp:117-119)
+        self.matcher = api.PwnMatcherBase(self.aligner, self.converter); self.matcher.setScale(1)
+        self.Km = np.array([[self.K[0], 0, self.K[2]], [0, self.K[1], self.K[3]], [0, 0, 1]], np.float32)
+        self.I = np.eye(4, dtype=np.float32)
+        # the cache of the other partition: this rank's shard, converted once (untimed)
+        self.other_dev = [torch.from_numpy(f.view(np.int16)).cuda() for f in other_frames_mm]
+        self.others = [api.Cloud(self.ctx, self.N) for _ in range(self.P)]
+        if self.P:
+            self.converter.computeBatch(self.others, self.other_dev, raw_scale=0.001)
+        self.other_dev = None
+        self.cur_dev = torch.from_numpy(current_mm.view(np.int16)).cuda() if rank == 0 else None
+        self.current = api.Cloud(self.ctx, self.N)        # rank 0: what the converter fills; other ranks: the replica the broadcast fills
+        # rank 0 of a forced one-rank run takes the replica path too (export -> broadcast -> import into a second cloud), so that the byte path is exercised
+        self.roundtrip = use_dist and world == 1
+        self.replica = api.Cloud(self.ctx, self.N) if self.roundtrip else None
+        self.flat = torch.empty(api.Cloud.flatBound(self.N, args.omega_storage, self.N), dtype=torch.uint8, device="cuda")
+        self.records = torch.empty((max(self.P, 1), api.MATCH_RECORD_FLOATS), dtype=torch.float32, device="cuda")
+        self.ids_np = np.asarray(self.ids, np.int32)
+        self.guesses = partition_guesses(self.ids)
+        ref = self.replica if self.roundtrip else self.current
+        self.prep = self.matcher.matchHandles([ref] * self.P, self.others, self.guesses)
+        self.stage_ms = {k: 0.0 for k in STAGES + ["match_score"]}; self.stage_n = {k: 0 for k in STAGES + ["match_score"]}
+        self.flat_bytes = 0
+        self.last = {}
+
+    def _collect(self, keys):
+        for k in keys:
+            ms, n = self.ctx.stage_ms(k); self.stage_ms[k] += ms; self.stage_n[k] += n
+
+    def step(self, profile=False):
+        import torch.distributed as dist
+        from g2o_frontend_amd import shard
+        if self.rank == 0:
+            self.converter.computeBatch([self.current], [self.cur_dev], raw_scale=0.001)           # makeCloud of `current` (pwn_closer.cpp:92-93: _cache->get(current))
+            if profile:
+                self._collect(STAGES[:6])
+            if self.use_dist:
+                self.flat_bytes = self.current.exportFlat(self.flat)                               # complete on return
+        if self.use_dist:
+            dist.broadcast(self.flat, src=0)                                                      # the only data-path collective: ~17 MB per step over xGMI
+            self.ctx.wait_stream()                                                                # the import reads what the broadcast wrote; the records
+            if self.rank != 0:                                                                    # buffer is free again (previous all-gather)
+                self.current.importFlat(self.flat)
+            elif self.roundtrip:
+                self.replica.importFlat(self.flat)
+        res = None
+        if self.P:
+            res = self.matcher.matchCloudsBatchRecords(None, None, self.I, self.I, self.Km, self.rows, self.cols, self.records, pair_ids=self.ids_np,
+                                                       prepared=self.prep)
+            if profile:
+                self._collect(STAGES[6:] + ["match_score"])
+        self.last["gathered"] = shard.gather_records(self.records[: self.P] if self.P else self.records[:0], self.world, self.Pmax, force=self.use_dist)
+        self.last["res"] = res
+
+    barrier = BatchWorkload.barrier
+    run = BatchWorkload.run
+
+    def time_collectives(self, n=20):
+        """the two collectives alone (no compute): ms per broadcast of the flat cloud, ms per all-gather of the records"""
+        import torch
+        import torch.distributed as dist
+        from g2o_frontend_amd import shard
+        out = {}
+        if not self.use_dist:
+            return out
+        self.barrier(); t0 = time.perf_counter()
+        for _ in range(n):
+            dist.broadcast(self.flat, src=0)
+        torch.cuda.synchronize(); out["broadcast_ms"] = (time.perf_counter() - t0) / n * 1e3
+        self.barrier(); t0 = time.perf_counter()
+        for _ in range(n):
+            shard.gather_records(self.records[: self.P], self.world, self.Pmax, force=True)
+        torch.cuda.synchronize(); out["gather_ms"] = (time.perf_counter() - t0) / n * 1e3
+        out["broadcast_bytes"] = int(self.flat.numel()); out["flat_cloud_bytes"] = int(self.flat_bytes)
+        return out
+
+    def report(self, steps, dt, dt_serial, world):
+        res, sc = self.last["res"]
+        P = self.P
+        r = res
+        nsub = max(1.0, self.stage_n["corr_linearize"] / max(steps, 1) / max(self.n_it, 1)) if dt_serial else 1.0
+        pc = self.stage_n["project_cur"] / max(steps, 1) / nsub if dt_serial else 1.0
+        pr = self.stage_n["project_ref"] / max(steps, 1) / nsub if dt_serial else float(self.n_it)
+        b = align_bytes(self.N, self.n_it, r, pc, pr)
+        Mcur = float(r["n_reference"][0]) if P else 0.0
+        step_bytes = float(b["align"].sum()) + (8.0 * self.N + 64.0 * Mcur) / max(world, 1)      # + this rank's share of the one conversion per step
+        launches = max(self.stage_n["corr_linearize"], 1)
+        k_ms = self.stage_ms["corr_linearize"] / launches
+        k_bytes = float(b["fused"].sum()) * steps / launches
+        achieved = k_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        acc = __import__("g2o_frontend_amd.api", fromlist=["api"]).PwnCloserAcceptance()
+        accepted = sum(1 for m in sc if acc.accept(dict(image_nonZeros=m.image_non_zeros, image_outliers=m.image_outliers, image_inliers=m.image_inliers)))
+        from g2o_frontend_amd import synth
+        terr = max(float(np.abs(r["T"][i].reshape(4, 4).T[:3, 3] - synth.pair_pose(PARTITION_POSE0 + k)[:3, 3]).max()) for i, k in enumerate(self.ids)) if P else 0.0
+        roofline = {"bound": "hbm", "kernel": "k_corr_linearize", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": None, "bytes_per_launch_algorithmic": k_bytes, "avg_launch_ms": k_ms, "launches": self.stage_n["corr_linearize"],
+                    "path_achieved_GBps": step_bytes * world * steps / dt / 1e9, "path_frac": step_bytes * world * steps / dt / 1e9 / HBM_PEAK_GBS / max(world, 1),
+                    "projections_per_pair": pc + pr,
+                    "algorithmic_bytes": "per pair: executed projections (16M + 4N each) + 10 x (8N + 72K_i + 28C_i) + 8N (SURVEY.md 8(d) align); per step one "
+                                         "conversion of `current` (8N + 64M); path_frac is per GPU",
+                    "measured_in": "serial profiled pass of the same K steps (one stream, hipEvent pair per kernel stage)"}
+        return dict(value=self.total * steps / dt, ms_per_step=dt / steps * 1e3, roofline=roofline,
+                    stage_ms_per_step={k: self.stage_ms[k] / max(steps, 1) for k in self.stage_ms},
+                    accepted_by_closer_thresholds_rank0=accepted, max_translation_error_m_rank0=terr,
+                    counters_mean={"M_current_frame": Mcur, "M_others": float(r["n_current"].mean()) if P else 0.0,
+                                   "K_sum": float(b["Ks"].mean()) if P else 0.0, "C_sum": float(b["Cs"].mean()) if P else 0.0})
+
+    def close(self):
+        self.others = None; self.current = None; self.replica = None
         self.ctx.close()
 
 
@@ -826,6 +1005,16 @@ def chi2_match(traces, res, w=None):
 RECORDS_CRC_FILE = os.path.join(ROOT, "profiles", "records_crc.json")
 
 
+CRC_DIR = os.path.dirname(RECORDS_CRC_FILE)
+
+
+def records_crc_file(mode="pairs", omega_storage="sym6"):
+    """one digest file per (workload, omega storage): the bench default (pairs, sym6) keeps the historical name"""
+    if mode == "pairs" and omega_storage == "sym6":
+        return os.path.join(CRC_DIR, "records_crc.json")
+    return os.path.join(CRC_DIR, "records_crc_%s_%s.json" % (mode, omega_storage))
+
+
 def records_crc(allrec):
     """CRC32 of every assembled 256-byte result record (shard.py: pose, final values, per-iteration traces, counts, pair id), in global pair order"""
     import zlib
@@ -843,17 +1032,20 @@ def kernel_source_digest():
     return h.hexdigest()[:16]
 
 
-def check_records_crc(allrec, rows, cols, write=False, omega_storage="exact9"):
+def check_records_crc(allrec, rows, cols, write=False, omega_storage="exact9", mode="pairs"):
     crc = records_crc(allrec)
     src = kernel_source_digest()
+    fn = records_crc_file(mode, omega_storage)
+    rel = os.path.relpath(fn, ROOT)
     if write:
-        with open(RECORDS_CRC_FILE, "w") as f:
-            json.dump({"made_by": "bench.py --gpus 1 --total-pairs %d --write-records-crc (one MI355X)" % len(crc), "rows": rows, "cols": cols,
+        with open(fn, "w") as f:
+            json.dump({"made_by": "bench.py --gpus 1 --mode %s --omega-storage %s --total-pairs %d --write-records-crc (one MI355X)" % (mode, omega_storage, len(crc)),
+                       "rows": rows, "cols": cols, "mode": mode,
                        "omega_storage": omega_storage, "kernel_source_digest": src, "pairs": len(crc), "crc32": crc}, f)
-    if not os.path.exists(RECORDS_CRC_FILE):
-        return {"checked": 0, "note": "no profiles/records_crc.json"}
+    if not os.path.exists(fn):
+        return {"checked": 0, "note": "no " + rel}
     try:
-        g = json.load(open(RECORDS_CRC_FILE))
+        g = json.load(open(fn))
     except Exception as e:
         return {"checked": 0, "note": "unreadable: %r" % (e,)}
     if (g.get("rows"), g.get("cols")) != (rows, cols):
@@ -863,7 +1055,7 @@ def check_records_crc(allrec, rows, cols, write=False, omega_storage="exact9"):
     n = min(len(crc), g["pairs"])
     bad = [i for i in range(n) if crc[i] != g["crc32"][i]]
     return {"checked": n, "equal": not bad, "first_mismatch": bad[0] if bad else None, "mismatches": len(bad),
-            "file_is_for_these_kernels": g.get("kernel_source_digest") == src, "file": "profiles/records_crc.json",
+            "file_is_for_these_kernels": g.get("kernel_source_digest") == src, "file": rel,
             "note": "records of pair p are the same bits whatever GPU / rank / sub-batch aligned it; a mismatch with a stale file (other kernel sources) means nothing"}
 
 
@@ -884,7 +1076,24 @@ def dry_run_cpu(args, rank, world):
     for i, s in enumerate(seeds):      # what pwn_hip_align_batch would have filled in for pair s
         T = np.eye(4, dtype=np.float32); T[:3, 3] = (s, 2 * s, -s)
         res["T"][i] = T.T.reshape(-1); res["error"][i] = 0.5 * s; res["inliers"][i] = 1000 + s; res["iterations"][i] = 10
-    rec = torch.from_numpy(shard.pack_results_raw(res, seeds))
+    packed = shard.pack_results_raw(res, seeds)
+    flat_ok = None
+    if args.mode == "partition":
+        # the byte path of --mode partition: a flat `current` cloud (here: a seeded byte pattern of a flat cloud's size) broadcast from rank 0,
+        # every rank checks what arrived; the records carry the four score words of PWN_HIP_MATCH_RECORD_FLOATS behind the alignment record
+        nbytes = 256 + 3 * ((P * 4 + 255) // 256 * 256)
+        pattern = (np.arange(nbytes, dtype=np.uint64) * 2654435761 % 251).astype(np.uint8)
+        flat = torch.from_numpy(pattern.copy() if rank == 0 else np.zeros(nbytes, np.uint8))
+        if world > 1:
+            dist.broadcast(flat, src=0)
+        ok = torch.tensor([1.0 if np.array_equal(flat.numpy(), pattern) else 0.0], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        flat_ok = bool(ok.item() == 1.0)
+        packed = np.concatenate([packed, np.zeros((P, 8), np.float32)], axis=1)
+        for i, sd in enumerate(seeds):
+            packed[i, 64:68] = (3000 + sd, sd % 7, 2900 + sd, 0.25 * sd)
+    rec = torch.from_numpy(packed)
     g = shard.gather_records(rec, world, Pmax)
     t = torch.tensor([float(rank)], dtype=torch.float64)
     if world > 1:
@@ -894,12 +1103,73 @@ def dry_run_cpu(args, rank, world):
         allrec = shard.assemble(g.numpy(), total)
         ok = all(allrec[p, 12] == p and allrec[p, 13] == 2 * p and allrec[p, 14] == -p and allrec[p, 17] == 1000 + p and allrec[p, 19] == p
                  for p in range(total))
-        print(json.dumps({"dry_run": True, "n_gpus": world, "records": int(allrec.shape[0]), "records_ok": bool(ok), "max_rank_seen": int(t.item()),
+        if args.mode == "partition":
+            ok = ok and allrec.shape[1] == 72 and all(allrec[p, 64] == 3000 + p and allrec[p, 66] == 2900 + p and allrec[p, 67] == 0.25 * p for p in range(total))
+        print(json.dumps({"dry_run": True, "n_gpus": world, "mode": args.mode, "flat_cloud_broadcast_ok": flat_ok, "records": int(allrec.shape[0]), "records_ok": bool(ok), "max_rank_seen": int(t.item()),
                           "pairs_per_gpu": P, "scaling": "strong" if args.total_pairs > 0 else "weak", "total_pairs": total,
                           "records_crc": records_crc(allrec)[:4], "records_crc_all": int(zlib.crc32(np.asarray(records_crc(allrec), np.uint32).tobytes())),
                           "rank0_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None}))
     if world > 1:
         dist.destroy_process_group()
+
+
+def host_cpu_info():
+    """what the `cores` of cpu_baseline are: logical cpus this process may use, physical cores among them, SMT, the cgroup's cpu quota"""
+    out = {}
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        out["logical_cpus"] = len(cpus)
+        cores = set()
+        for c in cpus:
+            try:
+                with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as f:
+                    cores.add(f.read().strip())
+            except Exception:
+                cores.add(str(c))
+        out["physical_cores"] = len(cores)
+        out["smt"] = len(cores) < len(cpus)
+    except Exception:
+        pass
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+            quota = None if q == "max" else float(q) / float(per)
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            quota = None if q < 0 else q / per
+        except Exception:
+            quota = None
+    out["cgroup_cpu_quota"] = quota
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    out["cpu_model"] = line.split(":", 1)[1].strip(); break
+    except Exception:
+        pass
+    return out
+
+
+def multi_gpu_diagnostics(w, args, rank, world, dt_rank, dt_serial, pinned, n_collective=20):
+    """Per-rank evidence for a scaling run (the builder cannot iterate on 8 GPUs, the line has to explain itself): every rank's own ms per step of
+    the timed region and of the serial profiled pass, its per-stage device times, the cores it was pinned to, and the collectives timed alone."""
+    import torch
+    import torch.distributed as dist
+    keys = sorted(w.stage_ms)
+    mine = [dt_rank / max(args.steps, 1) * 1e3, (dt_serial or 0.0) / max(args.steps, 1) * 1e3,
+            float(len(pinned)) if pinned else 0.0, float(pinned[0]) if pinned else -1.0, float(pinned[-1]) if pinned else -1.0]
+    mine += [w.stage_ms[k] / max(args.steps, 1) for k in keys]
+    t = torch.tensor(mine, dtype=torch.float64, device="cuda")
+    allt = torch.empty((world, len(mine)), dtype=torch.float64, device="cuda")
+    dist.all_gather_into_tensor(allt, t)
+    coll = w.time_collectives(n_collective)
+    a = allt.cpu().numpy()
+    return {"per_rank_ms_per_step": [float(x) for x in a[:, 0]], "per_rank_serial_pass_ms_per_step": [float(x) for x in a[:, 1]],
+            "rank_cpus": [{"count": int(r[2]), "first": int(r[3]), "last": int(r[4])} for r in a],
+            "per_rank_stage_ms_per_step": {k: [float(x) for x in a[:, 5 + i]] for i, k in enumerate(keys)},
+            "collectives_alone": dict(coll, steps=n_collective, note="no compute between the collectives; ms per call, this rank's clock after a device sync")}
 
 
 # ------------------------------------------------------------------------------------------------ main
@@ -919,7 +1189,8 @@ def main():
         return dry_run_cpu(args, rank, world)
     rows, cols, P = args.rows, args.cols, args.pairs
     K, conv, alig = conf(rows, cols)
-    extras_on = rank == 0 and world == 1 and not args.no_extras      # the extra lines are single-GPU measurements
+    partition = args.mode == "partition"
+    extras_on = rank == 0 and world == 1 and not args.no_extras and not partition      # the extra lines are single-GPU measurements of the headline workload
 
     # CPU baseline first (rank 0 at N = 1 only: the other ranks of a multi-GPU run would wait for it), in a child process started
     # before anything touches the GPU: the process that drives the GPU never loads the oracle library
@@ -931,16 +1202,22 @@ def main():
         try:
             cpu = json.loads(out.stdout.strip().splitlines()[-1])
             traces = cpu.pop("chi2_traces", None)
+            cpu.update(host_cpu_info())
         except Exception:
             cpu = {"error": (out.stderr or out.stdout)[-300:]}
 
     # synthetic inputs of this rank's shard (and of the extra lines), rendered on the CPU before the GPU is initialised
     from g2o_frontend_amd import shard, synth
     total = args.total_pairs if args.total_pairs > 0 else world * P      # strong scaling: the same pair list whatever N is; weak: --pairs per rank
+    if total < world:
+        print("bench.py: fewer pairs than ranks", file=sys.stderr); sys.exit(2)
     seeds = list(shard.shard_range(total, rank, world))                  # contiguous shard of the global pair list
     P = len(seeds)
-    jobs = [("pair", s, rows, cols, K) for s in seeds]
     n5 = 0; poses = None
+    if partition:
+        jobs = partition_jobs(seeds, rows, cols, K) + [("frame", PARTITION_SCENE, np.eye(4).tolist(), rows, cols, K, 0)]      # the shard's keyframes + `current`
+    else:
+        jobs = [("pair", s, rows, cols, K) for s in seeds]
     if extras_on and not args.no_config5 and (rows, cols) == (480, 640):
         n5 = 32
         jobs += [("pair", s, 960, 1280, synth.K_1280) for s in range(n5)]
@@ -949,7 +1226,8 @@ def main():
         jobs += [("frame", 9, poses[k].tolist(), 480, 640, synth.K_VGA, k) for k in range(args.tracker_frames)]
     # a pinned rank owns its cores: the pool takes all of them; unpinned ranks share the box (cores // world each)
     rendered = render_all(jobs, 1 if pinned else world, args.render_workers)
-    frames_mm = rendered[:P]; frames5 = rendered[P:P + n5]; frames_trk = rendered[P + n5:]
+    nmain = P + 1 if partition else P
+    frames_mm = rendered[:nmain]; frames5 = rendered[nmain:nmain + n5]; frames_trk = rendered[nmain + n5:]
 
     import torch
     import torch.distributed as dist
@@ -972,28 +1250,43 @@ def main():
             os.close(saved_fd)
     n_seen = dist.get_world_size() if use_dist else 1                            # the ranks the process group actually holds
 
-    w = BatchWorkload(args, local, rows, cols, P, frames_mm, seeds, use_dist, world)
-    w.total = total; w.Pmax = (total + world - 1) // world
-    dt, dt_serial = w.run(args.steps, args.warmup, profile=not args.no_profile)
+    if partition:
+        w = PartitionWorkload(args, local, rows, cols, seeds, frames_mm[:P], frames_mm[P], use_dist, world, rank, total)
+    else:
+        w = BatchWorkload(args, local, rows, cols, P, frames_mm, seeds, use_dist, world)
+        w.total = total; w.Pmax = (total + world - 1) // world
+    dt_rank, dt_serial = w.run(args.steps, args.warmup, profile=not args.no_profile)
+    dt = dt_rank
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     rep = w.report(args.steps, dt, dt_serial, world)
+    # what a sub-linear scaling curve would have to be explained with: every rank's own step time, the collectives alone, the cores each rank ran on
+    multi = multi_gpu_diagnostics(w, args, rank, world, dt_rank, dt_serial, pinned) if use_dist else None
     gather_info = None
     if rank == 0:
         allrec = shard.assemble(w.last["gathered"].cpu().numpy(), total)          # every pair of every rank arrived exactly once
         assert allrec.shape[0] == total
-        mine = shard.pack_results_raw(w.last["res"], seeds)                        # this rank's own records as they left the C-ABI
+        if partition:
+            res, sc = w.last["res"]
+            mine = shard.pack_results_raw(res, seeds)
+            mine = np.concatenate([mine, np.zeros((len(seeds), 8), np.float32)], axis=1)
+            for i, m in enumerate(sc):
+                mine[i, 64:68] = (m.image_non_zeros, m.image_outliers, m.image_inliers, m.image_reprojection_distance)
+        else:
+            mine = shard.pack_results_raw(w.last["res"], seeds)                    # this rank's own records as they left the C-ABI
         gather_info = {"backend": "nccl (RCCL), all_gather_into_tensor on device tensors" if use_dist else "none (one rank: the local records)",
                        "forced": bool(use_dist and world == 1), "world": n_seen, "records": int(allrec.shape[0]), "record_bytes": int(4 * allrec.shape[1]),
                        "records_equal_local": bool(np.array_equal(allrec[np.asarray(seeds)].view(np.uint32), mine.view(np.uint32)))}
         # determinism gate of the multi-GPU leg: a pair's record does not depend on which GPU aligned it, in which sub-batch or next to which
-        # other pairs (tests/test_gpu_properties.py), so the records any N assembles must equal, bit for bit, those of the one-GPU run
-        gather_info["records_vs_single_gpu_run"] = check_records_crc(allrec, rows, cols, write=args.write_records_crc and world == 1, omega_storage=args.omega_storage)
+        # other pairs (tests/test_gpu_properties.py) -- nor, in partition mode, on whether the `current` cloud is the converted original or a replica
+        # that travelled through export / broadcast / import -- so the records any N assembles must equal, bit for bit, those of the one-GPU run
+        gather_info["records_vs_single_gpu_run"] = check_records_crc(allrec, rows, cols, write=args.write_records_crc and world == 1 and not use_dist,
+                                                                     omega_storage=args.omega_storage, mode=args.mode)
 
     extra = {}
-    if not args.no_latency and rank == 0:
+    if not args.no_latency and rank == 0 and world == 1 and not partition:
         lat = []
         for _ in range(5):
             torch.cuda.synchronize(); a = time.perf_counter()
@@ -1002,10 +1295,10 @@ def main():
             lat.append((time.perf_counter() - a) * 1e3)
         extra["single_pair_latency_ms"] = float(np.median(lat))
         w.step()                                                                   # clouds of all pairs resident again
-    if rank == 0 and traces:
+    if rank == 0 and traces and not partition:
         extra["chi2_match"] = chi2_match(traces, w.last["res"], w)
     hbm_read = hbm_copy = None
-    if rank == 0:
+    if rank == 0 and world == 1:      # (at N > 1 the other ranks would wait in the final barrier meanwhile)
         try:      # the bandwidth this box actually delivers, next to the 8 TB/s spec figure (float4 streaming read / copy of 2 GiB)
             hbm_read, hbm_copy = w.ctx.measure_hbm(1 << 31)
         except Exception:
@@ -1016,6 +1309,24 @@ def main():
         except Exception as e:
             extra["extras_error"] = repr(e)[:300]
     w.close()
+    if extras_on and args.omega_storage == "sym6":
+        # the library's default storage (exact9: every converter output bit-identical to the CPU path) on the same pairs, so that the line
+        # carries both modes (the headline runs sym6: lower triangle of Omega_p mirrored, chi2 / H / b within 1e-5)
+        try:
+            a9 = argparse.Namespace(**vars(args)); a9.omega_storage = "exact9"
+            w9 = BatchWorkload(a9, local, rows, cols, P, frames_mm, seeds, False, 1)
+            s9 = max(2, min(args.steps, 5))
+            d9, _ = w9.run(s9, 1, profile=False)
+            r9 = w9.report(s9, d9, None, 1)
+            allrec9 = shard.pack_results_raw(w9.last["res"], seeds)
+            extra["omega_exact9"] = {"alignments_per_s": r9["value"], "ms_per_step": r9["ms_per_step"], "steps": s9, "path_frac": r9["roofline"]["path_frac"],
+                                     "algorithmic_bytes_per_pair": r9["path_roofline"]["algorithmic_bytes_per_pair"],
+                                     "note": "same step with omega_storage = exact9 (36-byte point information matrices, the library default); the byte count "
+                                             "keeps SURVEY.md 8(d)'s 24-byte figure",
+                                     "records_vs_single_gpu_run": check_records_crc(allrec9, rows, cols, omega_storage="exact9", mode="pairs")}
+            w9.close()
+        except Exception as e:
+            extra["omega_exact9_error"] = repr(e)[:300]
     if extras_on and n5:
         try:
             a5 = argparse.Namespace(**vars(args)); a5.sub_frames = min(args.sub_frames, 2 * n5); a5.sub_pairs = min(args.sub_pairs, n5)
@@ -1049,25 +1360,39 @@ def main():
         if "chi2_match" in extra:      # the parity gate travels with the number (flat, so that summaries of the line keep it)
             rep["roofline"]["chi2_max_rel_diff_vs_cpu"] = extra["chi2_match"]["max_rel_diff"]
             rep["roofline"]["chi2_match_ok"] = extra["chi2_match"]["ok"]
+        if partition:
+            workload = (f"PwnCloser::processPartition: one {cols}x{rows} `current` frame (converted per step on rank 0, its cloud broadcast to every GPU) matched "
+                        f"against {P} cached keyframe clouds per GPU (matchClouds: Aligner::align {alig['outer_iterations']}x{alig['inner_iterations']} GN iterations "
+                        f"from an odometry guess + depth-agreement score); SURVEY.md 8(e) partitioning")
+            parallelism = f"cached clouds sharded over {n_seen} GPU(s); RCCL broadcast of the `current` cloud (~17 MB) + all-gather of 288-byte records"
+        else:
+            workload = (f"loop-closure batch: {P} independent {cols}x{rows} depth pairs per GPU "
+                        f"(u16 mm frames resident in HBM; per pair: convert 2 frames + Aligner::align, "
+                        f"{alig['outer_iterations']}x{alig['inner_iterations']} GN iterations); BASELINE configs[3] shard")
+            parallelism = f"independent pairs sharded over {n_seen} GPU(s), RCCL all-gather of result records only"
         out = {
             "metric": "depth-pair alignments/sec (640x480, 10 GN iters)", "value": rep["value"], "unit": "alignments/s",
             "n_gpus": n_seen, "steps": args.steps, "warmup": args.warmup, "ms_per_step": rep["ms_per_step"],
             "higher_is_better": True, "scaling": "strong" if args.total_pairs > 0 else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"loop-closure batch: {P} independent {cols}x{rows} depth pairs per GPU "
-                                   f"(u16 mm frames resident in HBM; per pair: convert 2 frames + Aligner::align, "
-                                   f"{alig['outer_iterations']}x{alig['inner_iterations']} GN iterations); BASELINE configs[3] shard",
+            "config": {"workload": workload, "mode": args.mode,
                        "pairs_per_gpu": P, "total_pairs": total, "rows": rows, "cols": cols, "sub_frames": args.sub_frames, "sub_pairs": args.sub_pairs,
-                       "streams": args.streams, "omega_storage": args.omega_storage, "step_mode": args.step_mode,
-                       "parallelism": f"independent pairs sharded over {n_seen} GPU(s), RCCL all-gather of result records only",
+                       "streams": args.streams, "omega_storage": args.omega_storage, "step_mode": args.step_mode if not partition else None,
+                       "parallelism": parallelism,
                        "cpus_of_rank0": (len(pinned) if pinned else None)},
             "roofline": rep["roofline"],
             "cpu_baseline": cpu,
-            "path_roofline": rep["path_roofline"],
+            "path_roofline": rep.get("path_roofline"),
             "stage_ms_per_step": rep["stage_ms_per_step"],
-            "stage_launches_per_step": rep["stage_launches_per_step"],
+            "stage_launches_per_step": rep.get("stage_launches_per_step"),
             "counters_mean": rep["counters_mean"],
             "gather": gather_info,
+            "multi_gpu": multi,
         }
+        if partition:
+            out["partition"] = {"accepted_by_closer_thresholds_rank0": rep["accepted_by_closer_thresholds_rank0"], "keyframes_rank0": P,
+                                "max_translation_error_m_rank0": rep["max_translation_error_m_rank0"],
+                                "flat_cloud_bytes": int(w.flat_bytes) if use_dist else None, "broadcast_buffer_bytes": int(w.flat.numel()),
+                                "replica_roundtrip_on_rank0": bool(w.roundtrip)}
         out.update(extra)
         print(json.dumps(out))
     if use_dist:

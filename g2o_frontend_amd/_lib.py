@@ -70,6 +70,7 @@ PROTOTYPES = {
     "pwn_hip_ctx_destroy": (_I, [_VP]),
     "pwn_hip_ctx_set_stream": (_I, [_VP, _VP]),
     "pwn_hip_ctx_synchronize": (_I, [_VP]),
+    "pwn_hip_ctx_wait_stream": (_I, [_VP, _VP]),
     "pwn_hip_ctx_set_subbatch": (_I, [_VP, _I, _I]),
     "pwn_hip_ctx_set_concurrency": (_I, [_VP, _I]),
     "pwn_hip_ctx_set_omega_storage": (_I, [_VP, _I]),
@@ -91,6 +92,9 @@ PROTOTYPES = {
     "pwn_hip_cloud_download": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "pwn_hip_cloud_download_stats": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "pwn_hip_cloud_transform_in_place": (_I, [_VP, _VP, _VP]),
+    "pwn_hip_cloud_export_bound": (C.c_size_t, [_I, _I, _I, _I]),
+    "pwn_hip_cloud_export": (_I, [_VP, _VP, _VP, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "pwn_hip_cloud_import": (_I, [_VP, _VP, _VP, C.c_size_t]),
     "pwn_hip_depth_u16_to_f32": (_I, [_VP, _VP, _VP, _I, _F]),
     "pwn_hip_depth_f32_to_u16": (_I, [_VP, _VP, _VP, _I, _F]),
     "pwn_hip_depth_scale": (_I, [_VP, _VP, _I, _I, _I, _F, _VP]),
@@ -117,6 +121,7 @@ PROTOTYPES = {
     "pwn_hip_compute_statistics": (None, [_VP, _VP, _VP, _VP, _VP, _VP]),
     "pwn_hip_match_score": (_I, [_VP, _F, _VP]),
     "pwn_hip_match_batch": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _F, _VP, _VP]),
+    "pwn_hip_match_batch_records": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _F, _VP, _I, _VP, _VP, _VP]),
     "pwn_hip_projector_matrices": (None, [_VP, _VP, _VP, _VP, _VP]),
     "pwn_hip_iso_inverse": (None, [_VP, _VP]),
     "pwn_hip_iso_mul": (None, [_VP, _VP, _VP]),

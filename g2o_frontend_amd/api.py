@@ -116,6 +116,34 @@ def pinned_free(a):
     return None
 
 
+def _nbytes(x) -> int:
+    if hasattr(x, "data_ptr"):
+        return int(x.numel() * x.element_size())
+    return int(x.nbytes)
+
+
+def _check_records(records, n, floats, ctx=None):
+    """A records buffer the library writes n * floats float32 words into (k_pack_records on the device, or a copy to the host): anything
+    smaller, of another type, non-contiguous or on another device would be written out of bounds."""
+    if records is None:
+        return
+    if hasattr(records, "data_ptr"):
+        import torch
+        if records.dtype != torch.float32 or not records.is_contiguous():
+            raise ValueError("records must be a contiguous float32 tensor")
+        if records.numel() < n * floats:
+            raise ValueError(f"records holds {records.numel()} floats, {n} x {floats} are written")
+        if records.is_cuda and ctx is not None and records.device.index not in (None, ctx.device):
+            raise ValueError(f"records lives on cuda:{records.device.index}, the context on device {ctx.device}")
+    elif isinstance(records, np.ndarray):
+        if records.dtype != np.float32 or not records.flags["C_CONTIGUOUS"] or not records.flags["WRITEABLE"]:
+            raise ValueError("records must be a writable C-contiguous float32 array")
+        if records.size < n * floats:
+            raise ValueError(f"records holds {records.size} floats, {n} x {floats} are written")
+    else:
+        raise TypeError(type(records))
+
+
 def _colmajor(M, n):
     return np.ascontiguousarray(np.asarray(M, dtype=np.float32).reshape(n, n).T.reshape(-1))
 
@@ -138,6 +166,8 @@ assert ALIGN_RESULT_DTYPE.itemsize == C.sizeof(AlignResult)
 
 
 OMEGA_STORAGE = {"exact9": 0, "sym6": 1}      # PWN_HIP_OMEGA_EXACT9 / PWN_HIP_OMEGA_SYM6
+RECORD_FLOATS = 64                            # PWN_HIP_RECORD_FLOATS
+MATCH_RECORD_FLOATS = 72                      # PWN_HIP_MATCH_RECORD_FLOATS
 
 
 def device_count() -> int:
@@ -155,6 +185,7 @@ class Context:
         if rc:
             raise PwnHipError(rc, self._L.pwn_hip_last_error_string(None).decode())
         self.h = h
+        self.device = int(device)
         self.max_rows, self.max_cols, self.max_batch = max_rows, max_cols, max_batch
         self.omega_storage = "exact9"
         if omega_storage != "exact9":
@@ -195,6 +226,19 @@ class Context:
     def upload(self, array):
         """DeviceBuffer holding a copy of a host array (pwn_hip_device_alloc + pwn_hip_copy): a frame resident in HBM without torch"""
         return DeviceBuffer(self, array)
+
+    def wait_stream(self, stream=None):
+        """pwn_hip_ctx_wait_stream: what the context queues from now on runs after the work the caller's stream holds now.  stream: a raw
+        hipStream_t value, a torch.cuda.Stream, or None = torch's current stream (the legacy default stream without torch)."""
+        if stream is None:
+            try:
+                import torch
+                stream = torch.cuda.current_stream().cuda_stream
+            except Exception:
+                stream = 0
+        elif hasattr(stream, "cuda_stream"):
+            stream = stream.cuda_stream
+        self.check(self._L.pwn_hip_ctx_wait_stream(self.h, C.c_void_p(int(stream) or None)))
 
     def synchronize(self):
         self.check(self._L.pwn_hip_ctx_synchronize(self.h))
@@ -286,6 +330,27 @@ class Cloud:
             self.ctx.check(self.ctx._L.pwn_hip_cloud_download_stats(self.ctx.h, self.h, _ptr(out["stats"]),
                                                                     _ptr(out["eigenvalues"]), _ptr(out["npoints"])))
         return out
+
+    # ---- the cloud as one flat buffer (replication to other GPUs: include/pwn_hip.h, pwn_hip_cloud_export) ----
+    @staticmethod
+    def flatBound(capacity: int, omega_storage: str = "exact9", index_pixels: int = 0, with_omega_n: bool = False) -> int:
+        """bytes of a flat buffer that holds any cloud of this capacity"""
+        return int(_lib.lib().pwn_hip_cloud_export_bound(int(capacity), OMEGA_STORAGE[omega_storage], int(index_pixels), 1 if with_omega_n else 0))
+
+    def flatSize(self) -> int:
+        w = C.c_size_t(0)
+        self.ctx.check(self.ctx._L.pwn_hip_cloud_export(self.ctx.h, self.h, None, 0, C.byref(w)))
+        return int(w.value)
+
+    def exportFlat(self, buffer) -> int:
+        """pwn_hip_cloud_export into `buffer` (uint8 numpy array or CUDA tensor, >= flatSize() bytes); returns the bytes used"""
+        w = C.c_size_t(0)
+        self.ctx.check(self.ctx._L.pwn_hip_cloud_export(self.ctx.h, self.h, _ptr(buffer), _nbytes(buffer), C.byref(w)))
+        return int(w.value)
+
+    def importFlat(self, buffer):
+        """pwn_hip_cloud_import: this cloud becomes the cloud `buffer` was exported from (same omega storage, capacity >= its points)"""
+        self.ctx.check(self.ctx._L.pwn_hip_cloud_import(self.ctx.h, self.h, _ptr(buffer), _nbytes(buffer)))
 
     def transformInPlace(self, T):
         """pwn_core/cloud.cpp:173-186"""
@@ -774,6 +839,9 @@ class Aligner:
         if initialGuesses is not None:
             g = np.ascontiguousarray(np.stack([_colmajor(self._iso(T), 4) for T in initialGuesses]), np.float32)
         ids = None if pair_ids is None else np.ascontiguousarray(pair_ids, np.int32)
+        _check_records(records, n, RECORD_FLOATS, self.ctx)
+        if ids is not None and ids.size < n:
+            raise ValueError("pair_ids shorter than the batch")
         self.ctx.check(self.ctx._L.pwn_hip_align_batch_records(self.ctx.h, C.byref(p), n, refs, curs, _ptr(g), _ptr(ids), int(first_pair_id), res, _ptr(records)))
         return np.frombuffer(res, dtype=ALIGN_RESULT_DTYPE, count=n) if want_results else None
 
@@ -791,6 +859,9 @@ class Aligner:
         if initialGuesses is not None:
             g = np.ascontiguousarray(np.stack([_colmajor(self._iso(T), 4) for T in initialGuesses]), np.float32)
         ids = None if pair_ids is None else np.ascontiguousarray(pair_ids, np.int32)
+        _check_records(records, n, RECORD_FLOATS, self.ctx)
+        if ids is not None and ids.size < n:
+            raise ValueError("pair_ids shorter than the batch")
         self.ctx.check(self.ctx._L.pwn_hip_convert_align_batch_u16(self.ctx.h, C.byref(cp), C.byref(p), n, rf, cf, raw_scale, rows, cols, refs, curs, _ptr(g),
                                                                    _ptr(ids), int(first_pair_id), res, _ptr(records)))
         return np.frombuffer(res, dtype=ALIGN_RESULT_DTYPE, count=n) if want_results else None
@@ -937,6 +1008,37 @@ class PwnMatcherBase:
         g = np.ascontiguousarray(np.stack(gl), np.float32)
         a.ctx.check(a.ctx._L.pwn_hip_match_batch(a.ctx.h, C.byref(p), n, refs, curs, _ptr(g), self._frameInlierDepthThreshold, res, sc))
         return [self._result(Aligner._unpack(r), m) for r, m in zip(res, sc)]
+
+    def matchHandles(self, fromClouds, toClouds, initialGuesses=None):
+        """handle arrays + the guesses as matchClouds conditions them (z translation zeroed, pwn_matcher_base.cpp:114) for
+        matchCloudsBatchRecords(..., prepared=...)"""
+        n = len(fromClouds)
+        gl = []
+        for i in range(n):
+            ig = np.asarray(np.eye(4) if initialGuesses is None else initialGuesses[i], np.float64).astype(np.float32)
+            ig[2, 3] = 0; ig[3] = (0, 0, 0, 1)
+            gl.append(_colmajor(ig, 4))
+        g = np.ascontiguousarray(np.stack(gl), np.float32) if n else np.zeros((0, 16), np.float32)
+        return ((C.c_void_p * n)(*[c.h for c in fromClouds]), (C.c_void_p * n)(*[c.h for c in toClouds]), g, n)
+
+    def matchCloudsBatchRecords(self, fromClouds, toClouds, fromOffset, toOffset, toCameraMatrix, toRows, toCols, records, initialGuesses=None,
+                                pair_ids=None, first_pair_id=0, want_results=True, prepared=None):
+        """matchCloudsBatch whose results (also) leave as MATCH_RECORD_FLOATS-float records written on the device (pwn_hip_match_batch_records):
+        what the ranks of a sharded PwnCloser::processPartition exchange.  records: float32 [n, 72] CUDA tensor or numpy array.  Returns
+        (align results as a structured array, scores as a MatchResult array) or None."""
+        a = self._aligner
+        self._configure(fromOffset, toOffset, toCameraMatrix, toRows, toCols, None)
+        p = a.params()
+        refs, curs, g, n = prepared if prepared is not None else self.matchHandles(fromClouds, toClouds, initialGuesses)
+        _check_records(records, n, MATCH_RECORD_FLOATS, a.ctx)
+        ids = None if pair_ids is None else np.ascontiguousarray(pair_ids, np.int32)
+        if ids is not None and ids.size < n:
+            raise ValueError("pair_ids shorter than the batch")
+        res = (AlignResult * n)() if want_results else None
+        sc = (MatchResult * n)() if want_results else None
+        a.ctx.check(a.ctx._L.pwn_hip_match_batch_records(a.ctx.h, C.byref(p), n, refs, curs, _ptr(g), self._frameInlierDepthThreshold, _ptr(ids),
+                                                         int(first_pair_id), res, sc, _ptr(records)))
+        return (np.frombuffer(res, dtype=ALIGN_RESULT_DTYPE, count=n), sc) if want_results else None
 
 
 class PwnCloserAcceptance:

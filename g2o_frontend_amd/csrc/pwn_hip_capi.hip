@@ -77,6 +77,7 @@ struct pwn_hip_ctx {
   hipStream_t copy_stream = nullptr;       // host frames of a batch call are copied on their own stream, one sub-batch ahead of the kernels
   std::vector<hipEvent_t> sync_events;     // ordering events of that hand-over (copied[k], converted[k]); grown on demand
   hipEvent_t copy_ev = nullptr;            // pwn_hip_copy_async: the next call that reads frames waits for the copies issued so far
+  hipEvent_t foreign_ev = nullptr;         // pwn_hip_ctx_wait_stream: marks the caller's stream
   bool copy_pending = false;
   int max_rows = 0, max_cols = 0, max_batch = 0;
   int num_cus = 256;                       // compute units of the device (hipDeviceAttributeMultiprocessorCount)
@@ -89,12 +90,7 @@ struct pwn_hip_ctx {
   uint16_t* raw_ws = nullptr;
   unsigned long long* carry_ws = nullptr; size_t carry_slot = 0; size_t rowoff_slot = 0;   // single-pass integral image: hand-over words, strip offsets
   unsigned convert_epoch = 0; int* fault_dev = nullptr;
-  unsigned long long* fsync_ws = nullptr; size_t fsync_slot = 0;      // k_convert_fused: progress words of a frame slot (FrameDesc::fsync)
-  int last_convert_fault = 0;              // fault word of the last converter launch (1 = a bounded poll timed out, 2 = workgroup placement)
-  int fused_convert = 0;                   // PWN_FUSED_CONVERT=1: k_convert_fused (planes in a ring, never in HBM) for launches of >= PWN_SINGLE_PASS_MIN_FRAMES
-                                           // frames in lean mode.  Bit-identical to the two-kernel path and SLOWER on MI355X (6.0 against 3.4 ms per 256 VGA
-                                           // frames: see k_convert_fused), so it is off unless asked for; switched off for the context when a launch
-                                           // reports that its workgroups were not placed as the kernel needs
+  int last_convert_fault = 0;              // fault word of the last converter launch of the CURRENT call (1 = a bounded poll timed out); reset when a call starts
   int spin_limit = kSpinLimit; int dbg_withhold = -1;        // pwn_hip_debug_withhold_carry (test hook)
   int dbg_withhold_once = 0;                                 // the hook switches itself off after the first launch that timed out
   int convert_retries = 0;                                   // conversions repeated after a hand-over time-out (pwn_hip_debug_convert_retries)
@@ -172,11 +168,9 @@ void launch_corr_linearize(const pwn_hip_ctx* ctx, int sym, int nb, int m, hipSt
 }
 
 // projection of one cloud of each of the m pairs (which: 0 = reference, 1 = current): four points per thread when the launch is large
+constexpr int kProjectPPT = 4;
 void launch_project(int capacity, int m, hipStream_t st, const PairDesc* pr, const AlignParams& ap, int which, unsigned tag) {
-#ifndef PWN_PROJECT_PPT
-#define PWN_PROJECT_PPT 4
-#endif
-  if (m >= 8) hipLaunchKernelGGL((k_project<PWN_PROJECT_PPT>), dim3((capacity + 256 * PWN_PROJECT_PPT - 1) / (256 * PWN_PROJECT_PPT), m), dim3(256), 0, st, pr, ap, which, tag);
+  if (m >= 8) hipLaunchKernelGGL((k_project<kProjectPPT>), dim3((capacity + 256 * kProjectPPT - 1) / (256 * kProjectPPT), m), dim3(256), 0, st, pr, ap, which, tag);
   else hipLaunchKernelGGL((k_project<1>), dim3((capacity + 255) / 256, m), dim3(256), 0, st, pr, ap, which, tag);
 }
 
@@ -234,7 +228,7 @@ StreamPlan make_plan(pwn_hip_ctx* ctx, int want_sub, int n) {
   // works: the short dependent kernels of one sub-batch (projection, 6x6 step) fill the gaps of the other's large ones.  Measured on MI355X
   // (one-submission step, two streams): 64 VGA pairs as 2 x 32 instead of 1 x 64: 11 340 -> 12 170 alignments/s; 32 pairs as 2 x 16: 10 620 ->
   // 11 440; 32 pairs of 1280x960 as 2 x 16: 2 900 -> 3 090 (docs/experiments.md, round 4).  A call is only cut when every part keeps at least 16
-  // items (the converter's single-pass kernels start there: PWN_SINGLE_PASS_MIN_FRAMES); smaller calls stay one launch sequence.
+  // items (the converter's single-pass kernels start there: kSinglePassMinFrames); smaller calls stay one launch sequence.
   if (ctx->stream == ctx->own_stream && ctx->stream2 && ctx->concurrency >= 2) {
     const int kmax = std::min(std::min(ctx->concurrency, 4), (!ctx->extra[0] ? 2 : (!ctx->extra[1] ? 3 : 4)));
     for (int k = kmax; k >= 2; --k) {      // as many streams as leave every part 16 items
@@ -443,14 +437,12 @@ int ensure_desc(pwn_hip_ctx* ctx, int n) {
 
 // launch sequence of the converter for the frames [base, base+n) of the uploaded descriptor array
 // fault_out: page-locked host word for the launch's time-out flag (latency path only; nullptr = the caller copies ctx->fault_dev itself)
+// launches of at least this many frames take the single-pass strip kernel; measured on MI355X at VGA, three kernels vs single pass: 8 frames 0.20 vs
+// 0.27 ms, 16 frames 0.38 vs 0.35, 32 frames 0.74 vs 0.58
+constexpr int kSinglePassMinFrames = 16;
 int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, hipStream_t st, int* fault_out = nullptr) {
-#ifndef PWN_SINGLE_PASS_MIN_FRAMES
-#define PWN_SINGLE_PASS_MIN_FRAMES 16     // measured on MI355X at VGA (tools/ab_convert_n.py), three kernels vs single pass: 8 frames 0.20 vs 0.27 ms, 16 frames 0.38 vs 0.35, 32 frames 0.74 vs 0.58
-#endif
-  // the fused kernel serves the lean mode (no interval image, no point stores by the front end); the planes are never complete in memory
-  const bool use_fused = ctx->fused_convert && cp.lean && n >= PWN_SINGLE_PASS_MIN_FRAMES;
   const FrameDesc* fr = ctx->frames_dev + base;
-  if (n >= PWN_SINGLE_PASS_MIN_FRAMES) {
+  if (n >= kSinglePassMinFrames) {
     // throughput path: the integral planes are written once; a frame is a chain of strips * bands hand-over steps, so it
     // needs several frames in flight to fill the device
     { StageTimer t(ctx, "unproject", st);          // ordered compaction: valid pixels per (row, strip) and their offsets
@@ -465,16 +457,6 @@ int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, h
       else if (aligned) hipLaunchKernelGGL(k_strip_count<false>, dim3((cp.rows + 3) / 4, n), dim3(256), 0, st, fr, cp);
       else hipLaunchKernelGGL(k_strip_count_any, dim3(cp.rows, n), dim3(256), 0, st, fr, cp);
       hipLaunchKernelGGL(k_row_offsets, dim3(n), dim3(1024), 0, st, fr, cp.rows * strips_of(cp.cols)); }
-    if (use_fused) {
-      // one launch for the rest of the converter: producers (front end) and consumers (stats pass) of a frame side by side, planes in a ring
-      StageTimer t(ctx, "convert_fused", st);
-      const unsigned epoch = ++ctx->convert_epoch;
-      if (epoch == 0) return fail(ctx, PWN_HIP_ERR_LAUNCH, "convert epoch wrapped: recreate the context");
-      hipLaunchKernelGGL(k_convert_fused, dim3(8u * (unsigned)((n + 7) / 8) * (unsigned)(1 + kConsWG) * (unsigned)strips_of(cp.cols)), dim3(kII_Threads), 0, st, fr, cp, n,
-                         epoch, ctx->fault_dev);
-      HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
-      return PWN_HIP_OK;
-    }
     { StageTimer t(ctx, "integral", st);           // unProject + intervals + the three integral-image passes
       const unsigned epoch = ++ctx->convert_epoch;
       if (epoch == 0) return fail(ctx, PWN_HIP_ERR_LAUNCH, "convert epoch wrapped: recreate the context");
@@ -497,12 +479,7 @@ int launch_convert(pwn_hip_ctx* ctx, const ConvertParams& cp, int base, int n, h
   { StageTimer t(ctx, "stats", st);
     const unsigned perFrame = (unsigned)cp.rows * (unsigned)((cp.cols + 255) / 256);
     const unsigned nblk = (n >= 8 ? 8u * (unsigned)((n + 7) / 8) : (unsigned)n) * perFrame;      // see k_stats: XCD-aware placement from 8 frames on
-#ifndef PWN_STATS_LDS
-#define PWN_STATS_LDS 0
-#endif
-    // PWN_STATS_LDS: a dynamic-LDS request that only limits the resident blocks per CU, so that the rows in flight on an XCD
-    // (plus the 2*radius halo) fit its 4 MiB L2
-    hipLaunchKernelGGL(k_stats, dim3(nblk), dim3(256), PWN_STATS_LDS, st, fr, cp, n); }
+    hipLaunchKernelGGL(k_stats, dim3(nblk), dim3(256), 0, st, fr, cp, n); }
   HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
   return PWN_HIP_OK;
 }
@@ -515,7 +492,6 @@ void fill_frame(pwn_hip_ctx* ctx, int entry, int slot, const float* depth_dev, c
   (void)rows;
   f.rowoff = ctx->rowoff_ws + (size_t)slot * ctx->rowoff_slot;
   f.carry = ctx->carry_ws + (size_t)slot * ctx->carry_slot;
-  f.fsync = ctx->fsync_ws + (size_t)slot * ctx->fsync_slot;
   f.cloud = cl;
   f.count_out = nullptr;
 }
@@ -545,7 +521,6 @@ int counts_apply(pwn_hip_ctx* ctx, pwn_hip_cloud* const* clouds, int n) {
     (void)hipMemset(ctx->fault_dev, 0, sizeof(int));
     ctx->last_convert_fault = code;
     if (ctx->dbg_withhold_once) { ctx->dbg_withhold = -1; ctx->spin_limit = kSpinLimit; ctx->dbg_withhold_once = 0; }
-    if (code & 2) return fail(ctx, PWN_HIP_ERR_LAUNCH, "fused converter: the workgroups of a frame were not placed on one XCD (results invalid)");
     return fail(ctx, PWN_HIP_ERR_LAUNCH, "integral image: strip hand-over timed out (results invalid)");
   }
   ctx->last_convert_fault = 0;
@@ -573,11 +548,9 @@ template <typename SRC>
 int convert_prepare(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const SRC* const* frames, float depth_scale, int n, int rows, int cols,
                     pwn_hip_cloud* const* clouds, int keep_stats, bool want_interval, const std::vector<int>& slot, bool direct, ConvertJob& job) {
   const size_t N = (size_t)rows * cols;
-#ifndef PWN_LEAN
-#define PWN_LEAN 1      // 0: the front end always stores points and intervals (A/B experiments)
-#endif
+  ctx->last_convert_fault = 0;            // the fault word belongs to this call from here on (a stale 1 would make an unrelated failure look like a time-out)
   ConvertParams cp = make_convert_params(ctx, p, nullptr, rows, cols, keep_stats);
-  cp.lean = (PWN_LEAN && !want_interval) ? 1 : 0;      // the interval image leaves the converter only through pwn_hip_convert(..., interval_image)
+  cp.lean = want_interval ? 0 : 1;      // the interval image leaves the converter only through pwn_hip_convert(..., interval_image)
   if (int rc = ensure_desc(ctx, n)) return rc;
   const bool raw = std::is_same<SRC, uint16_t>::value;
   job.n = n; job.rows = rows; job.cols = cols; job.N = N; job.raw = raw; job.depth_scale = depth_scale; job.slot = slot; job.direct = direct;
@@ -657,7 +630,7 @@ int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, cons
   const int sub = plan.sub;
   std::vector<int> slot((size_t)std::max(n, 0));
   for (int i = 0; i < n; ++i) slot[i] = plan.slot0(i / sub) + i % sub;
-  const bool direct = n > 0 && n < PWN_SINGLE_PASS_MIN_FRAMES && n <= sub;
+  const bool direct = n > 0 && n < kSinglePassMinFrames && n <= sub;
   ConvertJob job;
   if (int rc = convert_prepare<SRC>(ctx, p, frames, depth_scale, n, rows, cols, clouds, keep_stats, want_interval, slot, direct, job)) return rc;
   if (int rc = plan_fork(ctx, plan)) return rc;
@@ -698,12 +671,6 @@ int convert_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, cons
     // the call is simply made again, once; a second time-out is reported.
     ++ctx->convert_retries;
     return convert_batch_impl<SRC>(ctx, p, frames, depth_scale, n, rows, cols, clouds, keep_stats, want_interval, true);
-  }
-  if (rc != PWN_HIP_OK && (ctx->last_convert_fault & 2) && ctx->fused_convert) {
-    // the fused kernel found its workgroups on different XCDs (the round-robin placement it is built on did not hold on this device /
-    // partition mode): never use it again on this context and convert the batch again with the two-kernel path
-    ctx->fused_convert = 0;
-    return convert_batch_impl<SRC>(ctx, p, frames, depth_scale, n, rows, cols, clouds, keep_stats, want_interval, retried);
   }
   return rc;
 }
@@ -812,7 +779,6 @@ int pwn_hip_ctx_create(pwn_hip_ctx** out, int device, int max_rows, int max_cols
   pwn_hip_ctx* ctx = new pwn_hip_ctx();
   ctx->device = device; ctx->max_rows = max_rows; ctx->max_cols = max_cols; ctx->max_batch = max_batch;
   ctx->N = (size_t)max_rows * max_cols;
-  if (const char* e = std::getenv("PWN_FUSED_CONVERT")) ctx->fused_convert = std::atoi(e);          // 1 = k_convert_fused instead of k_unproject_integral + k_stats
   { int cus = 0; if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->num_cus = cus; }
   const size_t N = ctx->N, B = (size_t)max_batch;
   ctx->nblocks_max = align_nblocks((int)N);
@@ -825,6 +791,7 @@ int pwn_hip_ctx_create(pwn_hip_ctx** out, int device, int max_rows, int max_cols
   (void)hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming); (void)hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming);
   (void)hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
   (void)hipEventCreateWithFlags(&ctx->copy_ev, hipEventDisableTiming);
+  (void)hipEventCreateWithFlags(&ctx->foreign_ev, hipEventDisableTiming);
   ALLOC(ctx->depth_ws, B * N * sizeof(float));
   ALLOC(ctx->raw_ws, B * N * sizeof(uint16_t));
   ALLOC(ctx->index_ws, B * N * sizeof(int));
@@ -834,14 +801,11 @@ int pwn_hip_ctx_create(pwn_hip_ctx** out, int device, int max_rows, int max_cols
     const size_t M = (size_t)std::max(max_rows, max_cols);
     ctx->rowoff_slot = N / 64 + M + 64;
     ctx->carry_slot = (N / ((size_t)kIR_Cols * kIR_Rows) + M / kIR_Cols + M / kIR_Rows + 2) * (size_t)kII_Chains;
-    ctx->fsync_slot = (1 + 4 * kConsWG) * (M / kIR_Cols + 1) + 2;      // prod[strips], cons[strips][4 kConsWG], XCC id
   }
   ALLOC(ctx->rowoff_ws, B * ctx->rowoff_slot * sizeof(int));
   ALLOC(ctx->carry_ws, B * ctx->carry_slot * sizeof(unsigned long long));
   ALLOC(ctx->fault_dev, sizeof(int));
-  ALLOC(ctx->fsync_ws, B * ctx->fsync_slot * sizeof(unsigned long long));
-  if (hipMemset(ctx->carry_ws, 0, B * ctx->carry_slot * sizeof(unsigned long long)) != hipSuccess || hipMemset(ctx->fault_dev, 0, sizeof(int)) != hipSuccess ||
-      hipMemset(ctx->fsync_ws, 0, B * ctx->fsync_slot * sizeof(unsigned long long)) != hipSuccess) {
+  if (hipMemset(ctx->carry_ws, 0, B * ctx->carry_slot * sizeof(unsigned long long)) != hipSuccess || hipMemset(ctx->fault_dev, 0, sizeof(int)) != hipSuccess) {
     pwn_hip_ctx_destroy(ctx); return fail(nullptr, PWN_HIP_ERR_ALLOCATION, "hipMemset of the hand-over workspace failed"); }
   ALLOC(ctx->zref_ws, N * sizeof(unsigned long long));
   ALLOC(ctx->z32ref_ws, B * N * sizeof(unsigned));
@@ -872,7 +836,7 @@ int pwn_hip_ctx_destroy(pwn_hip_ctx* ctx) {
   }
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);      // pwn_hip_copy_async transfers still in flight
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
-  void* dev[] = { ctx->depth_ws, ctx->raw_ws, ctx->index_ws, ctx->interval_ws, ctx->integral_ws, ctx->rowoff_ws, ctx->carry_ws, ctx->fsync_ws, ctx->fault_dev, ctx->zref_ws, ctx->z32ref_ws, ctx->z32cur_ws, ctx->curidx_ws,
+  void* dev[] = { ctx->depth_ws, ctx->raw_ws, ctx->index_ws, ctx->interval_ws, ctx->integral_ws, ctx->rowoff_ws, ctx->carry_ws, ctx->fault_dev, ctx->zref_ws, ctx->z32ref_ws, ctx->z32cur_ws, ctx->curidx_ws,
                   ctx->partials_ws, ctx->state_ws, ctx->frames_dev, ctx->pairs_dev, ctx->raw_dev, ctx->counts_dev, ctx->solve_dev, ctx->counters_dev,
                   ctx->corr_ws, ctx->scratch_count, ctx->io_ws };
   for (void* p : dev) if (p) (void)hipFree(p);
@@ -897,6 +861,7 @@ int pwn_hip_ctx_destroy(pwn_hip_ctx* ctx) {
   for (int k = 0; k < 2; ++k) { if (ctx->extra[k]) (void)hipStreamDestroy(ctx->extra[k]); if (ctx->join_extra[k]) (void)hipEventDestroy(ctx->join_extra[k]); }
   if (ctx->copy_stream) { (void)hipStreamSynchronize(ctx->copy_stream); (void)hipStreamDestroy(ctx->copy_stream); }
   if (ctx->copy_ev) (void)hipEventDestroy(ctx->copy_ev);
+  if (ctx->foreign_ev) (void)hipEventDestroy(ctx->foreign_ev);
   for (hipEvent_t e : ctx->sync_events) (void)hipEventDestroy(e);
   ctx->sync_events.clear();
   if (ctx->fork_ev) (void)hipEventDestroy(ctx->fork_ev);
@@ -908,6 +873,15 @@ int pwn_hip_ctx_set_stream(pwn_hip_ctx* ctx, void* hip_stream) {
   if (!ctx) return fail(nullptr, PWN_HIP_ERR_INVALID_ARGUMENT, "null ctx");
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
   ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+  return PWN_HIP_OK;
+}
+int pwn_hip_ctx_wait_stream(pwn_hip_ctx* ctx, void* hip_stream) {
+  if (!ctx) return fail(nullptr, PWN_HIP_ERR_INVALID_ARGUMENT, "null ctx");
+  if (!ctx->foreign_ev) return fail(ctx, PWN_HIP_ERR_ALLOCATION, "no event");
+  HIPCHK(ctx, hipSetDevice(ctx->device), PWN_HIP_ERR_NO_DEVICE);
+  // everything the context queues from now on (its other streams fork from ctx->stream) runs after what the caller's stream holds now
+  HIPCHK(ctx, hipEventRecord(ctx->foreign_ev, (hipStream_t)hip_stream), PWN_HIP_ERR_LAUNCH);
+  HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->foreign_ev, 0), PWN_HIP_ERR_LAUNCH);
   return PWN_HIP_OK;
 }
 int pwn_hip_ctx_synchronize(pwn_hip_ctx* ctx) {
@@ -1201,6 +1175,117 @@ int pwn_hip_cloud_transform_in_place(pwn_hip_ctx* ctx, pwn_hip_cloud* c, const f
   return PWN_HIP_OK;
 }
 
+// ---- a cloud as ONE flat buffer (replication of a cloud to the other GPUs of a node: PwnCloser::processPartition matches one `current` cloud
+// against every cloud of the other partition, pwn_tracker/pwn_closer.cpp:85-111; SURVEY.md 8(e): "replicate current's cloud to all GPUs") ----
+namespace {
+struct CloudFlatHeader {            // 256 bytes; sections start at multiples of 256 bytes
+  uint32_t magic, version;
+  int32_t n, omSym, hasOmN, idxValid, idxRows, idxCols;
+  float clsThr, idxMinD, idxMaxD;
+  float omN[2][9];
+  float idxK[9];
+  uint64_t offP3, offNc, offOm, offOmN, offIdx, total;
+  unsigned char pad[256 - (8 * 4 + 3 * 4 + 18 * 4 + 9 * 4 + 6 * 8)];
+};
+static_assert(sizeof(CloudFlatHeader) == 256, "flat cloud header");
+constexpr uint32_t kFlatMagic = 0x464E5750u;      // "PWNF"
+size_t up256(size_t b) { return (b + 255) & ~(size_t)255; }
+// section offsets for n points (plane stride inside the flat buffer = n points, not the cloud's capacity)
+void flat_layout(CloudFlatHeader& h, size_t n, int omSym, bool omN, size_t idxPixels) {
+  size_t o = sizeof(CloudFlatHeader);
+  h.offP3 = o; o += up256(n * 12);
+  h.offNc = o; o += up256(n * 16);
+  h.offOm = o; o += (size_t)om_planes(omSym) * up256(n * 12);
+  h.offOmN = o; if (omN) o += 3 * up256(n * 12);
+  h.offIdx = o; o += up256(idxPixels * 4);
+  h.total = o;
+}
+}  // namespace
+size_t pwn_hip_cloud_export_bound(int capacity, int omega_storage, int index_pixels, int with_omega_n) {
+  if (capacity < 0 || index_pixels < 0) return 0;
+  CloudFlatHeader h;
+  flat_layout(h, (size_t)capacity, omega_storage == PWN_HIP_OMEGA_SYM6 ? 1 : 0, with_omega_n != 0, (size_t)index_pixels);
+  return (size_t)h.total;
+}
+int pwn_hip_cloud_export(pwn_hip_ctx* ctx, const pwn_hip_cloud* c, void* dst, size_t dst_bytes, size_t* written) {
+  if (!ctx || !c || (!dst && !written)) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  HIPCHK(ctx, hipSetDevice(ctx->device), PWN_HIP_ERR_NO_DEVICE);
+  const size_t n = (size_t)std::min(c->n_host, c->d.capacity), cap = (size_t)c->d.capacity;
+  CloudFlatHeader h; std::memset(&h, 0, sizeof(h));
+  h.magic = kFlatMagic; h.version = 1; h.n = (int32_t)n; h.omSym = c->d.omSym; h.hasOmN = c->d.OmN ? 1 : 0;
+  h.clsThr = c->d.clsThr; std::memcpy(h.omN, c->d.omN, sizeof(h.omN));
+  const bool idx = c->idx_valid && c->idximg && (size_t)c->idx_rows * c->idx_cols <= c->idx_cap;
+  h.idxValid = idx ? 1 : 0; h.idxRows = idx ? c->idx_rows : 0; h.idxCols = idx ? c->idx_cols : 0;
+  h.idxMinD = c->idx_minD; h.idxMaxD = c->idx_maxD; std::memcpy(h.idxK, c->idx_K, sizeof(h.idxK));
+  const size_t npx = idx ? (size_t)c->idx_rows * c->idx_cols : 0;
+  flat_layout(h, n, c->d.omSym, c->d.OmN != nullptr, npx);
+  if (written) *written = (size_t)h.total;
+  if (!dst) return PWN_HIP_OK;                                   // size query
+  if (dst_bytes < h.total) return fail(ctx, PWN_HIP_ERR_CAPACITY, "flat cloud buffer too small (pwn_hip_cloud_export_bound)");
+  char* out = (char*)dst; hipStream_t st = ctx->stream;
+  HIPCHK(ctx, copy_any(out, &h, sizeof(h), st), PWN_HIP_ERR_COPY);
+  if (n > 0) {
+    HIPCHK(ctx, copy_any(out + h.offP3, c->d.P3, n * 12, st), PWN_HIP_ERR_COPY);
+    HIPCHK(ctx, copy_any(out + h.offNc, c->d.Nc, n * 16, st), PWN_HIP_ERR_COPY);
+    for (int r = 0; r < om_planes(c->d.omSym); ++r)
+      HIPCHK(ctx, copy_any(out + h.offOm + (size_t)r * up256(n * 12), c->d.Om + (size_t)r * cap * 3, n * 12, st), PWN_HIP_ERR_COPY);
+    if (c->d.OmN) for (int r = 0; r < 3; ++r)
+      HIPCHK(ctx, copy_any(out + h.offOmN + (size_t)r * up256(n * 12), c->d.OmN + (size_t)r * cap * 3, n * 12, st), PWN_HIP_ERR_COPY);
+  }
+  if (npx > 0) HIPCHK(ctx, copy_any(out + h.offIdx, c->idximg, npx * 4, st), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipStreamSynchronize(st), PWN_HIP_ERR_COPY);      // the header is a stack object; the buffer is complete on return
+  return PWN_HIP_OK;
+}
+int pwn_hip_cloud_import(pwn_hip_ctx* ctx, pwn_hip_cloud* c, const void* src, size_t src_bytes) {
+  if (!ctx || !c || !src) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  if (src_bytes < sizeof(CloudFlatHeader)) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "flat cloud buffer shorter than its header");
+  HIPCHK(ctx, hipSetDevice(ctx->device), PWN_HIP_ERR_NO_DEVICE);
+  if (int rc = absorb_copies(ctx)) return rc;
+  hipStream_t st = ctx->stream;
+  CloudFlatHeader h;
+  HIPCHK(ctx, copy_any(&h, src, sizeof(h), st), PWN_HIP_ERR_COPY);      // on the context's stream: ordered after pwn_hip_ctx_wait_stream
+  HIPCHK(ctx, hipStreamSynchronize(st), PWN_HIP_ERR_COPY);
+  if (h.magic != kFlatMagic || h.version != 1 || h.n < 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "not a flat cloud buffer (pwn_hip_cloud_export)");
+  CloudFlatHeader want; std::memset(&want, 0, sizeof(want));
+  const bool idx = h.idxValid != 0 && h.idxRows > 0 && h.idxCols > 0;
+  const size_t n = (size_t)h.n, npx = idx ? (size_t)h.idxRows * h.idxCols : 0, cap = (size_t)c->d.capacity;
+  flat_layout(want, n, h.omSym ? 1 : 0, h.hasOmN != 0, npx);
+  if (want.offP3 != h.offP3 || want.offNc != h.offNc || want.offOm != h.offOm || want.offOmN != h.offOmN || want.offIdx != h.offIdx || want.total != h.total)
+    return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "flat cloud buffer: inconsistent header");
+  if (src_bytes < h.total) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "flat cloud buffer shorter than its header says");
+  if (n > cap) return fail(ctx, PWN_HIP_ERR_CAPACITY, "cloud capacity smaller than the flat cloud");
+  if ((h.omSym ? 1 : 0) != c->d.omSym) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "flat cloud and destination cloud differ in omega storage (exact9 / sym6)");
+  cloud_changes(ctx, c);
+  c->has_stats = false; c->n_gauss = 0; c->idx_valid = false;
+  if (h.hasOmN && !c->d.OmN) HIPCHK(ctx, hipMalloc((void**)&c->d.OmN, cap * 9 * sizeof(float)), PWN_HIP_ERR_ALLOCATION);
+  if (!h.hasOmN && c->d.OmN) { (void)hipFree(c->d.OmN); c->d.OmN = nullptr; }      // the stream is idle (synchronised above)
+  if (idx && c->idx_cap < npx) {
+    if (c->idximg) (void)hipFree(c->idximg);
+    c->idximg = nullptr; c->idx_cap = 0;
+    HIPCHK(ctx, hipMalloc((void**)&c->idximg, npx * sizeof(int)), PWN_HIP_ERR_ALLOCATION);
+    c->idx_cap = npx;
+  }
+  const char* in = (const char*)src;
+  if (n > 0) {
+    HIPCHK(ctx, copy_any(c->d.P3, in + h.offP3, n * 12, st), PWN_HIP_ERR_COPY);
+    HIPCHK(ctx, copy_any(c->d.Nc, in + h.offNc, n * 16, st), PWN_HIP_ERR_COPY);
+    for (int r = 0; r < om_planes(c->d.omSym); ++r)
+      HIPCHK(ctx, copy_any(c->d.Om + (size_t)r * cap * 3, in + h.offOm + (size_t)r * up256(n * 12), n * 12, st), PWN_HIP_ERR_COPY);
+    if (h.hasOmN) for (int r = 0; r < 3; ++r)
+      HIPCHK(ctx, copy_any(c->d.OmN + (size_t)r * cap * 3, in + h.offOmN + (size_t)r * up256(n * 12), n * 12, st), PWN_HIP_ERR_COPY);
+  }
+  if (idx) HIPCHK(ctx, copy_any(c->idximg, in + h.offIdx, npx * 4, st), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, copy_any(c->d.count, &h.n, sizeof(int), st), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, hipStreamSynchronize(st), PWN_HIP_ERR_COPY);
+  c->d.clsThr = h.clsThr; std::memcpy(c->d.omN, h.omN, sizeof(h.omN));
+  c->n_host = h.n;
+  if (idx) {
+    c->idx_valid = true; c->idx_rows = h.idxRows; c->idx_cols = h.idxCols; c->idx_minD = h.idxMinD; c->idx_maxD = h.idxMaxD;
+    std::memcpy(c->idx_K, h.idxK, sizeof(h.idxK));
+  }
+  return PWN_HIP_OK;
+}
+
 // ------------------------------------------------------------------------------------------ input conditioning
 int pwn_hip_depth_u16_to_f32(pwn_hip_ctx* ctx, const uint16_t* src, float* dst, int n, float scale) {
   if (!ctx || !src || !dst || n < 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
@@ -1471,9 +1556,7 @@ static void finish_match(const MatchAcc& a, pwn_hip_match_result* r) {
   r->image_non_zeros = (int)a.nonZeros;
   r->image_inliers = (int)a.inliers;
   r->image_outliers = (int)a.nonZeros - (int)a.inliers;
-  // sum of the masked differences: exact in 1/64 units; values below 2^-120 only matter when nothing else was added
-  const double sum = a.sum64 ? (double)a.sum64 / 64.0 : (double)a.tiny * 1e-37;
-  r->image_reprojection_distance = (float)sum / (float)(int)a.nonZeros;          // pwn_matcher_base.cpp:179 (0/0 = NaN like the reference)
+  r->image_reprojection_distance = match_reprojection_distance(a);               // the expression k_pack_records evaluates for the score words of a record
 }
 // What a caller may weave into a batch alignment (pwn_hip_convert_align_batch_u16: the conversion of a sub-batch's frames goes in front of its
 // alignment on the same stream, so that one sub-batch converts while the other aligns and nothing waits for the host in between).
@@ -1487,9 +1570,11 @@ struct AlignHooks {
 static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* refs, pwn_hip_cloud* const* curs,
                             const float* guesses, pwn_hip_align_result* results, pwn_hip_match_result* scores, float match_threshold,
                             pwn_hip_align_statistics* statistics = nullptr, const AlignHooks* hooks = nullptr, float* records = nullptr,
-                            const int* pair_ids = nullptr, int first_pair_id = 0) {
+                            const int* pair_ids = nullptr, int first_pair_id = 0, bool match_records = false) {
   if (!ctx || !p || !refs || !curs || (!results && !records) || n < 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if (int rc = check_image(ctx, p->rows, p->cols)) return rc;
+  ctx->img_valid = false;                 // whatever happens below, the finder images of an earlier alignment are gone (set again on success)
+  const bool want_scores = scores != nullptr || (records && match_records);      // the score words of the long records come from the same accumulators
   if (p->min_distance < 0.f) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "min_distance must be >= 0");
   const int nit = p->outer_iterations * p->inner_iterations;
   if (p->outer_iterations < 0 || p->inner_iterations < 0 || nit > PWN_HIP_MAX_ITERATIONS)
@@ -1562,7 +1647,7 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
   if (n > 0) {
     HIPCHK(ctx, hipMemcpyAsync(ctx->pairs_dev, ctx->pairs_host, sizeof(PairDesc) * n, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
     HIPCHK(ctx, hipMemcpyAsync(ctx->state_ws, ctx->state_host, sizeof(PairState) * n, hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
-    if (scores) HIPCHK(ctx, hipMemsetAsync(ctx->match_dev, 0, sizeof(MatchAcc) * n, ctx->stream), PWN_HIP_ERR_COPY);
+    if (want_scores) HIPCHK(ctx, hipMemsetAsync(ctx->match_dev, 0, sizeof(MatchAcc) * n, ctx->stream), PWN_HIP_ERR_COPY);
   }
   // Every sub-batch takes its own block of tags (workspace slots are reused from sub-batch to sub-batch): tag0 for the
   // current-cloud projection (its own buffer) and tag0 - i for the reference projection of outer iteration i.  A call with
@@ -1621,7 +1706,7 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
       launch_corr_linearize<false, true>(ctx, omSym, nb, m, st, pr, ap, subLastRefTag, 1, 0);   // full H for _computeStatistics
       hipLaunchKernelGGL(k_reduce_pairs, dim3(m), dim3(256), 0, st, pr, nb, ctx->stats_dev + base);
     }
-    if (scores && p->outer_iterations > 0) {
+    if (want_scores && p->outer_iterations > 0) {
       StageTimer t(ctx, "match_score", st);     // the z-buffers of this sub-batch still hold the finder's last depth images
       hipLaunchKernelGGL(k_match_score, dim3(std::min((N + 255) / 256, 256), m), dim3(256), 0, st, pr, N, subLastRefTag, subTag0, 1000.0f,
                          match_threshold, ctx->match_dev + base, sub_own[kk] ? 1 : 0);
@@ -1633,10 +1718,11 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
     // the records leave the device as the kernel wrote them: straight into the caller's device buffer (what an all-gather sends), or through the
     // context's own buffer into host memory
     const bool dev = is_device_ptr(records);
+    const int rlen = match_records ? kMatchRecordFloats : kRecordFloats;
     if (!dev && ctx->records_cap < n) {
       if (ctx->records_ws) (void)hipFree(ctx->records_ws);
       ctx->records_ws = nullptr; ctx->records_cap = 0;
-      HIPCHK(ctx, hipMalloc((void**)&ctx->records_ws, (size_t)std::max(n, 64) * kRecordFloats * sizeof(float)), PWN_HIP_ERR_ALLOCATION);
+      HIPCHK(ctx, hipMalloc((void**)&ctx->records_ws, (size_t)std::max(n, 64) * kMatchRecordFloats * sizeof(float)), PWN_HIP_ERR_ALLOCATION);
       ctx->records_cap = std::max(n, 64);
     }
     if (pair_ids) {
@@ -1649,8 +1735,9 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
       HIPCHK(ctx, copy_any(ctx->ids_dev, pair_ids, sizeof(int) * n, ctx->stream), PWN_HIP_ERR_COPY);
     }
     float* dst = dev ? records : ctx->records_ws;
-    hipLaunchKernelGGL(k_pack_records, dim3(n), dim3(64), 0, ctx->stream, ctx->pairs_dev, pair_ids ? (const int*)ctx->ids_dev : nullptr, first_pair_id, dst);
-    if (!dev) HIPCHK(ctx, hipMemcpyAsync(records, ctx->records_ws, sizeof(float) * kRecordFloats * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
+    hipLaunchKernelGGL(k_pack_records, dim3(n), dim3(match_records ? 128 : 64), 0, ctx->stream, ctx->pairs_dev, pair_ids ? (const int*)ctx->ids_dev : nullptr, first_pair_id, dst,
+                       match_records ? (const MatchAcc*)ctx->match_dev : nullptr);
+    if (!dev) HIPCHK(ctx, hipMemcpyAsync(records, ctx->records_ws, sizeof(float) * rlen * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
   }
   if (hooks && hooks->before_sync) { if (int rc = hooks->before_sync()) return rc; }
   if (n > 0 && scores) HIPCHK(ctx, hipMemcpyAsync(ctx->match_host, ctx->match_dev, sizeof(MatchAcc) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
@@ -1825,6 +1912,12 @@ int pwn_hip_align_batch_records(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* 
   if (!records) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null records");
   return align_batch_impl(ctx, p, n, refs, curs, guesses, results, nullptr, 0.f, nullptr, nullptr, records, pair_ids, first_pair_id);
 }
+int pwn_hip_match_batch_records(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* refs, pwn_hip_cloud* const* curs,
+                                const float* guesses, float threshold, const int* pair_ids, int first_pair_id, pwn_hip_align_result* results,
+                                pwn_hip_match_result* scores, float* records) {
+  if (!records) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null records");
+  return align_batch_impl(ctx, p, n, refs, curs, guesses, results, scores, threshold, nullptr, nullptr, records, pair_ids, first_pair_id, true);
+}
 int pwn_hip_convert_align_batch_u16(pwn_hip_ctx* ctx, const pwn_hip_converter_params* cp, const pwn_hip_aligner_params* ap, int n,
                                     const uint16_t* const* ref_frames, const uint16_t* const* cur_frames, float depth_scale, int rows, int cols,
                                     pwn_hip_cloud* const* refs, pwn_hip_cloud* const* curs, const float* guesses, const int* pair_ids, int first_pair_id,
@@ -1832,6 +1925,15 @@ int pwn_hip_convert_align_batch_u16(pwn_hip_ctx* ctx, const pwn_hip_converter_pa
   if (!ctx || !cp || !ap || !ref_frames || !cur_frames || !refs || !curs || (!results && !records) || n < 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if (int rc = check_image(ctx, rows, cols)) return rc;
   if (ap->rows != rows || ap->cols != cols) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "aligner image size differs from the frames'");
+  // the clouds' host-side sizes are those of their PREVIOUS content while the step is being queued: bound what the conversion can produce instead
+  if ((size_t)rows * cols > (size_t)kMaxAlignerPoints)
+    return fail(ctx, PWN_HIP_ERR_CAPACITY, "Aligner::align: frames of more than 2^21 pixels (index field of the aligner's z-buffer word)");
+  {   // sub-batches run on different streams: a cloud that appears twice would be written by two of them at once
+    std::vector<const pwn_hip_cloud*> all; all.reserve((size_t)2 * std::max(n, 0));
+    for (int i = 0; i < n; ++i) { all.push_back(refs[i]); all.push_back(curs[i]); }
+    std::sort(all.begin(), all.end());
+    if (std::adjacent_find(all.begin(), all.end()) != all.end()) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "the 2 n clouds of a step must be distinct");
+  }
   if (int rc = absorb_copies(ctx)) return rc;
   if (int rc = ensure_desc(ctx, 2 * n)) return rc;       // once, before anything is queued: growing the descriptor arrays waits for the stream
   // the sub-batches and streams the alignment will use (align_batch_impl makes the same plan); the frames of sub-batch k -- its reference

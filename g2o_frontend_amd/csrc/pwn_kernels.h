@@ -107,7 +107,6 @@ struct FrameDesc {
   float* integral;   // [10][rows*cols]
   int* rowoff;       // [rows] (stand-alone unProject) or [rows][strips] (converter fast path)
   unsigned long long* carry; // [strips][bands][160] strip-to-strip hand-over words of k_unproject_integral
-  unsigned long long* fsync; // k_convert_fused: [strips] bands stored by the producers, [strips][4 kConsWG] bands finished by the consumer waves, [1] XCC id; each = launch epoch << 32 | value
   CloudDev cloud;
   int* count_out;    // optional: page-locked host word that receives the point count as well (single-frame calls: no gather kernel, no copy back)
 };
@@ -393,11 +392,9 @@ __global__ void __launch_bounds__(256) k_unproject(const FrameDesc* __restrict__
 // the covariance downstream differences these sums, so every chain keeps the reference's strictly sequential
 // left-to-right order: one thread per (row, channel) chain, tiles staged through LDS so that all global
 // traffic is row-coalesced.  grid = (ceil(rows/16), frames), block = 256.
-#ifndef PWN_IR_ROWS
-#define PWN_IR_ROWS 8       // band height of the integral-image kernels (a multiple of 4: one row per compute wave and step); measured on
-                           // MI355X: the hand-over wavefront of the strip kernel fills and drains in half the time with 8-row bands: -7 % against 16
-#endif
-constexpr int kIR_Rows = PWN_IR_ROWS, kIR_Cols = 64, kIR_Stride = kIR_Cols + 1;
+// band height of the integral-image kernels (a multiple of 4: one row per compute wave and step); measured on MI355X: the hand-over
+// wavefront of the strip kernel fills and drains in half the time with 8-row bands: -7 % against 16
+constexpr int kIR_Rows = 8, kIR_Cols = 64, kIR_Stride = kIR_Cols + 1;
 static_assert(kIR_Rows % 4 == 0 && (kIR_Rows & (kIR_Rows - 1)) == 0 && kIR_Rows <= 64, "band height");
 __global__ void __launch_bounds__(256) k_integral_rows(const FrameDesc* __restrict__ frames, int rows, int cols) {
   const FrameDesc& f = frames[blockIdx.y];
@@ -660,39 +657,9 @@ __device__ __forceinline__ void lds_barrier() {
 // waits for a load also waits for every store it issued before it; the compute waves issue ~60 KB of stores per band and must not
 // wait for memory at all.  The loader wave therefore does every global read of the block (depth and strip offsets of the NEXT
 // band, hand-over words of the current one) and passes the values on through LDS; it never stores to global memory.
-#ifndef PWN_II_X
-#define PWN_II_X 0   // timing experiments only: 1 = no plane stores, 2 = no point/index/interval stores, 4 = no hand-over wait, 8 = planes stored into a 128-row ring
-#endif
-#ifndef PWN_II_NT
-#define PWN_II_NT 3  // 1 = non-temporal plane stores, 2 = non-temporal index/interval stores, 3 = both (measured: strip kernel -5 %, k_stats after it -4 %)
-#endif
+// Plane, index and interval stores are non-temporal (measured: strip kernel -5 %, k_stats after it -4 %).
 constexpr int kII_Threads = 320;
-#ifndef PWN_CONS_WG
-#define PWN_CONS_WG 2                // k_convert_fused: consumer workgroups per strip (each takes every PWN_CONS_WG-th row pair of a band)
-#endif
-#ifndef PWN_FUSED_X
-#define PWN_FUSED_X 0                // timing experiments only (results wrong): 1 = consumers do nothing, 2 = consumers wait and load but skip the arithmetic
-#endif
-constexpr int kConsWG = PWN_CONS_WG;
-static_assert(kConsWG == 1 || kConsWG == 2, "consumer workgroups per strip");
-constexpr int kRingRows = 128;       // k_convert_fused: rows of a frame's plane ring -- a power of two, a multiple of the band height, >= the window reach
-                                     // (31 rows back, 29 ahead) + the bands a producer may run ahead of the consumers that still read the old rows
-static_assert(kRingRows % kIR_Rows == 0 && (kRingRows & (kRingRows - 1)) == 0, "ring rows");
-// bounded poll of a tagged progress word (launch epoch << 32 | count) until count >= need; false = timed out (the caller raises the fault flag)
-__device__ __forceinline__ bool wait_progress(gptr<unsigned long long> w, unsigned epoch, unsigned need, int spinLimit) {
-  unsigned long long v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  int spins = 0;
-  while ((unsigned)(v >> 32) != epoch || (unsigned)v < need) {
-    if (++spins >= spinLimit) return false;
-    __builtin_amdgcn_s_sleep(2);
-    v = __hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  return true;
-}
-// Body of the single-pass front end for strip s of frame f.  FUSED = false: k_unproject_integral (planes [10][rows][cols], read back by
-// k_stats).  FUSED = true: the producer side of k_convert_fused -- the planes are a ring of kRingRows rows that the consumer workgroups of
-// the same launch read while it is being written (see k_convert_fused for the protocol).
-template <bool FUSED>
+// Body of the single-pass front end for strip s of frame f (planes [10][rows][cols], read back by k_stats).
 __device__ __forceinline__ void unproject_integral_body(const FrameDesc& f, const ConvertParams& cp, const int s, const unsigned epoch, int* __restrict__ fault) {
   const int rows = cp.rows, cols = cp.cols;
   const int S = strips_of(cols), NB = bands_of(rows);
@@ -762,7 +729,7 @@ __device__ __forceinline__ void unproject_integral_body(const FrameDesc& f, cons
     if (loader) {
       const int nb = (band + 1 < NB) ? band + 1 : band;        // the last band re-reads itself (unconditional loads, result unused)
       request_band(nb);
-      if (s > 0 && !(PWN_II_X & 4)) {
+      if (s > 0) {
         const gptr<unsigned long long> src = gcarry + ((size_t)(s - 1) * NB + band) * kII_Chains;
 #pragma unroll
         for (int m = 0; m < 3; ++m) {
@@ -778,15 +745,6 @@ __device__ __forceinline__ void unproject_integral_body(const FrameDesc& f, cons
             cin[k] = __uint_as_float((unsigned)w);
           }
         }
-      }
-      if (FUSED && band >= kRingRows / kIR_Rows - 4 && !starved) {
-        // ring back-pressure: band `band` overwrites the slots of rows [8 band - kRingRows, +7]; the consumers of this strip and of its two
-        // neighbours that read those rows (bands <= band - (kRingRows - 32) / 8) must have finished.  Consumers normally trail the producers
-        // by 5-7 bands, so this wait is not taken in a healthy pipeline.
-        const unsigned need = (unsigned)(band - (kRingRows - 32) / kIR_Rows + 1);
-        const int sp = s - 1 + lane / (4 * kConsWG);            // lanes 0 .. 3 * 4 kConsWG - 1: the words of the consumer waves of strips s-1, s, s+1
-        if (!(PWN_FUSED_X & 1) && lane < 3 * 4 * kConsWG && sp >= 0 && sp < S &&
-            !wait_progress(as_global(f.fsync) + S + sp * (4 * kConsWG) + lane % (4 * kConsWG), epoch, need, cp.spinLimit)) { atomicOr(fault, 1); starved = true; }
       }
       stage_band(band + 1);
     } else {
@@ -813,7 +771,7 @@ __device__ __forceinline__ void unproject_integral_body(const FrameDesc& f, cons
             p.z = dot4seq(cp.iKRt(2,0), a, cp.iKRt(2,1), b, cp.iKRt(2,2), dd, cp.iKRt(2,3), 1.0f);
             p.w = 0.f;
             if (idx < capacity) {
-              if (!(PWN_II_X & 2) && !lean) store_xyz(gP3, idx, p.x, p.y, p.z);
+              if (!lean) store_xyz(gP3, idx, p.x, p.y, p.z);
               v[0] = p.x; v[1] = p.y; v[2] = p.z; v[3] = 1.0f;
               v[4] = p.x * p.x; v[5] = p.x * p.y; v[6] = p.x * p.z;
               v[7] = p.y * p.y; v[8] = p.y * p.z; v[9] = p.z * p.z;
@@ -824,9 +782,8 @@ __device__ __forceinline__ void unproject_integral_body(const FrameDesc& f, cons
               itv = (px > py) ? (int)px : (int)py;
             }
           }
-          if (!(PWN_II_X & 2) || idx == -12345) {
-          if (PWN_II_NT & 2) { __builtin_nontemporal_store(idx, gindex + (unsigned)(r * cols + c)); if (!lean) __builtin_nontemporal_store(itv, ginterval + (unsigned)(r * cols + c)); }
-          else { gindex[(unsigned)(r * cols + c)] = idx; if (!lean) ginterval[(unsigned)(r * cols + c)] = itv; } }
+          __builtin_nontemporal_store(idx, gindex + (unsigned)(r * cols + c));
+          if (!lean) __builtin_nontemporal_store(itv, ginterval + (unsigned)(r * cols + c));
         }
 #pragma unroll
         for (int k = 0; k < kIntegralChannels; ++k) tile[(k * kIR_Rows + lr) * kIR_Stride + lane] = v[k];
@@ -854,8 +811,6 @@ __device__ __forceinline__ void unproject_integral_body(const FrameDesc& f, cons
     }
     lds_barrier();
     // 3. y pass, chain q = (channel = q / 64, column = q % 64)
-    if (FUSED && !loader) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the plane stores of the PREVIOUS band (issued a band ago) have landed in L2:
-                                                                               // what the progress word published below promises
     if (!loader) {
 #pragma unroll
       for (int jj = 0; jj < 3; ++jj) {
@@ -869,27 +824,15 @@ __device__ __forceinline__ void unproject_integral_body(const FrameDesc& f, cons
 #pragma unroll
           for (int r = 0; r < kIR_Rows; ++r) { vc = vals[r] + vc; vals[r] = vc; }
           vcarry[jj] = vc;
-          if (c < cols && (!(PWN_II_X & 1) || vc == 12345.678f)) {
-            const gptr<float> dst = gintegral + ((size_t)ch * N + (size_t)((FUSED || (PWN_II_X & 8)) ? (r0 & (kRingRows - 1)) : r0) * cols + c);      // PWN_II_X & 8: timing experiment, planes as a ring
+          if (c < cols) {
+            const gptr<float> dst = gintegral + ((size_t)ch * N + (size_t)r0 * cols + c);
 #pragma unroll
-            for (int r = 0; r < kIR_Rows; ++r) if (r0 + r < rows) {
-              if (PWN_II_NT & 1) __builtin_nontemporal_store(vals[r], dst + (unsigned)(r * cols));
-              else dst[(unsigned)(r * cols)] = vals[r];
-            }
+            for (int r = 0; r < kIR_Rows; ++r) if (r0 + r < rows) __builtin_nontemporal_store(vals[r], dst + (unsigned)(r * cols));
           }
         }
       }
     }
     lds_barrier();
-    // every compute wave has passed its drain of this band: the planes of bands < band are complete in L2
-    if (FUSED && tid == 0)
-      __hip_atomic_store(as_global(f.fsync) + s, ((unsigned long long)epoch << 32) | (unsigned long long)(unsigned)band, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (FUSED) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0)
-      __hip_atomic_store(as_global(f.fsync) + s, ((unsigned long long)epoch << 32) | (unsigned long long)(unsigned)NB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 __global__ void __launch_bounds__(kII_Threads) k_unproject_integral(const FrameDesc* __restrict__ frames, ConvertParams cp, int nframes,
@@ -898,7 +841,7 @@ __global__ void __launch_bounds__(kII_Threads) k_unproject_integral(const FrameD
   const unsigned j = blockIdx.x >> 3;
   const int fi = 8 * (int)(j / (unsigned)S) + (int)(blockIdx.x & 7u), s = (int)(j % (unsigned)S);
   if (fi >= nframes) return;
-  unproject_integral_body<false>(frames[fi], cp, s, epoch, fault);
+  unproject_integral_body(frames[fi], cp, s, epoch, fault);
 }
 // pass 3 (pwn_core/pointintegralimage.cpp:38-43): prefix-sum along image y inside each image column, sequential.
 // one thread per (column, channel) chain, lanes along x.  grid = (ceil(cols/64), 10, frames), block = 64: this kernel only runs on the
@@ -938,63 +881,19 @@ __global__ void __launch_bounds__(kIC_Block) k_integral_cols(const FrameDesc* __
 // L2 fill per XCD.  Placement only affects speed.  grid = 8 * ceil(frames/8) * rows * ceil(cols/256) (frames >= 8; else frames * rows *
 // ceil(cols/256), frame-major), block = 256.
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { v = (v < lo) ? lo : v; v = (v > hi) ? hi : v; return v; }
-#ifndef PWN_STATS_NT
-#define PWN_STATS_NT 1
-#endif
 // streamed-once data of k_stats (index / interval / point in, cloud out) uses non-temporal accesses so that it does not evict the
 // integral-image lines, which are the only data with reuse (each value is read by ~4 pixels)
 template <typename PTR> __device__ __forceinline__ auto stream_load(PTR p) -> std::remove_cv_t<std::remove_reference_t<decltype(*p)>> {
-#if PWN_STATS_NT
   return __builtin_nontemporal_load(p);
-#else
-  return *p;
-#endif
 }
-template <typename PTR, typename T> __device__ __forceinline__ void stream_store(PTR p, T v) {
-#if PWN_STATS_NT
-  __builtin_nontemporal_store(v, p);
-#else
-  *p = v;
-#endif
-}
+template <typename PTR, typename T> __device__ __forceinline__ void stream_store(PTR p, T v) { __builtin_nontemporal_store(v, p); }
 // the 12-byte records: not through the templates above (template argument deduction drops the typedef's alignment attribute and the access
 // would be emitted with the vector type's natural `align 16`)
-__device__ __forceinline__ v3f_raw stream_load3(gptr<const float> p) {
-#if PWN_STATS_NT
-  return __builtin_nontemporal_load((gptr<const v3f>)p);
-#else
-  return *(gptr<const v3f>)p;
-#endif
-}
-__device__ __forceinline__ void stream_store3(gptr<float> p, v3f_raw v) {
-#if PWN_STATS_NT
-  __builtin_nontemporal_store(v, (gptr<v3f>)p);
-#else
-  *(gptr<v3f>)p = v;
-#endif
-}
+__device__ __forceinline__ v3f_raw stream_load3(gptr<const float> p) { return __builtin_nontemporal_load((gptr<const v3f>)p); }
+__device__ __forceinline__ void stream_store3(gptr<float> p, v3f_raw v) { __builtin_nontemporal_store(v, (gptr<v3f>)p); }
 
-#ifndef PWN_ST_X
-#define PWN_ST_X 0   // timing experiments only (results wrong): 1 = no cloud stores, 2 = no arithmetic between the corner loads and the stores
-                     // (memory traffic alone), 4 = no integral-plane loads (the corner sums come from registers: arithmetic + stores alone),
-                     // 8 = plane rows taken modulo 128 (the gathers of a ring that stays in the XCD's L2)
-#endif
-// One pixel of the stats pass (everything after the thread has found its pixel).  RING = false: k_stats (planes [10][rows][cols], point index
-// from the index image).  RING = true: the consumer side of k_convert_fused (planes are a ring of kRingRows rows, index and depth handed in).
-#ifndef PWN_RING_LOAD
-#define PWN_RING_LOAD 1      // 0 = nt, 1 = sc1 (agent-scope relaxed atomic load), 2 = plain (timing only: may read stale L1 lines)
-#endif
-__device__ __forceinline__ float ring_load(gptr<const float> p) {
-#if PWN_RING_LOAD == 0
-  return __builtin_nontemporal_load(p);
-#elif PWN_RING_LOAD == 1
-  return __uint_as_float(__hip_atomic_load((gptr<const unsigned>)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-#else
-  return *p;
-#endif
-}
-template <bool RING>
-__device__ __forceinline__ void stats_pixel(const FrameDesc& f, const ConvertParams& cp, const int r, const int c, const int idx_in, const float d_in) {
+// One pixel of the stats pass (everything after the thread has found its pixel): planes [10][rows][cols], point index from the index image.
+__device__ __forceinline__ void stats_pixel(const FrameDesc& f, const ConvertParams& cp, const int r, const int c) {
   const int rows = cp.rows, cols = cp.cols;
   const size_t N = (size_t)rows * cols;
   // descriptor pointers are generic to the compiler; they all point to hipMalloc'ed memory: global_* instructions with a scalar
@@ -1004,15 +903,14 @@ __device__ __forceinline__ void stats_pixel(const FrameDesc& f, const ConvertPar
   const gptr<float> gP = as_global(f.cloud.P3), gN = as_global((float*)f.cloud.Nc), gOm = as_global(f.cloud.Om);
   const int cap = f.cloud.capacity;
   const unsigned upix = (unsigned)(r * cols + c);
-  const int idx = RING ? idx_in : stream_load(gindex + upix);      // RING: the caller ranked the pixel itself (row / strip offset + ballot)
+  const int idx = stream_load(gindex + upix);
   if (idx < 0 || idx >= cap) return;
   int itv;
   float4 P;
-  if (RING || cp.lean) {
+  if (cp.lean) {
     // the front end kept the point and the interval to itself: the same expressions on the same depth (pinholepointprojector.h:246-251,264-274)
     float d;
-    if (RING) d = d_in;
-    else if (f.raw) { const unsigned sv = stream_load(as_global(f.raw) + upix); d = sv ? f.raw_scale * (float)sv : 0.0f; }
+    if (f.raw) { const unsigned sv = stream_load(as_global(f.raw) + upix); d = sv ? f.raw_scale * (float)sv : 0.0f; }
     else d = stream_load(as_global(f.depth) + upix);
     const float a = (float)c * d, b = (float)r * d;
     P.x = dot4seq(cp.iKRt(0,0), a, cp.iKRt(0,1), b, cp.iKRt(0,2), d, cp.iKRt(0,3), 1.0f);
@@ -1043,51 +941,21 @@ __device__ __forceinline__ void stats_pixel(const FrameDesc& f, const ConvertPar
     // PointIntegralImage::getRegion (pointintegralimage.cpp:53-66)
     const int xmin = clampi(c - rad - 1, 0, cols - 1), xmax = clampi(c + rad - 1, 0, cols - 1);
     const int ymin = clampi(r - rad - 1, 0, rows - 1), ymax = clampi(r + rad - 1, 0, rows - 1);
-    // RING (fused converter): the planes are a ring of kRingRows image rows per frame, row y at slot y & (kRingRows - 1)
-    const int ya = (RING || (PWN_ST_X & 8)) ? (ymax & (kRingRows - 1)) : ymax, yb = (RING || (PWN_ST_X & 8)) ? (ymin & (kRingRows - 1)) : ymin;
-    const unsigned oA = (unsigned)(ya * cols + xmax), oB = (unsigned)(yb * cols + xmin);
-    const unsigned oC = (unsigned)(ya * cols + xmin), oD = (unsigned)(yb * cols + xmax);
+    const unsigned oA = (unsigned)(ymax * cols + xmax), oB = (unsigned)(ymin * cols + xmin);
+    const unsigned oC = (unsigned)(ymax * cols + xmin), oD = (unsigned)(ymin * cols + xmax);
     float a[kIntegralChannels];
-#if PWN_ST_X & 4
-    {   // timing experiment: a plausible window (a few thousand points around the pixel's own point) without touching the planes
-      const float cnt = (float)(2000 + ((oA ^ oB ^ oC ^ oD) & 1023));
-      const float jx = 0.01f * (float)(c & 31), jy = 0.01f * (float)(r & 31);
-      a[0] = cnt * P.x; a[1] = cnt * P.y; a[2] = cnt * P.z; a[3] = cnt;
-      a[4] = cnt * (P.x * P.x + 0.0100f + jx); a[5] = cnt * (P.x * P.y + 0.0010f); a[6] = cnt * (P.x * P.z + 0.0005f);
-      a[7] = cnt * (P.y * P.y + 0.0200f + jy); a[8] = cnt * (P.y * P.z + 0.0007f); a[9] = cnt * (P.z * P.z + 0.0001f);
-    }
-#else
 #pragma unroll
     for (int k = 0; k < kIntegralChannels; ++k) {
       const gptr<const char> pl = (gptr<const char>)(gintegral + (size_t)k * N);      // plane base: scalar; lane offsets: 32-bit bytes
       float v;
-      if (RING) {
-        // ring slots are rewritten while the kernel runs and a CU's L1 is never refreshed by other CUs' stores: every load is an sc1 load
-        // (L2-served, L1 bypassed).  NOT a non-temporal load: nt lines are not kept in L2, and every ring line is read by ~40 pixels --
-        // measured 7.8 ms per 256 VGA frames with nt loads against 6.0 with sc1 (tools/ab_fused.sh).
-        v = ring_load((gptr<const float>)(pl + 4u * oA));
-        v = v + ring_load((gptr<const float>)(pl + 4u * oB));
-        v = v - ring_load((gptr<const float>)(pl + 4u * oC));
-        v = v - ring_load((gptr<const float>)(pl + 4u * oD));
-      } else {
-        v = *(gptr<const float>)(pl + 4u * oA);
-        v = v + *(gptr<const float>)(pl + 4u * oB);
-        v = v - *(gptr<const float>)(pl + 4u * oC);
-        v = v - *(gptr<const float>)(pl + 4u * oD);
-      }
+      v = *(gptr<const float>)(pl + 4u * oA);
+      v = v + *(gptr<const float>)(pl + 4u * oB);
+      v = v - *(gptr<const float>)(pl + 4u * oC);
+      v = v - *(gptr<const float>)(pl + 4u * oD);
       a[k] = v;
     }
-#endif
     const int n = (int)a[3];
-#if PWN_ST_X & 2
-    if (n >= cp.minPoints) {   // timing experiment: the loaded sums go straight to the stores
-      npts = n; nx = a[0]; ny = a[1]; nz = a[2]; curvature = a[4];
-      om[0] = a[5]; om[1] = a[6]; om[2] = a[7]; om[3] = a[8]; om[4] = a[9]; om[5] = a[0] + a[9]; om[6] = a[1] + a[8]; om[7] = a[2] + a[7]; om[8] = a[4] + a[6];
-    }
-    if (false) {
-#else
     if (n >= cp.minPoints) {
-#endif
       npts = n;
       // PointAccumulator::mean / covariance (pointaccumulator.h:66-86)
       float d = a[3];
@@ -1118,7 +986,7 @@ __device__ __forceinline__ void stats_pixel(const FrameDesc& f, const ConvertPar
   }
   // information matrices
   const float sq = dot4seq(nx, nx, ny, ny, nz, nz, 0.f, 0.f);
-  if (sq > 0 && !(PWN_ST_X & 2)) {
+  if (sq > 0) {
     float dg[3];
     if (curvature < cp.pointInfoCurvThr) { dg[0] = cp.pFlat[0]; dg[1] = cp.pFlat[1]; dg[2] = cp.pFlat[2]; }
     else { dg[0] = 1.0f / ev[0]; dg[1] = 1.0f / ev[1]; dg[2] = 1.0f / ev[2]; }
@@ -1171,12 +1039,6 @@ __device__ __forceinline__ void stats_pixel(const FrameDesc& f, const ConvertPar
       for (int j = 0; j < 3; ++j) om[3 * i + j] = dot3seq(t1[3 * i], m(j,0), t1[3 * i + 1], m(j,1), t1[3 * i + 2], m(j,2));
   }
   (void)cls;      // not stored: normal_class(normal, curvature, normalInfoCurvThr) gives it back
-#if PWN_ST_X & 1
-  {   // timing experiment: no stores; the test depends on every output so that none of the arithmetic can be sunk behind it
-    const float chk = ((((P.x + P.y) + (P.z + nx)) + ((ny + nz) + (curvature + om[0]))) + (((om[1] + om[2]) + (om[3] + om[4])) + ((om[5] + om[6]) + (om[7] + om[8]))));
-    if (chk != 12345.678f) return;
-  }
-#endif
   {
     // one 12-byte and one 16-byte store (dword stores per lane would write every 1 KiB segment of the wave several times at a fraction of the density)
     v3f_raw pv; pv.x = P.x; pv.y = P.y; pv.z = P.z;
@@ -1203,14 +1065,8 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
   int frame, rem;
   if (nframes >= 8) {
     const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-#if PWN_ST_X & 16     /* timing experiment: the frames of an XCD advance together, row by row (what consumers of a 64-frame producer launch would do) */
-    const int fpx = (nframes + 7) / 8;              // frames per XCD
-    frame = (k % fpx) * 8 + xcd;
-    rem = k / fpx;
-#else
     frame = (k / perFrame) * 8 + xcd;
     rem = k % perFrame;
-#endif
   } else {                                   // fewer frames than XCDs (tracker, makeCloud): a frame per XCD would idle the others; grid = nframes * perFrame
     frame = blockIdx.x / perFrame;
     rem = blockIdx.x % perFrame;
@@ -1220,121 +1076,7 @@ __global__ void __launch_bounds__(256) k_stats(const FrameDesc* __restrict__ fra
   const int r = rem / nxb;
   const int c = (rem % nxb) * 256 + threadIdx.x;
   if (c >= cp.cols) return;
-  stats_pixel<false>(f, cp, r, c, 0, 0.f);
-}
-
-// ------------------------------------------------------------------------------------------------------------------
-// Fused converter (throughput path, lean mode): DepthImageConverterIntegralImage::compute (depthimageconverterintegralimage.cpp:15-55) as ONE
-// launch in which the integral planes never travel to HBM and back.  Per frame there are S producer workgroups (the single-pass front end,
-// unproject_integral_body<true>: strip s walks its 64 columns top to bottom in 8-row bands) and S consumer workgroups (the stats pass of the
-// same 64 columns, stats_pixel<true>, trailing the producers).  The ten planes are a RING of kRingRows image rows per frame (row y at slot
-// y mod kRingRows): a row is written once, read by the consumers of its own strip and of the two neighbouring strips (the window reaches 31
-// columns / rows back and 29 ahead) while it is still in the XCD's L2 / the Infinity Cache, and overwritten 128 rows later.  Against the
-// two-kernel form (k_unproject_integral + k_stats) that removes 40 bytes per pixel written to HBM and 40 read back, and the two halves --
-// a chain of dependent LDS steps that leaves the vector ALUs idle, and gathers + arithmetic + streamed stores -- share the CUs.
-//
-// Protocol (all words are launch epoch << 32 | value, so nothing is ever cleared; relaxed agent-scope atomics):
-//   prod[s] = bands of strip s whose plane stores have landed in L2 (every storing wave drains its stores -- s_waitcnt vmcnt(0) one band
-//             later, when they have long completed -- then a workgroup barrier, then one lane publishes);
-//   cons[s][m] = bands consumer wave m of strip s has finished (its ring loads have returned: their values were used), updated every 2nd band.
-//   consumer of band b: waits prod[s-1], prod[s], prod[s+1] >= min(NB, b + 5)        (rows up to 8 b + 36 are stored); it polls only when it
-//                       has caught up with the counts it read last -- producers run ahead, so most bands start without a poll;
-//   producer of band b >= 12: waits cons[s-1..s+1][*] >= b - 11                      (nobody still needs the rows its stores overwrite).
-//   Consumers load the ring with L1-bypassing (nt) loads: a CU's L1 is never refreshed by other CUs' stores and ring addresses are reused.
-// Forward progress: the 2 S workgroups of a frame are consecutive in dispatch order on one XCD (ids are dealt round-robin over the XCDs);
-// a workgroup waits only for workgroups of its own frame, so the lowest unfinished frame of every XCD is resident as a whole and completes
-// -- the same in-order-dispatch assumption as the strip hand-over, with the same safety net: every poll is bounded and raises *fault
-// (1 = time-out) instead of hanging.  Producers and consumers of a frame must share an L2: every workgroup checks its XCC id against the
-// frame's first arrival and raises *fault = 2 on a mismatch (the host then repeats the batch with the two-kernel path and stops using this
-// kernel).  Results are bit-identical to the two-kernel path: the same chains, the same per-pixel code.
-//
-// MEASURED (MI355X, round 3, tools/ab_fused.sh, profiles/r03_converter_experiments.txt): correct and bit-identical, but SLOWER than the two
-// kernels -- 5.8-6.2 ms per 256 VGA frames against 3.3-3.5 -- whatever the consumer waves per strip (4 or 8), the VGPR cap (5, 6, 7 or 8
-// waves per SIMD), the frames per launch (32 or 64) or the producers' wave priority.  One stats row of 64 pixels is ~12 us of latency (a
-// depth load, 40 dependent gathers, ~1000 arithmetic instructions, 5 stores) of which 1.3 us is arithmetic: k_stats hides that with 8
-// short-lived waves per SIMD = 8 192 rows in flight; here the rows in flight are the RESIDENT consumer waves (~2 700: the 3 200 producer
-// waves -- chains of dependent LDS steps that issue little -- hold the other slots, and the kernel needs 85 VGPRs), each walking its rows
-// one after the other.  Throughput = rows in flight / 12 us in both kernels; the ring removes the HBM round trip of the planes (the same
-// plane traffic emulated in the two-kernel form saves 20 %, PWN_ST_X=8 / PWN_II_X=8) but cannot pay for 3x fewer rows in flight.  Kept as an
-// opt-in path (PWN_FUSED_CONVERT=1) and a tested reference for the protocol; the product path is the two kernels.
-// grid = 8 * ceil(frames / 8) * (1 + kConsWG) * strips, block = kII_Threads.
-constexpr int kConsWaves = 4 * kConsWG;        // consumer waves per strip; each is an independent agent (no workgroup barriers): wave m takes
-                                               // rows m, m + kConsWaves, ... of every band, polls the producers only when it has caught up
-                                               // with what it last saw of them, and publishes its own progress word every second band
-static_assert(kIR_Rows % kConsWaves == 0, "rows of a band per consumer wave");
-constexpr int kConsPublish = 2;                // bands between two updates of a consumer wave's progress word
-__device__ __forceinline__ void stats_consumer(const FrameDesc& f, const ConvertParams& cp, const int s, const int part, const unsigned epoch, int* __restrict__ fault) {
-  const int rows = cp.rows, cols = cp.cols;
-  const int S = strips_of(cols), NB = bands_of(rows);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  if (wave >= 4 || (PWN_FUSED_X & 1)) return;
-  const int me = part * 4 + wave;
-  const int c = s * kIR_Cols + lane;
-  const gptr<unsigned long long> gsync = as_global(f.fsync);
-  const gptr<const int> growoff = as_global((const int*)f.rowoff);
-  const gptr<const uint16_t> graw = as_global(f.raw);
-  const gptr<const float> gdepth = as_global(f.depth);
-  const bool is_raw = f.raw != nullptr;
-  bool starved = false;
-  unsigned seen = 0;                                          // bands all three producers had stored when this wave last looked
-  for (int band = 0; band < NB; ++band) {
-    const unsigned need = (unsigned)((band + 5 < NB) ? band + 5 : NB);
-    if (seen < need && !starved) {
-      const int sp = s - 1 + lane;
-      unsigned got = 0xFFFFFFFFu;
-      if (lane < 3 && sp >= 0 && sp < S) {
-        if (!wait_progress(gsync + sp, epoch, need, cp.spinLimit)) { atomicOr(fault, 1); starved = true; }
-        got = (unsigned)__hip_atomic_load(gsync + sp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // same epoch: wait_progress has seen it
-      }
-      got = min(got, (unsigned)__shfl_xor((int)got, 1, 64));
-      got = min(got, (unsigned)__shfl_xor((int)got, 2, 64));
-      seen = (unsigned)__builtin_amdgcn_readfirstlane((int)got);
-      starved = __ballot(starved) != 0ull;
-      if (starved) seen = 0xFFFFFFFFu;                        // the launch is lost: finish without further waits
-    }
-#pragma unroll 1
-    for (int jj = 0; jj < kIR_Rows / kConsWaves; ++jj) {
-      const int r = band * kIR_Rows + me + kConsWaves * jj;   // wave-uniform
-      if (r >= rows) continue;
-      const bool in = c < cols;
-      const unsigned pix = in ? (unsigned)(r * cols + c) : 0u;
-      float d;
-      if (is_raw) { const unsigned sv = __builtin_nontemporal_load(graw + pix); d = sv ? f.raw_scale * (float)sv : 0.0f; }      // pwn_static.cpp:54-68
-      else d = __builtin_nontemporal_load(gdepth + pix);
-      const bool valid = in && !(d < cp.minD || d > cp.maxD);
-      const unsigned long long bal = __ballot(valid);
-      const int base = growoff[r * S + s];                    // point index of the strip row's first valid pixel (k_strip_count + k_row_offsets)
-      const int idx = valid ? base + __popcll(bal & ((1ull << lane) - 1ull)) : -1;
-      stats_pixel<true>(f, cp, r, c, idx, d);
-    }
-    // this wave's ring loads of the band have returned (their values went into the stores above)
-    if (lane == 0 && ((band + 1) % kConsPublish == 0 || band + 1 == NB))
-      __hip_atomic_store(gsync + S + s * kConsWaves + me, ((unsigned long long)epoch << 32) | (unsigned long long)(unsigned)(band + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-__global__ void __launch_bounds__(kII_Threads) k_convert_fused(const FrameDesc* __restrict__ frames, ConvertParams cp, int nframes,
-                                                               unsigned epoch, int* __restrict__ fault) {
-  const int S = strips_of(cp.cols);
-  const unsigned j = blockIdx.x >> 3;
-  const int G = (1 + kConsWG) * S;                               // workgroups of a frame: S producers, then kConsWG consumers per strip
-  const int fi = 8 * (int)(j / (unsigned)G) + (int)(blockIdx.x & 7u), w = (int)(j % (unsigned)G);
-  if (fi >= nframes) return;
-  const FrameDesc& f = frames[fi];
-  if (threadIdx.x == 0) {
-    // placement check: all workgroups of a frame must sit on one XCD (they hand data over through its L2)
-    const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg(20 | (0 << 6) | ((4 - 1) << 11)) & 0xFu;      // hwreg(HW_REG_XCC_ID, 0, 4)
-    const gptr<unsigned long long> wd = as_global(f.fsync) + (1 + 4 * kConsWG) * S;
-    const unsigned long long mine = ((unsigned long long)epoch << 32) | xcc;
-    unsigned long long cur = __hip_atomic_load(wd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int t = 0; t < 8 && (unsigned)(cur >> 32) != epoch; ++t) {
-      const unsigned long long prev = atomicCAS((unsigned long long*)f.fsync + (1 + 4 * kConsWG) * S, cur, mine);
-      cur = (prev == cur) ? mine : prev;
-    }
-    if ((unsigned)(cur >> 32) != epoch || (unsigned)cur != xcc) atomicOr(fault, 2);
-  }
-  if (w < S) unproject_integral_body<true>(f, cp, w, epoch, fault);
-  else stats_consumer(f, cp, (w - S) / kConsWG, (w - S) % kConsWG, epoch, fault);
+  stats_pixel(f, cp, r, c);
 }
 
 // Cloud::transformInPlace on an existing device cloud (cloud.cpp:173-186); grid = ceil(cap/256)
@@ -1379,11 +1121,7 @@ __device__ __forceinline__ void project_point(const Mat4& KRt, float minD, float
   // int conversion of out-of-range floats is undefined on the CPU; such points are rejected by the bounds test
   if (!(fx >= 0.f && fx < (float)cols && fy >= 0.f && fy < (float)rows)) return;
   const int x = (int)fx, y = (int)fy;
-#ifdef PWN_TIMING_PLAIN_STORE      /* timing experiment only: wrong results */
-  z[(size_t)y * cols + x] = zkey(tag, d, i);
-#else
   atomicMin(&z[(size_t)y * cols + x], zkey(tag, d, i));
-#endif
 }
 // depth of a point under a projector matrix: the third row of _project (pinholepointprojector.h:224-233), same expression as project_point
 __device__ __forceinline__ float point_depth(const Mat4& KRt, const float4 p) {
@@ -1519,12 +1257,6 @@ struct RegAcc {
   float* a;
   __device__ __forceinline__ void add(int k, float v) const { a[k] += v; }
 };
-#ifndef PWN_LDS_ACC
-#define PWN_LDS_ACC 1
-#endif
-#ifndef PWN_LDS_ATOMIC_ACC
-#define PWN_LDS_ATOMIC_ACC 0
-#endif
 // The Gauss-Newton step solves with Matrix6f::ldlt(), which reads the LOWER triangle of H only (aligner.cpp:112; Eigen's LDLT
 // default): the strictly upper entries of the Htt and Hrr blocks (sums 3, 6, 7 and 21, 24, 25) are never looked at, so the
 // iteration kernels do not accumulate them (FULL = false: 28 sums).  Aligner::_computeStatistics inverts the full H, the pass
@@ -1536,25 +1268,12 @@ template <bool FULL> struct LdsAcc {
   float* base;      // &lds[threadIdx.x], stride kAlignBlock
   __device__ __forceinline__ void add(int k, float v) const {
     if (!FULL && acc_is_upper(k)) return;
-#if PWN_LDS_ATOMIC_ACC
-    // the thread's own slot: an LDS float add without return (ds_add_f32) instead of ds_read + v_add + ds_write -- no wait for read data
-    (void)__hip_atomic_fetch_add(&base[(FULL ? k : acc_slot_lower(k)) * kAlignBlock], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
     base[(FULL ? k : acc_slot_lower(k)) * kAlignBlock] += v;
-#endif
   }
 };
-// returns false if the term is rejected (non-robust kernel and chi2 above threshold)
-// a*b + c*d of the H / b products.  PWN_LIN_FMA=1 (experiment) contracts it to fma(a, b, c*d): fewer VALU instructions, last-bit
-// differences in H and b (chi2, the acceptance tests and the counters are not touched).
-#ifndef PWN_LIN_FMA
-#define PWN_LIN_FMA 0
-#endif
-#if PWN_LIN_FMA
-#define MAD2(a, b, c, d) fmaf((a), (b), (c) * (d))
-#else
+// a*b + c*d of the H / b products: two roundings of the products and one of the sum, as the CPU path evaluates them (no FMA)
 #define MAD2(a, b, c, d) ((a) * (b) + (c) * (d))
-#endif
+// returns false if the term is rejected (non-robust kernel and chi2 above threshold)
 template <typename ACC>
 __device__ __forceinline__ bool linearize_term(const float3 rp, const float3 rn, const float3 cp, const float3 cn,
                                                const float* oP, const float* oN, float maxChi2, int robust, const ACC acc) {
@@ -1687,24 +1406,10 @@ __device__ __forceinline__ void block_reduce_store(float* acc, double* out_gener
 // The kernel is latency-bound (index -> point/normal gathers -> information-matrix gathers are dependent loads), so it
 // is software-pipelined by hand as a rolling three-stage loop: indices of pixel j+2, point/normal gathers of pixel j+1,
 // tests + arithmetic of pixel j.  Measured on MI355X: prefetching the 9 information-matrix planes as well costs more
-// in occupancy (174 VGPRs -> 2 waves/SIMD) than it hides (PWN_OMEGA_PREFETCH=1: 13.2 ms vs 9.8 ms per 128x10 pair-iterations).
+// in occupancy (174 VGPRs -> 2 waves/SIMD) than it hides (13.2 ms vs 9.8 ms per 128x10 pair-iterations; docs/experiments.md).
 // grid = (ceil(N / (256*kPixPerThread)), pairs), block = 256.
-#ifndef PWN_OMEGA_PREFETCH
-#define PWN_OMEGA_PREFETCH 0
-#endif
-#ifndef PWN_CL_WAVES
-#define PWN_CL_WAVES 1
-#endif
-// PWN_CL_X (timing experiments only, results are wrong): 1 = no information-matrix loads, 2 = no reference-normal gather,
-// 4 = the reference index comes from the converter's index image in every iteration (no z-buffer word, coherent reference gathers)
-#ifndef PWN_CL_X
-#define PWN_CL_X 0
-#endif
 struct Candidate {
   float4 rP, rN, cP, cN;
-#if PWN_OMEGA_PREFETCH
-  float oP[9];
-#endif
   int ci;
   bool valid;
 };
@@ -1735,16 +1440,8 @@ __device__ __forceinline__ void candidate_load(const PairPtrs& q, int ri, int ci
   if (c.valid) {
     // 12 + 16 bytes per side; the rest of the pass keeps the (point, curvature) / (normal, -) records it was written for
     c.rP = load_xyz(q.refP, (unsigned)ri); c.cP = load_xyz(q.curP, (unsigned)ci); c.cN = load4(q.curN + (unsigned)ci);
-#if PWN_CL_X & 2
-    c.rN = c.cN;
-#else
     c.rN = load4(q.refN + (unsigned)ri);
-#endif
     c.rP.w = c.rN.w; c.cP.w = c.cN.w;
-#if PWN_OMEGA_PREFETCH
-#pragma unroll
-    for (int k = 0; k < 9; ++k) c.oP[k] = q.curOm[om_at(q.cap, (unsigned)ci, k)];      // experiment switch: exact9 clouds only
-#endif
   }
 }
 template <bool SAME_T, bool SYM, typename ACC>
@@ -1769,18 +1466,9 @@ __device__ __forceinline__ void candidate_consume(const PairDesc& pd, const Pair
   }
   if (!SAME_T) { rp = iso_point(Tl, c.rP); rn = iso_normal(Tl, c.rN); }   // inner iterations > 0: the linearizer's transform moved on
   float oP[9];
-#if PWN_OMEGA_PREFETCH
-#pragma unroll
-  for (int k = 0; k < 9; ++k) oP[k] = c.oP[k];
-#else
   {
     const size_t cap = (size_t)q.cap;
     const unsigned ci = (unsigned)c.ci;
-#if PWN_CL_X & 1
-    (void)cap; (void)ci;
-#pragma unroll
-    for (int k = 0; k < 9; ++k) oP[k] = oN[k] * 10.f;
-#else
     if (SYM) {                            // sym6 storage: two 12-byte loads, the lower triangle mirrored in registers (no extra VALU)
       const v3f_raw r0 = *(gptr<const v3f>)(q.curOm + 3u * ci);
       const v3f_raw r1 = *(gptr<const v3f>)(q.curOm + 3u * cap + 3u * ci);
@@ -1792,38 +1480,24 @@ __device__ __forceinline__ void candidate_consume(const PairDesc& pd, const Pair
         oP[3 * r3] = rw.x; oP[3 * r3 + 1] = rw.y; oP[3 * r3 + 2] = rw.z;
       }
     }
-#endif
   }
-#endif
   if (linearize_term(rp, rn, make_float3(c.cP.x, c.cP.y, c.cP.z), make_float3(c.cN.x, c.cN.y, c.cN.z), oP, oN, ap.maxChi2, ap.robust, acc))
     cnt[2] += 1.f;
 }
 // usePrevTc: the acceptance tests run with the previous outer iteration's transform (Aligner::_computeStatistics re-linearizes
 // the finder's existing correspondences at the final transform, aligner.cpp:165-170).
 template <bool SAME_T, bool FULL_H, bool SYM = false, int PPT = kPixPerThread>
-#ifdef PWN_CL_WAVES_EU
-#define PWN_CL_EU_ATTR __attribute__((amdgpu_waves_per_eu(PWN_CL_WAVES_EU, PWN_CL_WAVES_EU)))
-#else
-#define PWN_CL_EU_ATTR
-#endif
-__global__ void PWN_CL_EU_ATTR __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_corr_linearize(const PairDesc* __restrict__ pairs, AlignParams ap, unsigned tag, int usePrevTc, int ownRefIndex) {
+__global__ void __launch_bounds__(kAlignBlock, 1) k_corr_linearize(const PairDesc* __restrict__ pairs, AlignParams ap, unsigned tag, int usePrevTc, int ownRefIndex) {
   const PairDesc& pd = pairs[blockIdx.y];
   const int N = ap.rows * ap.cols;
   const PairState* stp = pd.state;
   const Mat4 Tc = uniform_iso_global(as_global((const float*)(usePrevTc ? stp->invTcorrPrev.m : stp->invTcorr.m)));
   const Mat4 Tl = uniform_iso_global(as_global((const float*)stp->invT.m));
-#if PWN_LDS_ACC
   constexpr int kSlots = LdsAcc<FULL_H>::kSlots;
   __shared__ float lacc[kSlots * kAlignBlock];        // float sums of the thread in column threadIdx.x (bank-conflict free)
 #pragma unroll
   for (int k = 0; k < kSlots; ++k) lacc[k * kAlignBlock + threadIdx.x] = 0.f;
   const LdsAcc<FULL_H> sums = { &lacc[threadIdx.x] };
-#else
-  float acc[kAccN];
-#pragma unroll
-  for (int k = 0; k < kAccN; ++k) acc[k] = 0.f;
-  const RegAcc sums = { acc };
-#endif
   __shared__ float omNtab[27];
   if (threadIdx.x < 27) omNtab[threadIdx.x] = threadIdx.x < 9 ? 0.f : pd.cur.omN[(threadIdx.x - 9) / 9][(threadIdx.x - 9) % 9];
   __syncthreads();
@@ -1835,11 +1509,7 @@ __global__ void PWN_CL_EU_ATTR __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_co
     const int pix = pix0 + j * kAlignBlock;
     ri = -1; ci = -1;
     if (j < PPT && pix < N) {
-#if PWN_CL_X & 4
-      ri = q.refidx0 ? q.refidx0[(unsigned)pix] : z32_index(q.zref[(unsigned)pix], tag);
-#else
       ri = ownRefIndex ? q.refidx0[(unsigned)pix] : z32_index(q.zref[(unsigned)pix], tag);      // wave-uniform choice
-#endif
       ci = q.curidx[(unsigned)pix];
     }
   };
@@ -1855,12 +1525,10 @@ __global__ void PWN_CL_EU_ATTR __launch_bounds__(kAlignBlock, PWN_CL_WAVES) k_co
     load_indices(j + 2, ri2, ci2);                        // indices of pixel j+2
     candidate_consume<SAME_T, SYM>(pd, q, ap, Tc, Tl, cur, sums, cnt, omNtab);
   }
-#if PWN_LDS_ACC
   float acc[kAccN];
 #pragma unroll
   for (int k = 0; k < 34; ++k)
     acc[k] = (FULL_H || !acc_is_upper(k)) ? lacc[(FULL_H ? k : acc_slot_lower(k)) * kAlignBlock + threadIdx.x] : 0.f;
-#endif
   acc[36] = cnt[0]; acc[35] = cnt[1]; acc[34] = cnt[2];
   block_reduce_store<FULL_H>(acc, pd.partials + (size_t)blockIdx.x * kAccN);
 }
@@ -2007,6 +1675,12 @@ __global__ void __launch_bounds__(kAlignBlock) k_linearize_list(CloudDev ref, Cl
 // mask && diff < threshold, sum of diff.  Every surviving diff is a multiple of 1/64 (or < 2^-120), so the sum is kept
 // exactly in 1/64 fixed point with integer atomics -> bitwise reproducible.  out[pair] = {nonZeros, inliers, sum64, tiny}.
 struct MatchAcc { unsigned long long nonZeros, inliers; long long sum64; unsigned long long tiny; };
+// sum of the masked differences / nonZeros (pwn_matcher_base.cpp:179; 0/0 = NaN like the reference): the sum is exact in 1/64 units; values
+// below 2^-120 only matter when nothing else was added.  One expression for the host (pwn_hip_match_result) and the device (result records).
+__host__ __device__ __forceinline__ float match_reprojection_distance(const MatchAcc& a) {
+  const double sum = a.sum64 ? (double)a.sum64 / 64.0 : (double)a.tiny * 1e-37;
+  return (float)sum / (float)(int)a.nonZeros;
+}
 __device__ __forceinline__ unsigned short depth_to_u16(float d, float scale) { return (d < FLT_MAX) ? (unsigned short)(scale * d) : (unsigned short)0; }
 // curOwn: the current cloud was not projected (batch path, identity current offset): its depth image is read off the cloud through its
 // own index image -- pixel -> point -> z.  With an identity offset the projector's depth is the point's z bit for bit (row 2 of K*R
@@ -2063,10 +1737,7 @@ __device__ __forceinline__ void reduce_partials(const double* partials, int nblo
     int b = s;
     // up to kRW independent loads in flight, then the adds in block order (one pair at VGA: 150 records, 38 per wave: ONE memory round trip;
     // with 32 + a remainder loop it was three).  Records past the end are neither loaded nor added: the sum is the same chain as before.
-#ifndef PWN_REDUCE_WIDTH
-#define PWN_REDUCE_WIDTH 40
-#endif
-    constexpr int kRW = PWN_REDUCE_WIDTH;
+    constexpr int kRW = 40;
     for (; b < nblocks; b += 4 * kRW) {
       double v[kRW];
 #pragma unroll
@@ -2097,9 +1768,6 @@ __device__ __forceinline__ void assemble_Hb(const double* s, float* H, float* b)
 #pragma unroll
   for (int i = 0; i < 3; ++i) { b[i] = (float)s[27 + i]; b[i + 3] = (float)s[30 + i]; }
 }
-#ifndef PWN_SOLVE_X
-#define PWN_SOLVE_X 0     // timing experiments only (results wrong): 1 = no LDLT, 2 = no end-of-iteration pose clean-up, 4 = first partial record only
-#endif
 // The step is written out in the kernel, on registers with constant indices only.  (Round 3 had it as a pure function returning the new state in a
 // struct, for two experiments that evaluated it inside other kernels: the struct cost the kernel 29 VGPRs, 68 bytes of scratch and a 16 KB
 // LDS-promoted array, and a 64-pair launch 18 us instead of 10.5 -- found in the v14 kernel trace and undone.)
@@ -2108,7 +1776,7 @@ __device__ __forceinline__ void assemble_Hb(const double* s, float* H, float* b)
 __global__ void __launch_bounds__(256) k_solve_update(const PairDesc* __restrict__ pairs, AlignParams ap, int nblocks, int outerEnd, int last) {
   const PairDesc& pd = pairs[blockIdx.x];
   __shared__ double sums[kAccN];
-  reduce_partials(pd.partials, (PWN_SOLVE_X & 4) ? 1 : nblocks, sums);
+  reduce_partials(pd.partials, nblocks, sums);
   if (threadIdx.x != 0) return;
   PairState& st = *pd.state;
   PairState* const so = pd.state_out;
@@ -2130,16 +1798,11 @@ __global__ void __launch_bounds__(256) k_solve_update(const PairDesc* __restrict
   float nb[6], dx[6];
 #pragma unroll
   for (int d = 0; d < 6; ++d) nb[d] = -b[d];
-#if PWN_SOLVE_X & 1
-#pragma unroll
-  for (int d = 0; d < 6; ++d) dx[d] = nb[d] / H[d + 6 * d];
-#else
   ldlt_solve6(H, nb, dx);
-#endif
   Mat4 invT = st.invT;
   set_last_row(invT);
   invT = iso_mul(v2t(dx), invT);
-  if (outerEnd && !(PWN_SOLVE_X & 2)) {
+  if (outerEnd) {
     Mat4 T = iso_inverse(invT);
     float v[6];
     t2v(T, v);
@@ -2164,13 +1827,25 @@ __global__ void __launch_bounds__(256) k_solve_update(const PairDesc* __restrict
 //   [20:30] chi2_i  [30:40] inliers_i  [40:50] C_i  [50:60] K_i (first 10 iterations)  [60] M_ref  [61] M_cur  [62] iterations in the traces  [63] 0
 // written on the device from the pair's state, so that a gather of records needs no trip through the host.  Counts travel as float
 // (exact below 2^24).  grid = pairs, block = 64
-constexpr int kRecordFloats = 64, kRecordTrace = 10;
-__global__ void __launch_bounds__(64) k_pack_records(const PairDesc* __restrict__ pairs, const int* __restrict__ pair_ids, int first_id, float* __restrict__ out) {
+// match != nullptr: a record has kMatchRecordFloats words, [64:68] = PwnMatcherBase::MatcherResult's image fields of the pair (nonZeros, outliers,
+// inliers, reprojection distance: pwn_matcher_base.cpp:175-181) from its MatchAcc, [68:72] = 0.  block = 64, or 128 for the long records.
+constexpr int kRecordFloats = 64, kRecordTrace = 10, kMatchRecordFloats = 72;
+__global__ void __launch_bounds__(128) k_pack_records(const PairDesc* __restrict__ pairs, const int* __restrict__ pair_ids, int first_id, float* __restrict__ out,
+                                                      const MatchAcc* __restrict__ match) {
   const PairDesc& pd = pairs[blockIdx.x];
   const PairState& st = *pd.state;
   const int t = threadIdx.x, it = st.it, m = it < kRecordTrace ? it : kRecordTrace;
+  const int len = match ? kMatchRecordFloats : kRecordFloats;
+  if (t >= len) return;
   float v = 0.f;
-  if (t < 16) v = st.T.m[t];
+  if (t >= kRecordFloats) {
+    const MatchAcc a = match[blockIdx.x];
+    if (t == 64) v = (float)(int)a.nonZeros;
+    else if (t == 65) v = (float)((int)a.nonZeros - (int)a.inliers);
+    else if (t == 66) v = (float)(int)a.inliers;
+    else if (t == 67) v = match_reprojection_distance(a);
+  }
+  else if (t < 16) v = st.T.m[t];
   else if (t == 16) v = it > 0 ? st.chi2[it - 1] : 0.f;
   else if (t == 17) v = it > 0 ? (float)st.inliers[it - 1] : 0.f;
   else if (t == 18) v = (float)it;
@@ -2182,7 +1857,7 @@ __global__ void __launch_bounds__(64) k_pack_records(const PairDesc* __restrict_
   else if (t == 60) v = (float)*pd.ref.count;
   else if (t == 61) v = (float)*pd.cur.count;
   else if (t == 62) v = (float)m;
-  out[(size_t)blockIdx.x * kRecordFloats + t] = v;
+  out[(size_t)blockIdx.x * len + t] = v;
 }
 // reduction only, one record per pair (Aligner::_computeStatistics' 11th update).  grid = pairs, block = 256
 __global__ void __launch_bounds__(256) k_reduce_pairs(const PairDesc* __restrict__ pairs, int nblocks, SolveOut* __restrict__ out) {

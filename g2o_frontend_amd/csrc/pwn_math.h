@@ -297,17 +297,11 @@ PWN_HD void eig3_direct(float a00, float a10, float a20, float a11, float a21, f
     const float rho = sqrtf(a_over_3);
     // The three trig calls: fixed double-precision algorithms rounded once to float (see pwn_atan2_pos): the same bits on the host and on
     // the device, a third of the instructions of the ocml double routines (this kernel is VALU-bound).
-#ifdef PWN_TRIG_LIBM_DOUBLE       /* the previous canonical form: libm / ocml double routines rounded to float */
-    const float theta = (float)atan2((double)sqrtf(q), (double)half_b) * s_inv3;
-    const float cos_theta = (float)cos((double)theta);
-    const float sin_theta = (float)sin((double)theta);
-#else
     const float theta = (float)pwn_atan2_pos((double)sqrtf(q), (double)half_b) * s_inv3;
     double sd, cd;
     pwn_sincos_small((double)theta, sd, cd);
     const float cos_theta = (float)cd;
     const float sin_theta = (float)sd;
-#endif
     e[0] = c2_over_3 - rho * (cos_theta + s_sqrt3 * sin_theta);
     e[1] = c2_over_3 - rho * (cos_theta - s_sqrt3 * sin_theta);
     e[2] = c2_over_3 + 2.0f * rho * cos_theta;

@@ -100,6 +100,7 @@ class Context {
   // PWN_HIP_OMEGA_EXACT9 (default) / PWN_HIP_OMEGA_SYM6: storage of the point information matrices of clouds created from now on
   void setOmegaStorage(int mode) { check(pwn_hip_ctx_set_omega_storage(_ctx, mode)); }
   void synchronize() { check(pwn_hip_ctx_synchronize(_ctx)); }
+  void waitStream(void* hipStream) { check(pwn_hip_ctx_wait_stream(_ctx, hipStream)); }      // what the context queues from now on runs after that stream's work
  private:
   pwn_hip_ctx* _ctx = nullptr;
 };
@@ -136,6 +137,10 @@ class Cloud {
     return pwn_hip_cloud_save(_ctx->handle(), _h, filename, T.data(), step, binary ? 1 : 0) == PWN_HIP_OK;
   }
   bool load(Isometry3f& T, const char* filename) { return pwn_hip_cloud_load(_ctx->handle(), _h, filename, T.data()) == PWN_HIP_OK; }
+  // the cloud as one flat buffer, host or device (replication to the other GPUs of a node: pwn_closer.cpp:85-111; include/pwn_hip.h)
+  size_t flatSize() const { size_t w = 0; _ctx->check(pwn_hip_cloud_export(_ctx->handle(), _h, nullptr, 0, &w)); return w; }
+  size_t exportFlat(void* dst, size_t bytes) const { size_t w = 0; _ctx->check(pwn_hip_cloud_export(_ctx->handle(), _h, dst, bytes, &w)); return w; }
+  void importFlat(const void* src, size_t bytes) { _ctx->check(pwn_hip_cloud_import(_ctx->handle(), _h, src, bytes)); }
   size_t numGaussians() const { int n = 0; _ctx->check(pwn_hip_cloud_num_gaussians(_ctx->handle(), _h, &n)); return (size_t)n; }
   Context* context() const { return _ctx; }
  private:
@@ -623,6 +628,30 @@ struct PwnMatcherBase {
     const std::vector<pwn_hip_align_result> r = _aligner->alignBatch(fromClouds, toClouds, g, &scores, _frameInlierDepthThreshold);
     results.resize(r.size());
     for (size_t i = 0; i < r.size(); ++i) fill(results[i], r[i], scores[i]);
+  }
+  // the same call with the results (also) leaving as PWN_HIP_MATCH_RECORD_FLOATS-float records, device or host: what the ranks of a sharded
+  // processPartition exchange.  pairIds may be empty (record i then carries firstPairId + i).
+  void matchCloudsBatchRecords(float* records, const std::vector<Cloud*>& fromClouds, const std::vector<Cloud*>& toClouds,
+                               const Isometry3f& fromOffset, const Isometry3f& toOffset, const Matrix3f& toCameraMatrix, int toRows, int toCols,
+                               const std::vector<Isometry3f>& initialGuesses = std::vector<Isometry3f>(), const std::vector<int>& pairIds = std::vector<int>(),
+                               int firstPairId = 0, std::vector<MatcherResult>* results = nullptr) {
+    configure(fromOffset, toOffset, toCameraMatrix, toRows, toCols, Isometry3f::Identity());
+    const int n = (int)fromClouds.size();
+    std::vector<float> g((size_t)n * 16);
+    for (int i = 0; i < n; ++i) {
+      Isometry3f t; if (!initialGuesses.empty()) t = initialGuesses[(size_t)i];
+      t(2,3) = 0.f; t.forceLastRow();
+      std::memcpy(&g[(size_t)i * 16], t.data(), 16 * sizeof(float));
+    }
+    std::vector<pwn_hip_cloud*> r((size_t)n), c((size_t)n);
+    for (int i = 0; i < n; ++i) { r[(size_t)i] = fromClouds[(size_t)i]->handle(); c[(size_t)i] = toClouds[(size_t)i]->handle(); }
+    std::vector<pwn_hip_align_result> res(results ? (size_t)n : 0);
+    std::vector<pwn_hip_match_result> sc(results ? (size_t)n : 0);
+    const pwn_hip_aligner_params p = _aligner->params();
+    _ctx->check(pwn_hip_match_batch_records(_ctx->handle(), &p, n, r.data(), c.data(), g.data(), _frameInlierDepthThreshold,
+                                            pairIds.empty() ? nullptr : pairIds.data(), firstPairId, results ? res.data() : nullptr,
+                                            results ? sc.data() : nullptr, records));
+    if (results) { results->resize((size_t)n); for (int i = 0; i < n; ++i) fill((*results)[(size_t)i], res[(size_t)i], sc[(size_t)i]); }
   }
   int numCalls = 0;
  protected:

@@ -139,6 +139,15 @@ int pwn_hip_ctx_destroy(pwn_hip_ctx* ctx);                       /* cf. destroyC
 /* hip_stream: a hipStream_t (e.g. torch.cuda.current_stream().cuda_stream); NULL = the context's own stream */
 int pwn_hip_ctx_set_stream(pwn_hip_ctx* ctx, void* hip_stream);
 int pwn_hip_ctx_synchronize(pwn_hip_ctx* ctx);
+/* Ordering against a stream of the caller (hip_stream: a hipStream_t, NULL = the legacy default stream): everything the context queues from
+ * now on runs after the work that stream holds now.  The context runs its kernels on non-blocking streams of its own, so device buffers that
+ * the caller's streams touch are NOT ordered against it by themselves.  Two cases need this call:
+ *   - a device buffer the context WRITES call after call (the `records` of the *_records entry points) is still being READ on the caller's
+ *     stream (an all-gather of step k while step k+1 packs its records): call it after queueing the reader, before the next writing call;
+ *   - a device buffer the caller's stream WRITES (a broadcast that receives a flat cloud, a kernel that fills frames) is READ by the next call
+ *     (pwn_hip_cloud_import, convert*): call it after queueing the writer.
+ * The other direction needs nothing: every call is complete on return (outputs valid), pwn_hip_copy_async excepted (see there). */
+int pwn_hip_ctx_wait_stream(pwn_hip_ctx* ctx, void* hip_stream);
 /* Batch calls are executed in sub-batches of at most this many frames / pairs (default 64, capped by
  * max_batch), which bounds the workspace the temporaries (integral images, z-buffers) need.  Measured on
  * MI355X: larger sub-batches are faster (fewer, fuller launches) -- as long as every stream has one: a call of
@@ -219,6 +228,22 @@ int pwn_hip_cloud_download_stats(pwn_hip_ctx* ctx, const pwn_hip_cloud* cloud, f
 /* Cloud::transformInPlace (cloud.cpp:173-186): points, normals, both information matrices (T Omega T^t, informationmatrix.h:111-121), the
  * Stats when the cloud carries them (m * S, stats.h:125-131) and the Gaussians (gaussian3.h:65-73); skipped when T is the identity (:176) */
 int pwn_hip_cloud_transform_in_place(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud, const float T[16]);
+/* A cloud as ONE flat buffer, host or device: what replicates a cloud to the other GPUs of a node.  PwnCloser::processPartition
+ * (pwn_tracker/pwn_closer.cpp:85-111) matches the cloud of ONE `current` frame against every cached cloud of the other partition; sharded over
+ * GPUs, the others stay where they were converted and `current` travels ("replicate current's cloud to all GPUs; one
+ * broadcast") -- export on the rank that converted it, one broadcast of the buffer, import on every rank.  The reference's own whole-cloud
+ * form is Cloud::save / load (cloud.cpp:11-136; pwn_hip_cloud_save / _load), which goes through a file and drops the information matrices.
+ * Content: 256-byte header, points (12 B), normal + curvature (16 B), the point information matrices as stored (exact9 / sym6), the class
+ * matrices of the normal information matrix (or its full planes for uploaded clouds), and the converter's index image with the projector it
+ * belongs to when the cloud carries one (so that an imported cloud takes the same projection shortcuts as the original: bitwise the same
+ * alignments).  Not carried: Stats, Gaussians (the scene stage's data; Aligner::align reads neither).
+ * export_bound: buffer size that holds any cloud of that capacity.  export: *written (optional) = bytes used; PWN_HIP_ERR_CAPACITY when
+ * dst_bytes is too small (*written then = bytes needed); dst = NULL: size query only.  import: the destination cloud must have been created with
+ * the same omega storage and capacity >= the flat cloud's points.  Both are complete on return; with device buffers that another stream
+ * produces / consumes see pwn_hip_ctx_wait_stream. */
+size_t pwn_hip_cloud_export_bound(int capacity, int omega_storage, int index_pixels, int with_omega_n);
+int pwn_hip_cloud_export(pwn_hip_ctx* ctx, const pwn_hip_cloud* cloud, void* dst, size_t dst_bytes, size_t* written);
+int pwn_hip_cloud_import(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud, const void* src, size_t src_bytes);
 
 /* ------------------------------------------------------------------ input conditioning ------- */
 /* DepthImage_convert_16UC1_to_32FC1 (pwn_static.cpp:54-68) */
@@ -326,11 +351,24 @@ int pwn_hip_align_batch_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, in
  *   [60] points of the reference cloud   [61] of the current cloud   [62] iterations carried in the traces   [63] 0
  * Counts travel as float (exact below 2^24).  The records are written by a kernel from the pairs' device state: `records` may be a DEVICE
  * buffer (n * PWN_HIP_RECORD_FLOATS floats; e.g. the tensor an all-gather sends -- no trip through the host) or host memory.
- * pair_ids (host, may be NULL: then record i carries first_pair_id + i).  results may be NULL when only the records are wanted. */
+ * pair_ids (host, may be NULL: then record i carries first_pair_id + i).  results may be NULL when only the records are wanted.
+ * ORDERING: the kernel writes a device `records` buffer on the context's own stream.  If a stream of the caller still reads the buffer from
+ * the previous call (an all-gather queued after it), call pwn_hip_ctx_wait_stream(ctx, that stream) before this call -- or alternate two buffers. */
 #define PWN_HIP_RECORD_FLOATS 64
 int pwn_hip_align_batch_records(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* references,
                                 pwn_hip_cloud* const* currents, const float* initial_guesses, const int* pair_ids, int first_pair_id,
                                 pwn_hip_align_result* results, float* records);
+/* pwn_hip_match_batch whose results (also) leave as records of PWN_HIP_MATCH_RECORD_FLOATS floats (288 bytes): the 64 words of the alignment
+ * record, then PwnMatcherBase::MatcherResult's image fields (pwn_tracker/pwn_matcher_base.cpp:175-181)
+ *   [64] image_nonZeros   [65] image_outliers   [66] image_inliers   [67] image_reprojectionDistance   [68:72] 0
+ * -- everything PwnCloser::matchFrames thresholds and stores in a PwnCloserRelation (pwn_closer.cpp:138-151), written on the device.  `records`:
+ * device or host, n * PWN_HIP_MATCH_RECORD_FLOATS floats; results and scores may be NULL.  A device `records` buffer that another stream still
+ * reads from the previous call: pwn_hip_ctx_wait_stream. */
+#define PWN_HIP_MATCH_RECORD_FLOATS 72
+int pwn_hip_match_batch_records(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* references,
+                                pwn_hip_cloud* const* currents, const float* initial_guesses, float frame_inlier_depth_threshold,
+                                const int* pair_ids, int first_pair_id, pwn_hip_align_result* results, pwn_hip_match_result* scores,
+                                float* records);
 /* One candidate batch from raw frames as ONE submission: per pair i, DepthImageConverter::compute of ref_frames[i] -> references[i] and
  * cur_frames[i] -> currents[i] (PwnMatcherBase::makeCloud, pwn_matcher_base.cpp:77-85), then Aligner::align of the pair
  * (pwn_matcher_base.cpp:120-128).  The conversion of a sub-batch's frames is queued in front of its alignment on the same stream, so one
@@ -397,7 +435,7 @@ void pwn_hip_t2v(const float T[16], float v[6]);
  * function k_solve_update runs on the device */
 void pwn_hip_ldlt_solve6(const float H[36], const float b[6], float x[6]);
 /* per-kernel device time (ms) of the stages of the last batch/single call, for bench.py:
- * names: "unproject","integral","integral_rows","integral_cols","stats","convert_fused","project_cur","project_ref","corr_linearize","solve",
+ * names: "unproject","integral","integral_rows","integral_cols","stats","project_cur","project_ref","corr_linearize","solve",
  * "statistics","match_score" ("project": the stand-alone pwn_hip_project).  launches = timed launch groups (one per sub-batch). */
 int pwn_hip_last_stage_ms(pwn_hip_ctx* ctx, const char* stage, float* ms, int* launches);
 /* what this GPU's HBM delivers, for the roofline report (SURVEY 8(d) asks for the measured figure next to the 8 TB/s spec):

@@ -156,7 +156,7 @@ def test_records_crc_gate(tmp_path, monkeypatch):
     sys.path.insert(0, ROOT)
     import bench
     rec = np.arange(5 * 20, dtype=np.float32).reshape(5, 20)
-    monkeypatch.setattr(bench, "RECORDS_CRC_FILE", str(tmp_path / "records_crc.json"))
+    monkeypatch.setattr(bench, "CRC_DIR", str(tmp_path))
     assert bench.check_records_crc(rec, 480, 640)["checked"] == 0                     # no file yet
     w = bench.check_records_crc(rec, 480, 640, write=True)
     assert w["checked"] == 5 and w["equal"] and w["file_is_for_these_kernels"]
@@ -165,6 +165,11 @@ def test_records_crc_gate(tmp_path, monkeypatch):
     r = bench.check_records_crc(bad, 480, 640)
     assert not r["equal"] and r["first_mismatch"] == 2 and r["mismatches"] == 1
     assert bench.check_records_crc(rec, 960, 1280)["checked"] == 0                    # another frame size: not comparable
+    # one file per (workload, omega storage): the other three combinations do not see the one just written
+    assert bench.check_records_crc(rec, 480, 640, omega_storage="sym6")["checked"] == 0
+    assert bench.check_records_crc(rec, 480, 640, mode="partition")["checked"] == 0
+    assert bench.check_records_crc(rec, 480, 640, omega_storage="sym6", mode="partition", write=True)["checked"] == 5
+    assert sorted(os.listdir(tmp_path)) == ["records_crc_pairs_exact9.json", "records_crc_partition_sym6.json"]
 
 
 def test_committed_records_crc_file_belongs_to_the_committed_kernels():
@@ -176,3 +181,25 @@ def test_committed_records_crc_file_belongs_to_the_committed_kernels():
     ref = json.load(open(bench.RECORDS_CRC_FILE))
     assert ref["kernel_source_digest"] == bench.kernel_source_digest(), "regenerate profiles/records_crc.json (see profiles/README.md)"
     assert ref["pairs"] == 1024 and len(ref["crc32"]) == 1024 and (ref["rows"], ref["cols"]) == (480, 640)
+
+
+def test_partition_mode_byte_plumbing_world_2_and_8_gloo():
+    """bench.py --mode partition (SURVEY.md 8(e): PwnCloser::processPartition sharded, `current` replicated by one broadcast) with the CPU dry run:
+    launcher -> ranks -> a flat-cloud-sized byte pattern broadcast from rank 0 and checked on every rank -> 72-float match records (alignment
+    record + the four score words) all-gathered and assembled by pair id.  World 2 and world 8 assemble the records of the one-rank run."""
+    def run(n, pairs):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--dry-run-cpu", "--mode", "partition", "--total-pairs", str(pairs)],
+                             capture_output=True, text=True, timeout=300, env=dict(os.environ, PWN_BENCH_NO_AFFINITY="1"))
+        assert out.returncode == 0, out.stderr[-1500:]
+        return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    one, two, eight = run(1, 24), run(2, 24), run(8, 24)
+    for r, n in ((one, 1), (two, 2), (eight, 8)):
+        assert r["mode"] == "partition" and r["n_gpus"] == n and r["records"] == 24 and r["records_ok"] is True and r["flat_cloud_broadcast_ok"] is True
+    assert one["records_crc_all"] == two["records_crc_all"] == eight["records_crc_all"]
+
+
+def test_host_cpu_info_names_what_cores_means():
+    import bench
+    info = bench.host_cpu_info()
+    assert info["logical_cpus"] >= 1 and 1 <= info["physical_cores"] <= info["logical_cpus"] and isinstance(info["smt"], bool)
+    assert "cgroup_cpu_quota" in info

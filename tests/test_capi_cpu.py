@@ -303,3 +303,17 @@ def test_kernel_resources_of_the_hot_and_the_serial_kernels():
         assert r["vgpr"] <= 64, (name, r)
     for name, r in one(r"16k_corr_linearizeILb1ELb0E"):
         assert r["vgpr"] <= 102, (name, r)
+
+
+def test_product_sources_carry_no_compile_time_or_environment_switches():
+    """The kernels' bit-exactness is the product: the sources under g2o_frontend_amd/csrc hold no `#if` / `#ifdef` / `#ifndef` block (round 4's
+    header had 38, several of them timing experiments that produce wrong results when defined) and read no environment variable; the build
+    passes no -D flag.  Experiments live in history and in docs/experiments.md."""
+    from g2o_frontend_amd import build
+    d = os.path.join(ROOT, "g2o_frontend_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        text = open(os.path.join(d, f)).read()
+        for n, line in enumerate(text.splitlines(), 1):
+            assert not re.match(r"\s*#\s*(if|ifdef|ifndef|elif|else|endif)\b", line), (f, n, line)
+        assert "getenv" not in text, f
+    assert not [x for x in build.FLAGS if x.startswith("-D")]

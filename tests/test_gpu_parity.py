@@ -644,22 +644,6 @@ def test_odd_image_sizes(oracle, rows, cols):
         converter.computeBatch(many, [ref_mm, cur_mm] * 13, raw_scale=0.001)
         for k in (0, 1, 24, 25):
             same((oref if k % 2 == 0 else ocur).arrays(), many[k].arrays())
-        # the opt-in fused converter (planes in a 128-row ring, producers and consumers in one launch) at the same odd size: partial strips,
-        # partial bands, rings that wrap (rows > 128) or never wrap (rows < 128)
-        os.environ["PWN_FUSED_CONVERT"] = "1"
-        try:
-            fctx = api.Context(0, rows, cols, 32)
-        finally:
-            del os.environ["PWN_FUSED_CONVERT"]
-        _, fconv, _ = gpu_objects(fctx, "small")
-        fconv.projector().setCameraMatrix([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]]); fconv.projector().setImageSize(rows, cols)
-        fused = [api.Cloud(fctx, rows * cols) for _ in range(21)]
-        fctx.set_profiling(True)
-        fconv.computeBatch(fused, ([ref_mm, cur_mm] * 11)[:21], raw_scale=0.001)
-        assert fctx.stage_ms("convert_fused")[1] == 1
-        for k in (0, 1, 19, 20):
-            same((oref if k % 2 == 0 else ocur).arrays(), fused[k].arrays())
-        fctx.close()
         if len(oref) == 0 or len(ocur) == 0:
             return
         ap = oracle.aligner_params(rows, cols, K=K, accumulate_fp64=1, **alig)

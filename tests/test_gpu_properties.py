@@ -193,37 +193,6 @@ def test_measured_hbm_bandwidth_is_sane(world):
 
 
 
-def test_fused_converter_is_bit_identical_to_the_two_kernel_path(world, monkeypatch):
-    """k_convert_fused (PWN_FUSED_CONVERT=1, opt-in: producers and consumers of a frame in one launch, integral planes in a ring that never
-    travels to HBM) against the product path (k_unproject_integral + k_stats) on a 24-frame batch and on a batch that is not a multiple of
-    eight frames: every cloud array and the index images bit for bit, and the alignments that follow."""
-    from g2o_frontend_amd import api
-    from test_gpu_parity import gpu_objects
-    rows, cols = world["rows"], world["cols"]
-    frames = [p[0] for p in world["pairs"]] + [p[1] for p in world["pairs"]]                # 24 uint16 frames
-    monkeypatch.setenv("PWN_FUSED_CONVERT", "1")
-    ctx = api.Context(0, rows, cols, 32)                                                    # the switch is read when the context is created
-    monkeypatch.delenv("PWN_FUSED_CONVERT")
-    _, converter, aligner = gpu_objects(ctx, "vga")
-    for n in (24, 19):
-        clouds = [api.Cloud(ctx, rows * cols) for _ in range(n)]
-        converter.computeBatch(clouds, frames[:n], raw_scale=0.001)
-        for i in (0, 7, n - 1):
-            ref = (world["refs"] + world["curs"])[i].arrays()
-            got = clouds[i].arrays()
-            for k in ref:
-                assert np.array_equal(ref[k].view(np.uint32), got[k].view(np.uint32)), (n, i, k)
-    ctx.set_profiling(True)
-    clouds = [api.Cloud(ctx, rows * cols) for _ in range(24)]
-    converter.computeBatch(clouds, frames, raw_scale=0.001)
-    assert ctx.stage_ms("convert_fused")[1] == 1 and ctx.stage_ms("stats")[1] == 0          # the fused kernel did run
-    ctx.set_profiling(False)
-    res = aligner.alignBatch(clouds[:12], clouds[12:])
-    base = world["aligner"].alignBatch(world["refs"], world["curs"])
-    assert _digest(res) == _digest(base)
-    ctx.close()
-
-
 def test_pinned_blocks_live_as_long_as_their_views_and_buffers_outlive_their_context():
     """Round-2 advisor findings: (1) a page-locked block (pwn_hip_host_alloc) is released with its LAST numpy view, not by pinned_free while
     views are alive; (2) a DeviceBuffer freed after its context was closed is released (pwn_hip_device_free with a NULL context) instead

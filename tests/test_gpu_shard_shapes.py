@@ -1,5 +1,6 @@
-"""The per-GPU shard shapes of BASELINE configs[3] and configs[4] through the product configuration of bench.py -- one
-`computeBatch` + one `alignBatch` over the whole shard, sub-batches of 64 dealt over two HIP streams -- as -m gpu tests:
+"""The per-GPU shard shapes of BASELINE configs[3] and configs[4] through the two-call sequence -- one `computeBatch` + one `alignBatch` over
+the whole shard, sub-batches of 64 dealt over two HIP streams, exact9 clouds -- as -m gpu tests (the configuration bench.py ships -- sym6 clouds,
+one submission per step, four streams -- has its own oracle test: tests/test_gpu_step.py::test_the_shipped_configuration_against_the_oracle):
 
   * configs[3]: 128 VGA pairs per GPU (the 1024-pair loop-closure batch of pwn_tracker/pwn_closer.cpp:92-111 over 8 GPUs);
   * configs[4]: 32 pairs of 1280x960 per GPU (batch 256 over 8 GPUs).
@@ -44,7 +45,7 @@ def _run_shard(name, seeds, singles, oracle_on, oracle, omega_storage="exact9"):
     rows, cols, K, conv, alig = case_params(name)
     P, N = len(seeds), rows * cols
     pairs = _render(name, seeds)
-    ctx = api.Context(0, rows, cols, 128, omega_storage=omega_storage)                     # 2 streams x 64 slots, as bench.py
+    ctx = api.Context(0, rows, cols, 128, omega_storage=omega_storage)                     # 2 streams x 64 slots
     ctx.set_subbatch(64, 64); ctx.set_concurrency(2)
     _, converter, aligner = gpu_objects(ctx, name)
     frames = [ctx.upload(p[0]) for p in pairs] + [ctx.upload(p[1]) for p in pairs]      # resident uint16 frames, as in the timed region

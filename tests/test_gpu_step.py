@@ -126,6 +126,59 @@ def test_fused_step_vga_against_oracle_sym6(oracle):
     ctx.close()
 
 
+def test_the_shipped_configuration_against_the_oracle(oracle):
+    """The exact configuration bench.py times and reports (BENCH_rNN.json): 128 VGA pairs, omega_storage = sym6, ONE submission per step
+    (pwn_hip_convert_align_batch_u16), the library's default plan (four streams, 4 x 32 pairs), uint16 frames resident on the device, result
+    records packed on the device into a CUDA tensor.  Held against
+      * the oracle on sampled pairs of every sub-batch: converter clouds (sym6 comparison: everything bit for bit but the mirrored lower
+        triangle of Omega_p, 1e-6), every iteration of the oracle's trace re-run from the oracle's iterate (teacher-forced chi2 <= 1e-5 vs the
+        fp64-accumulated oracle, K_i / C_i / inliers_i exact), final pose within 1e-5 of the oracle's own free run;
+      * the two-call path (convert_batch_u16, then align_batch_records) on other clouds: the same records, bit for bit."""
+    import torch
+    from g2o_frontend_amd import api, shard
+    from test_gpu_parity import oracle_params, _check_teacher_forced
+    from test_omega_sym6 import compare_clouds_sym6
+    n = 128
+    ctx, converter, aligner, pairs, refs, curs = _rig("vga", n, 256, omega="sym6")      # 4 streams x 64 slots, as bench.py's context
+    rows, cols, _, _, _ = case_params("vga")
+    ctx.set_subbatch(64, 64); ctx.set_concurrency(4)                                     # bench.py's defaults (--sub-frames 64 --sub-pairs 64 --streams 4)
+    bufs = [torch.from_numpy(p[0].view(np.int16)).cuda() for p in pairs] + [torch.from_numpy(p[1].view(np.int16)).cuda() for p in pairs]
+    rec = torch.full((n, shard.RECORD_FLOATS), -7.0, dtype=torch.float32, device="cuda")
+    ids = np.arange(9000, 9000 + n, dtype=np.int32)
+    prep = aligner.convertAlignHandles(refs, curs, bufs[:n], bufs[n:], converter=converter)
+    ctx.set_profiling(True)
+    got = aligner.convertAlignBatch(converter, None, None, None, None, raw_scale=0.001, records=rec, pair_ids=ids, prepared=prep).copy()
+    launches = ctx.stage_ms("corr_linearize")[1]
+    ctx.set_profiling(False)
+    assert launches == 4 * 10, launches                                                  # the plan the line reports: 4 sub-batches of 32 pairs x 10 iterations
+    rec_fused = rec.cpu().numpy().copy()
+    assert np.array_equal(_bits(rec_fused), _bits(shard.pack_results_raw(got, ids)))
+    # the two-call path on other clouds
+    refs2 = [api.Cloud(ctx, rows * cols) for _ in range(n)]; curs2 = [api.Cloud(ctx, rows * cols) for _ in range(n)]
+    converter.computeBatch(refs2 + curs2, bufs, raw_scale=0.001)
+    rec2 = torch.full((n, shard.RECORD_FLOATS), -3.0, dtype=torch.float32, device="cuda")
+    aligner.alignBatchRecords(refs2, curs2, rec2, pair_ids=ids, want_results=False)
+    assert np.array_equal(_bits(rec2.cpu().numpy()), _bits(rec_fused))
+    # the oracle on one pair of every sub-batch (first, inner, last positions)
+    cp, ap = oracle_params(oracle, "vga", accumulate_fp64=1)
+    worst_chi2 = worst_pose = worst_lower = 0.0
+    for i in (0, 45, 77, 127):
+        oref, _, _ = oracle.convert(cp, oracle.convert_16u_to_32f(pairs[i][0])); ocur, _, _ = oracle.convert(cp, oracle.convert_16u_to_32f(pairs[i][1]))
+        worst_lower = max(worst_lower, compare_clouds_sym6(oref.arrays(), refs[i].arrays()), compare_clouds_sym6(ocur.arrays(), curs[i].arrays()))
+        o = oracle.align(ap, oref, ocur)
+        aligner.setReferenceCloud(refs[i]); aligner.setCurrentCloud(curs[i])
+        worst_chi2 = max(worst_chi2, _check_teacher_forced(aligner, o))                  # asserts 1e-5 and exact counters per iteration
+        it0 = o["iterations"][0]
+        assert (int(got["iter_candidates"][i][0]), int(got["iter_correspondences"][i][0]), int(got["iter_inliers"][i][0])) == (it0["K"], it0["C"], it0["inliers"]), i
+        T = got["T"][i].reshape(4, 4).T
+        d = float(np.abs(T - o["T"]).max()); worst_pose = max(worst_pose, d)
+        assert d <= 1e-5, (i, d)
+        assert int(got["n_reference"][i]) == len(oref) and int(got["n_current"][i]) == len(ocur)
+    print(f"shipped configuration (128 VGA pairs, sym6, one submission, 4 x 32): 4 pairs vs oracle: worst teacher-forced chi2 rel diff {worst_chi2:.1e}, "
+          f"worst |T - T_oracle| {worst_pose:.1e}, mirrored lower triangle within {worst_lower:.1e} of |Omega_p|; records == two-call path bitwise")
+    ctx.close()
+
+
 def test_fused_step_error_paths():
     from g2o_frontend_amd._lib import PwnHipError
     ctx, converter, aligner, pairs, refs, curs = _rig("small", 2, 8)

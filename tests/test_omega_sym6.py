@@ -178,8 +178,9 @@ def test_sym6_teacher_forced_on_disturbed_frames(rig, oracle, seed):
 
 
 def test_sym6_shard_128_vga_pairs_product_configuration(oracle):
-    """bench.py's shard (128 VGA pairs, two streams, sub-batches of 64) with sym6 clouds: every pair converges to the true pose, the batch
-    is bitwise reproducible and equals single alignments, sampled pairs teacher-forced against the oracle"""
+    """The 128-pair VGA shard through the two-call sequence (two streams, sub-batches of 64) with sym6 clouds: every pair converges to the true
+    pose, the batch is bitwise reproducible and equals single alignments, sampled pairs teacher-forced against the oracle.  (bench.py's own
+    step -- one submission, four streams -- is tests/test_gpu_step.py::test_the_shipped_configuration_against_the_oracle.)"""
     import test_gpu_shard_shapes as S
     seeds = list(range(3000, 3128))
     S._run_shard("vga", seeds, singles=(0, 63, 64, 127), oracle_on=(5, 64), oracle=oracle, omega_storage="sym6")

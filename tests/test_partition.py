@@ -1,0 +1,219 @@
+"""SURVEY.md 8(e)'s processPartition mode: one `current` cloud against the cached clouds of the other partition, the clouds sharded over the
+GPUs of a node and `current` replicated by one broadcast (pwn_tracker/pwn_closer.cpp:85-111).
+
+  * the flat form of a cloud (pwn_hip_cloud_export / _import) is the cloud, bit for bit: arrays, index image, projection shortcuts, and
+    therefore every alignment it takes part in -- through device and host buffers, into the same and into another context;
+  * pwn_hip_match_batch_records: the 72-float records written on the device carry what pwn_hip_match_batch returns on the host;
+  * bench.py --mode partition: the line of a one-rank run, and the same run with broadcast + all-gather forced through RCCL (world size 1,
+    rank 0 matching against the REPLICA that travelled through export / broadcast / import): records equal CRC by CRC.
+"""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import case_params, make_depth_pair
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32) if a.dtype.itemsize == 4 else a
+
+
+def _same_cloud(a, b):
+    A, B = a.arrays(), b.arrays()
+    assert a.size() == b.size()
+    for k in A:
+        assert np.array_equal(_bits(A[k]), _bits(B[k])), k
+
+
+@pytest.mark.parametrize("storage", ["exact9", "sym6"])
+def test_flat_cloud_round_trip_is_the_cloud_bit_for_bit(storage):
+    import torch
+    from g2o_frontend_amd import api
+    from test_gpu_parity import gpu_objects
+    name = "small"
+    rows, cols, K, conv, alig = case_params(name)
+    ref, cur, _, _, _ = make_depth_pair(name, 3)
+    ctx = api.Context(0, rows, cols, 4, omega_storage=storage)
+    _, converter, aligner = gpu_objects(ctx, name)
+    N = rows * cols
+    gref, gcur = api.Cloud(ctx, N), api.Cloud(ctx, N)
+    converter.compute(gref, ref); converter.compute(gcur, cur)
+    bound = api.Cloud.flatBound(N, storage, N)
+    assert gref.flatSize() <= bound and gref.flatSize() % 256 == 0
+    # device buffer, same context
+    flat = torch.zeros(bound, dtype=torch.uint8, device="cuda")
+    used = gref.exportFlat(flat)
+    assert used == gref.flatSize()
+    rep = api.Cloud(ctx, N)
+    rep.importFlat(flat)
+    _same_cloud(gref, rep)
+    # host buffer (numpy), exact size
+    host = np.zeros(gcur.flatSize(), np.uint8)
+    assert gcur.exportFlat(host) == host.size
+    rep_cur = api.Cloud(ctx, N)
+    rep_cur.importFlat(host)
+    _same_cloud(gcur, rep_cur)
+    # the bytes themselves: device and host exports of one cloud are the same bytes
+    host2 = np.zeros(used, np.uint8); gref.exportFlat(host2)
+    assert np.array_equal(flat[:used].cpu().numpy(), host2)
+    # alignments: replica in either role, and in both, are bitwise the original's (the replica carries the converter's index image, so it takes
+    # the same projection shortcuts)
+    aligner.setReferenceCloud(gref); aligner.setCurrentCloud(gcur)
+    base = aligner.align()
+    for r, c in ((rep, gcur), (gref, rep_cur), (rep, rep_cur)):
+        aligner.setReferenceCloud(r); aligner.setCurrentCloud(c)
+        g = aligner.align()
+        for k in ("T", "chi2", "C", "K", "iter_inliers"):
+            assert np.array_equal(_bits(g[k]), _bits(base[k])), k
+    batch = aligner.alignBatch([gref, rep, rep], [gcur, gcur, rep_cur])
+    for g in batch:
+        assert np.array_equal(_bits(g["T"]), _bits(base["T"])) and np.array_equal(_bits(g["chi2"]), _bits(base["chi2"]))
+    # another context (what another rank's process does with the broadcast buffer), larger capacity than the cloud needs
+    ctx2 = api.Context(0, rows, cols, 2, omega_storage=storage)
+    _, _, aligner2 = gpu_objects(ctx2, name)
+    far_ref, far_cur = api.Cloud(ctx2, 2 * N), api.Cloud(ctx2, N)
+    far_ref.importFlat(flat); far_cur.importFlat(host)
+    _same_cloud(gref, far_ref); _same_cloud(gcur, far_cur)
+    aligner2.setReferenceCloud(far_ref); aligner2.setCurrentCloud(far_cur)
+    g = aligner2.align()
+    assert np.array_equal(_bits(g["T"]), _bits(base["T"])) and np.array_equal(_bits(g["chi2"]), _bits(base["chi2"]))
+    # errors: short buffers, foreign bytes, the other omega storage, a cloud that is too small
+    with pytest.raises(api.PwnHipError) as e:
+        gref.exportFlat(np.zeros(used - 256, np.uint8))
+    assert e.value.code == 6
+    with pytest.raises(api.PwnHipError):
+        rep.importFlat(np.zeros(4096, np.uint8))
+    with pytest.raises(api.PwnHipError):
+        rep.importFlat(host2[: used - 256])
+    other = "sym6" if storage == "exact9" else "exact9"
+    ctx3 = api.Context(0, rows, cols, 1, omega_storage=other)
+    with pytest.raises(api.PwnHipError):
+        api.Cloud(ctx3, N).importFlat(host2)
+    with pytest.raises(api.PwnHipError) as e:
+        api.Cloud(ctx2, 16).importFlat(host2)
+    assert e.value.code == 6
+    _same_cloud(gref, rep)                       # failed imports above went to other clouds; this one is untouched
+    for c in (ctx3, ctx2, ctx):
+        c.close()
+
+
+def test_flat_cloud_of_an_uploaded_cloud_carries_its_normal_information_planes(oracle):
+    """clouds that did not come from the converter hold full normal information matrices instead of a class (pwn_hip_cloud_upload) and no index image"""
+    from g2o_frontend_amd import api
+    from test_gpu_parity import oracle_params, upload
+    name = "small"
+    rows, cols, _, _, _ = case_params(name)
+    ref, _, _, _, _ = make_depth_pair(name, 2)
+    cp, _ = oracle_params(oracle, name)
+    oref, _, _ = oracle.convert(cp, ref)
+    ctx = api.Context(0, rows, cols, 1)
+    up = upload(ctx, oref)
+    buf = np.zeros(up.flatSize(), np.uint8)
+    up.exportFlat(buf)
+    rep = api.Cloud(ctx, rows * cols)
+    rep.importFlat(buf)
+    _same_cloud(up, rep)
+    ctx.close()
+
+
+def test_match_batch_records_carry_the_matcher_results():
+    import torch
+    from g2o_frontend_amd import api
+    from test_gpu_parity import gpu_objects
+    sys.path.insert(0, ROOT)
+    import bench
+    name = "small"
+    rows, cols, K, conv, alig = case_params(name)
+    from g2o_frontend_amd import synth
+    ctx = api.Context(0, rows, cols, 16)
+    _, converter, aligner = gpu_objects(ctx, name)
+    alproj = api.PinholePointProjector(); alproj.setMinDistance(alig["min_distance"]); alproj.setMaxDistance(alig["max_distance"])
+    aligner.setProjector(alproj)
+    matcher = api.PwnMatcherBase(aligner, converter); matcher.setScale(1)
+    Km = np.array([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]], np.float32); I = np.eye(4, dtype=np.float32)
+    n = 9
+    ids = list(range(n))
+    cur_mm = synth.render_depth_mm(bench.PARTITION_SCENE, np.eye(4), rows, cols, K, hole_stream=0)
+    others_mm = [bench._render_job(j) for j in bench.partition_jobs(ids, rows, cols, K)]
+    N = rows * cols
+    current = api.Cloud(ctx, N)
+    others = [api.Cloud(ctx, N) for _ in range(n)]
+    converter.computeBatch([current] + others, [cur_mm] + others_mm, raw_scale=0.001)
+    guesses = bench.partition_guesses(ids)
+    base = matcher.matchCloudsBatch([current] * n, others, I, I, Km, rows, cols, guesses)
+    rec_dev = torch.full((n, api.MATCH_RECORD_FLOATS), -7.0, dtype=torch.float32, device="cuda")
+    pid = np.arange(100, 100 + n, dtype=np.int32)
+    res, sc = matcher.matchCloudsBatchRecords([current] * n, others, I, I, Km, rows, cols, rec_dev, guesses, pair_ids=pid)
+    rec = rec_dev.cpu().numpy()
+    rec_host = np.full((n, api.MATCH_RECORD_FLOATS), -7.0, np.float32)
+    matcher.matchCloudsBatchRecords([current] * n, others, I, I, Km, rows, cols, rec_host, guesses, pair_ids=pid, want_results=False)
+    assert np.array_equal(_bits(rec), _bits(rec_host))
+    for i in range(n):
+        b = base[i]
+        assert np.array_equal(_bits(rec[i, :16]), _bits(np.ascontiguousarray(b["align"]["T"].T.reshape(-1))))
+        assert rec[i, 17] == b["cloud_inliers"] and rec[i, 18] == 10 and rec[i, 19] == 100 + i
+        assert np.array_equal(_bits(rec[i, 20:30]), _bits(b["align"]["chi2"][:10]))
+        assert (rec[i, 64], rec[i, 65], rec[i, 66]) == (b["image_nonZeros"], b["image_outliers"], b["image_inliers"])
+        assert np.array_equal(_bits(rec[i, 67:68]), _bits(np.float32([b["image_reprojectionDistance"]])))
+        assert np.all(rec[i, 68:] == 0)
+        assert (sc[i].image_non_zeros, sc[i].image_inliers) == (b["image_nonZeros"], b["image_inliers"])
+        assert np.array_equal(_bits(res["T"][i]), _bits(rec[i, :16]))
+        # the alignments found the relative pose of the views (same scene, <= 5 cm / 2.3 deg apart, guess 1 cm / 0.5 deg off)
+        assert np.abs(b["align"]["T"][:3, 3] - synth.pair_pose(bench.PARTITION_POSE0 + i)[:3, 3]).max() < 2e-2, i
+        assert b["image_nonZeros"] > N // 2
+    # a records buffer that is too small or of the wrong type never reaches the library
+    with pytest.raises(ValueError):
+        matcher.matchCloudsBatchRecords([current] * n, others, I, I, Km, rows, cols, torch.empty((n, 64), dtype=torch.float32, device="cuda"), guesses)
+    with pytest.raises(ValueError):
+        matcher.matchCloudsBatchRecords([current] * n, others, I, I, Km, rows, cols, np.empty((n, 72), np.float64), guesses)
+    with pytest.raises(ValueError):
+        aligner.alignBatchRecords([current] * n, others, np.empty((n - 1, 64), np.float32))
+    ctx.close()
+
+
+def test_bench_partition_mode_original_and_replica_give_the_same_records(tmp_path):
+    """bench.py --mode partition on one GPU: (1) plain -- every pair matched against the converted `current` cloud; (2) broadcast and all-gather
+    forced through RCCL at world size 1 -- rank 0 matches against the replica that went through export / broadcast / import.  Both lines carry the
+    roofline and the closer's acceptance count; the assembled 288-byte records are equal, CRC by CRC (run 1 writes the digests into a scratch
+    directory, run 2 is checked against them)."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    crc_dir = str(tmp_path)
+    # bench.py reads its CRC directory from the module constant: run it through a tiny driver that redirects it
+    driver = tmp_path / "run_bench.py"
+    driver.write_text("import sys; sys.path.insert(0, %r); import bench; bench.CRC_DIR = %r; sys.argv[0] = %r; bench.main()\n"
+                      % (ROOT, crc_dir, os.path.join(ROOT, "bench.py")))
+
+    def run(env, args):
+        e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PWN_BENCH_FORCE_DIST")}
+        e.update(env)
+        out = subprocess.run([sys.executable, str(driver), "--gpus", "1", "--mode", "partition", "--pairs", "40", "--steps", "2", "--warmup", "1",
+                              "--no-cpu-baseline", "--render-workers", "1"] + args, env=e, capture_output=True, text=True, timeout=900)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+
+    plain = run({}, ["--write-records-crc"])
+    assert plain["config"]["mode"] == "partition" and plain["value"] > 0 and plain["gather"]["records"] == 40 and plain["gather"]["record_bytes"] == 288
+    assert plain["gather"]["records_equal_local"] is True
+    assert plain["gather"]["records_vs_single_gpu_run"]["checked"] == 40 and plain["gather"]["records_vs_single_gpu_run"]["equal"] is True
+    assert plain["partition"]["accepted_by_closer_thresholds_rank0"] >= 30 and plain["partition"]["max_translation_error_m_rank0"] < 1e-2
+    assert 0.2 < plain["roofline"]["frac"] < 1.0 and plain["roofline"]["projections_per_pair"] == 10.0      # non-identity guesses: every reference projection runs
+    forced = run(dict(PWN_BENCH_FORCE_DIST="1", RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0"), [])
+    g = forced["gather"]
+    assert g["backend"].startswith("nccl") and g["forced"] is True and forced["partition"]["replica_roundtrip_on_rank0"] is True
+    assert g["records_vs_single_gpu_run"]["checked"] == 40 and g["records_vs_single_gpu_run"]["equal"] is True, g
+    assert g["records_vs_single_gpu_run"]["file_is_for_these_kernels"] is True
+    m = forced["multi_gpu"]
+    assert len(m["per_rank_ms_per_step"]) == 1 and m["per_rank_ms_per_step"][0] > 0
+    assert m["collectives_alone"]["broadcast_ms"] > 0 and m["collectives_alone"]["gather_ms"] > 0
+    assert 10e6 < m["collectives_alone"]["flat_cloud_bytes"] <= m["collectives_alone"]["broadcast_bytes"]
+    assert set(m["per_rank_stage_ms_per_step"]) >= {"corr_linearize", "project_ref", "solve", "match_score"}

@@ -16,7 +16,7 @@ import sys
 from collections import defaultdict
 
 KERNELS = ("k_corr_linearize", "k_stats", "k_unproject_integral", "k_project", "k_strip_count", "k_row_offsets", "k_solve_update",
-           "k_convert_fused", "k_probe_read", "k_probe_copy")
+           "k_probe_read", "k_probe_copy")
 
 
 def short(name):
