@@ -261,6 +261,11 @@ def cpu_baseline_child(args):
     from oracle import oracle as O
     O.lib()                                                 # builds oracle/_fast/<cpu>/libpwn_oracle.so on first use (untimed)
     cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    # the cpus this process may be scheduled on are not the cpu TIME it may use: a container's cgroup quota (the one-GPU boxes: 16 of a 256-thread
+    # host) bounds what any number of threads gets; more threads than the quota only add contention
+    quota = host_cpu_info().get("cgroup_cpu_quota")
+    if quota:
+        cores = max(1, min(cores, int(round(quota))))
     cp = O.converter_params(K=K, **conv)
     apar = O.aligner_params(rows, cols, K=K, **alig)
     fast = getattr(O.lib(), "_pwn_variant", "checker") == "fast"
@@ -466,11 +471,15 @@ class BatchWorkload:
             except Exception:
                 tj = {}
 
+        # a table measured at this very frame size (profiles/traffic.json: "sizes") is used as it is; otherwise the VGA table scaled by pixels
+        tsz = tj.get("sizes", {}).get(f"{self.rows}x{self.cols}")
+        tuse = tsz if tsz else tj
+
         def pmc_bytes(kernel, items_per_launch):
-            e = tj.get("kernels", {}).get(kernel)
+            e = tuse.get("kernels", {}).get(kernel)
             if not e:
                 return None
-            return e["bytes_per_launch"] / tj.get("items_per_launch", 64) * (self.N / tj.get("pixels_per_frame", 307200)) * items_per_launch
+            return e["bytes_per_launch"] / e.get("items_per_launch", tuse.get("items_per_launch", 64)) * (self.N / tuse.get("pixels_per_frame", 307200)) * items_per_launch
         traffic = pmc_bytes("k_corr_linearize", P * self.n_it * steps / launches)
         # the other kernels of the step, each against the same peak: algorithmic bytes of its share of SURVEY.md 8(d)'s formulas / its own
         # average launch time (hipEvent pairs of the serial profiled pass), PMC traffic beside it
@@ -500,7 +509,8 @@ class BatchWorkload:
         roofline = {"bound": "hbm", "kernel": "k_corr_linearize", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                     "traffic_over_algorithmic": (traffic / k_bytes) if (traffic and k_bytes) else None,
-                    "traffic_source": {"file": "profiles/traffic.json", "version": tj.get("version"), "pmc_summary": tj.get("source")},
+                    "traffic_source": {"file": "profiles/traffic.json", "version": tuse.get("version"), "pmc_summary": tuse.get("source"),
+                                       "measured_at_this_frame_size": bool(tsz) or (self.rows, self.cols) == (480, 640)},
                     "bytes_per_launch_algorithmic": k_bytes, "avg_launch_ms": k_ms, "launches": self.stage_n["corr_linearize"],
                     "dominant_by_time": dom,
                     "traffic_GBps": (traffic / (k_ms * 1e-3) / 1e9) if (traffic and k_ms > 0) else None,

@@ -117,6 +117,8 @@ def pinned_free(a):
 
 
 def _nbytes(x) -> int:
+    if isinstance(x, DeviceBuffer):
+        return int(x.nbytes)
     if hasattr(x, "data_ptr"):
         return int(x.numel() * x.element_size())
     return int(x.nbytes)
@@ -126,6 +128,10 @@ def _check_records(records, n, floats, ctx=None):
     """A records buffer the library writes n * floats float32 words into (k_pack_records on the device, or a copy to the host): anything
     smaller, of another type, non-contiguous or on another device would be written out of bounds."""
     if records is None:
+        return
+    if isinstance(records, DeviceBuffer):
+        if records.dtype != np.float32 or records.nbytes < 4 * n * floats:
+            raise ValueError(f"records must be a float32 device buffer of at least {n} x {floats} floats")
         return
     if hasattr(records, "data_ptr"):
         import torch

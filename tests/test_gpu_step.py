@@ -134,7 +134,6 @@ def test_the_shipped_configuration_against_the_oracle(oracle):
         triangle of Omega_p, 1e-6), every iteration of the oracle's trace re-run from the oracle's iterate (teacher-forced chi2 <= 1e-5 vs the
         fp64-accumulated oracle, K_i / C_i / inliers_i exact), final pose within 1e-5 of the oracle's own free run;
       * the two-call path (convert_batch_u16, then align_batch_records) on other clouds: the same records, bit for bit."""
-    import torch
     from g2o_frontend_amd import api, shard
     from test_gpu_parity import oracle_params, _check_teacher_forced
     from test_omega_sym6 import compare_clouds_sym6
@@ -142,8 +141,8 @@ def test_the_shipped_configuration_against_the_oracle(oracle):
     ctx, converter, aligner, pairs, refs, curs = _rig("vga", n, 256, omega="sym6")      # 4 streams x 64 slots, as bench.py's context
     rows, cols, _, _, _ = case_params("vga")
     ctx.set_subbatch(64, 64); ctx.set_concurrency(4)                                     # bench.py's defaults (--sub-frames 64 --sub-pairs 64 --streams 4)
-    bufs = [torch.from_numpy(p[0].view(np.int16)).cuda() for p in pairs] + [torch.from_numpy(p[1].view(np.int16)).cuda() for p in pairs]
-    rec = torch.full((n, shard.RECORD_FLOATS), -7.0, dtype=torch.float32, device="cuda")
+    bufs = [ctx.upload(p[0]) for p in pairs] + [ctx.upload(p[1]) for p in pairs]
+    rec = ctx.upload(np.full((n, shard.RECORD_FLOATS), -7.0, np.float32))                # a device buffer, as the tensor the all-gather sends
     ids = np.arange(9000, 9000 + n, dtype=np.int32)
     prep = aligner.convertAlignHandles(refs, curs, bufs[:n], bufs[n:], converter=converter)
     ctx.set_profiling(True)
@@ -151,14 +150,14 @@ def test_the_shipped_configuration_against_the_oracle(oracle):
     launches = ctx.stage_ms("corr_linearize")[1]
     ctx.set_profiling(False)
     assert launches == 4 * 10, launches                                                  # the plan the line reports: 4 sub-batches of 32 pairs x 10 iterations
-    rec_fused = rec.cpu().numpy().copy()
+    rec_fused = rec.numpy().copy()
     assert np.array_equal(_bits(rec_fused), _bits(shard.pack_results_raw(got, ids)))
     # the two-call path on other clouds
     refs2 = [api.Cloud(ctx, rows * cols) for _ in range(n)]; curs2 = [api.Cloud(ctx, rows * cols) for _ in range(n)]
     converter.computeBatch(refs2 + curs2, bufs, raw_scale=0.001)
-    rec2 = torch.full((n, shard.RECORD_FLOATS), -3.0, dtype=torch.float32, device="cuda")
+    rec2 = ctx.upload(np.full((n, shard.RECORD_FLOATS), -3.0, np.float32))
     aligner.alignBatchRecords(refs2, curs2, rec2, pair_ids=ids, want_results=False)
-    assert np.array_equal(_bits(rec2.cpu().numpy()), _bits(rec_fused))
+    assert np.array_equal(_bits(rec2.numpy()), _bits(rec_fused))
     # the oracle on one pair of every sub-batch (first, inner, last positions)
     cp, ap = oracle_params(oracle, "vga", accumulate_fp64=1)
     worst_chi2 = worst_pose = worst_lower = 0.0

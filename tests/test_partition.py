@@ -36,7 +36,6 @@ def _same_cloud(a, b):
 
 @pytest.mark.parametrize("storage", ["exact9", "sym6"])
 def test_flat_cloud_round_trip_is_the_cloud_bit_for_bit(storage):
-    import torch
     from g2o_frontend_amd import api
     from test_gpu_parity import gpu_objects
     name = "small"
@@ -50,7 +49,7 @@ def test_flat_cloud_round_trip_is_the_cloud_bit_for_bit(storage):
     bound = api.Cloud.flatBound(N, storage, N)
     assert gref.flatSize() <= bound and gref.flatSize() % 256 == 0
     # device buffer, same context
-    flat = torch.zeros(bound, dtype=torch.uint8, device="cuda")
+    flat = ctx.upload(np.zeros(bound, np.uint8))              # a device buffer (the library's own allocator: no torch in this process)
     used = gref.exportFlat(flat)
     assert used == gref.flatSize()
     rep = api.Cloud(ctx, N)
@@ -64,7 +63,7 @@ def test_flat_cloud_round_trip_is_the_cloud_bit_for_bit(storage):
     _same_cloud(gcur, rep_cur)
     # the bytes themselves: device and host exports of one cloud are the same bytes
     host2 = np.zeros(used, np.uint8); gref.exportFlat(host2)
-    assert np.array_equal(flat[:used].cpu().numpy(), host2)
+    assert np.array_equal(flat.numpy()[:used], host2)
     # alignments: replica in either role, and in both, are bitwise the original's (the replica carries the converter's index image, so it takes
     # the same projection shortcuts)
     aligner.setReferenceCloud(gref); aligner.setCurrentCloud(gcur)
@@ -102,6 +101,7 @@ def test_flat_cloud_round_trip_is_the_cloud_bit_for_bit(storage):
         api.Cloud(ctx2, 16).importFlat(host2)
     assert e.value.code == 6
     _same_cloud(gref, rep)                       # failed imports above went to other clouds; this one is untouched
+    flat.free()
     for c in (ctx3, ctx2, ctx):
         c.close()
 
@@ -126,7 +126,6 @@ def test_flat_cloud_of_an_uploaded_cloud_carries_its_normal_information_planes(o
 
 
 def test_match_batch_records_carry_the_matcher_results():
-    import torch
     from g2o_frontend_amd import api
     from test_gpu_parity import gpu_objects
     sys.path.insert(0, ROOT)
@@ -150,10 +149,10 @@ def test_match_batch_records_carry_the_matcher_results():
     converter.computeBatch([current] + others, [cur_mm] + others_mm, raw_scale=0.001)
     guesses = bench.partition_guesses(ids)
     base = matcher.matchCloudsBatch([current] * n, others, I, I, Km, rows, cols, guesses)
-    rec_dev = torch.full((n, api.MATCH_RECORD_FLOATS), -7.0, dtype=torch.float32, device="cuda")
+    rec_dev = ctx.upload(np.full((n, api.MATCH_RECORD_FLOATS), -7.0, np.float32))
     pid = np.arange(100, 100 + n, dtype=np.int32)
     res, sc = matcher.matchCloudsBatchRecords([current] * n, others, I, I, Km, rows, cols, rec_dev, guesses, pair_ids=pid)
-    rec = rec_dev.cpu().numpy()
+    rec = rec_dev.numpy()
     rec_host = np.full((n, api.MATCH_RECORD_FLOATS), -7.0, np.float32)
     matcher.matchCloudsBatchRecords([current] * n, others, I, I, Km, rows, cols, rec_host, guesses, pair_ids=pid, want_results=False)
     assert np.array_equal(_bits(rec), _bits(rec_host))
@@ -172,7 +171,7 @@ def test_match_batch_records_carry_the_matcher_results():
         assert b["image_nonZeros"] > N // 2
     # a records buffer that is too small or of the wrong type never reaches the library
     with pytest.raises(ValueError):
-        matcher.matchCloudsBatchRecords([current] * n, others, I, I, Km, rows, cols, torch.empty((n, 64), dtype=torch.float32, device="cuda"), guesses)
+        matcher.matchCloudsBatchRecords([current] * n, others, I, I, Km, rows, cols, ctx.upload(np.zeros((n, 64), np.float32)), guesses)
     with pytest.raises(ValueError):
         matcher.matchCloudsBatchRecords([current] * n, others, I, I, Km, rows, cols, np.empty((n, 72), np.float64), guesses)
     with pytest.raises(ValueError):

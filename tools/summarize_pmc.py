@@ -4,6 +4,7 @@ traffic table bench.py reads (profiles/traffic.json).
 
   tools/summarize_pmc.py <pmc output dir>                                   -> the summary text on stdout (tools/profile_pmc.sh)
   tools/summarize_pmc.py <dir or committed summary .txt> --traffic-json profiles/traffic.json --version r03_v13 [--launch-items 64]
+  ... --size-key 960x1280 --pixels 1228800 --launch-items 32 --frame-items 64     -> the table of another frame size, stored under "sizes"
 
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced read
 (MI355X_MICROARCH.md, HBM section; re-checked in every set of passes on k_probe_read, which streams exactly 2 GiB per launch)."""
@@ -69,7 +70,10 @@ def collect_txt(path):
     return means, stats, []
 
 
-def traffic_table(means, stats, version, source, launch_items, pixels):
+FRAME_KERNELS = ("k_stats", "k_unproject_integral", "k_strip_count", "k_row_offsets")      # launched per sub-batch of FRAMES, the others per sub-batch of pairs
+
+
+def traffic_table(means, stats, version, source, launch_items, pixels, frame_items=None):
     kernels = {}
     for k in KERNELS:
         m = means.get(k)
@@ -77,7 +81,7 @@ def traffic_table(means, stats, version, source, launch_items, pixels):
             continue
         fetch_kb, write_kb = m["FETCH_SIZE"][0], m["WRITE_SIZE"][0]
         e = {"fetch_size_kb": fetch_kb, "write_size_kb": write_kb, "bytes_per_launch": (2.0 * fetch_kb + write_kb) * 1024.0,
-             "dispatches": m["FETCH_SIZE"][1]}
+             "dispatches": m["FETCH_SIZE"][1], "items_per_launch": (frame_items or launch_items) if k in FRAME_KERNELS else launch_items}
         if k in stats:
             e["avg_ns_rocprof"] = stats[k][0]
         for c in ("SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU", "SQ_BUSY_CYCLES", "SQ_WAVES", "SQ_BUSY_CU_CYCLES", "SQ_INST_CYCLES_VMEM", "SQ_WAVE_CYCLES"):
@@ -105,13 +109,23 @@ def main(argv):
         means, stats, stats_text = collect_txt(src)
     if "--traffic-json" in opts:
         t = traffic_table(means, stats, opts.get("--version", "unversioned"), opts.get("--source", src),
-                          int(opts.get("--launch-items", 64)), int(opts.get("--pixels", 307200)))
+                          int(opts.get("--launch-items", 64)), int(opts.get("--pixels", 307200)),
+                          int(opts["--frame-items"]) if "--frame-items" in opts else None)
         old = {}
         if os.path.exists(opts["--traffic-json"]):
             try:
                 old = json.load(open(opts["--traffic-json"]))
             except Exception:
                 old = {}
+        if "--size-key" in opts:
+            # a table measured at another frame size (e.g. 960x1280: BASELINE configs[4]) goes beside the VGA table, which stays the top level
+            old.setdefault("sizes", {})[opts["--size-key"]] = t
+            with open(opts["--traffic-json"], "w") as f:
+                json.dump(old, f, indent=1)
+            print("wrote", opts["--traffic-json"], "sizes[%s]" % opts["--size-key"], "version", t["version"], "kernels", sorted(t["kernels"]))
+            return
+        if "sizes" in old:
+            t["sizes"] = old["sizes"]
         hist = dict(old.get("history", {}))
         if old.get("k_corr_linearize_bytes_per_pair_iteration") and old.get("version", "r02_v11") != t["version"]:
             hist[old.get("version", "r02_v11") + "_k_corr_linearize_bytes_per_pair_iteration"] = old["k_corr_linearize_bytes_per_pair_iteration"]
