@@ -1,9 +1,12 @@
 #!/usr/bin/env python3
-"""Builds library variants for A/B timing on the GPU box: tools/ab_build.py name1:-DFLAG=1,-DX=2 name2: ...  ->  build/variants/<name>.so
-(run locally; build/ travels with the gpurun snapshot).  `base` = the product flags."""
+"""Builds library variants for same-box A/B timing on the GPU box:
+     tools/ab_build.py base:HEAD~1 new            ->  build/variants/base.so (the sources of that git revision), build/variants/new.so (working tree)
+(run locally; build/ travels with the gpurun snapshot; tools/ab_run.sh runs bench.py once per variant through PWN_HIP_LIB).  The product sources
+carry no compile-time switches (tests/test_capi_cpu.py): a variant is another revision of the sources, built with the product flags."""
 import os
 import subprocess
 import sys
+import tempfile
 from concurrent.futures import ThreadPoolExecutor
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,10 +15,15 @@ from g2o_frontend_amd import build as b  # noqa: E402
 
 
 def one(spec):
-    name, _, flags = spec.partition(":")
+    name, _, rev = spec.partition(":")
     out = os.path.join(ROOT, "build", "variants", name + ".so")
-    extra = [f for f in flags.split(",") if f]
-    subprocess.check_call(["/opt/rocm/bin/hipcc"] + b.FLAGS + extra + ["-o", out, b.SOURCES[0]])
+    if not rev:
+        subprocess.check_call(["/opt/rocm/bin/hipcc"] + b.FLAGS + ["-o", out, b.SOURCES[0]])
+        return out
+    with tempfile.TemporaryDirectory(prefix="pwn_ab_") as d:
+        tar = subprocess.run(["git", "-C", ROOT, "archive", rev, "g2o_frontend_amd/csrc", "include"], check=True, capture_output=True).stdout
+        subprocess.run(["tar", "-x", "-C", d], input=tar, check=True)
+        subprocess.check_call(["/opt/rocm/bin/hipcc"] + b.FLAGS + ["-o", out, os.path.join(d, "g2o_frontend_amd", "csrc", "pwn_hip_capi.hip")])
     return out
 
 
