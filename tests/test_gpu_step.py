@@ -189,6 +189,34 @@ def test_fused_step_error_paths():
     import ctypes as C
     empty = ((C.c_void_p * 0)(), (C.c_void_p * 0)(), (C.c_void_p * 0)(), (C.c_void_p * 0)(), 0, (120, 160))
     assert len(aligner.convertAlignBatch(converter, None, None, None, None, prepared=empty)) == 0             # an empty batch is a no-op
+    with pytest.raises(PwnHipError) as e:                 # a cloud that appears twice among the 2 n clouds of a step: two streams would write it at once
+        aligner.convertAlignBatch(converter, [refs[0], refs[0]], curs, [p[0] for p in pairs], [p[1] for p in pairs])
+    assert e.value.code == 1
+    with pytest.raises(PwnHipError):
+        aligner.convertAlignBatch(converter, refs, [refs[1], curs[1]], [p[0] for p in pairs], [p[1] for p in pairs])
+    with pytest.raises(ValueError):                       # a records buffer smaller than n x 64 floats never reaches the library
+        aligner.convertAlignBatch(converter, refs, curs, [p[0] for p in pairs], [p[1] for p in pairs], records=np.empty((1, 64), np.float32))
+    ctx.wait_stream(0)                                    # ordering against a caller's stream (here: the legacy default stream, idle): a no-op that must not fail
     r = aligner.convertAlignBatch(converter, refs, curs, [p[0] for p in pairs], [p[1] for p in pairs])      # the context still works
     assert (r["iterations"] == 10).all()
+    ctx.close()
+
+
+def test_step_refuses_frames_beyond_the_aligners_index_field():
+    """The aligner's 32-bit z-buffer word indexes 2^21 points.  In the one-submission step the clouds' host-side sizes are those of their previous
+    content while the call is queued, so the step bounds what the conversion can produce: frames of more than 2^21 pixels are refused with
+    PWN_HIP_ERR_CAPACITY (the two-call path refuses in align_batch, which sees the converted sizes)."""
+    from g2o_frontend_amd import api
+    from g2o_frontend_amd._lib import PwnHipError
+    from test_gpu_parity import gpu_objects
+    rows, cols = 1456, 1456                                # 2 119 936 pixels > 2^21
+    ctx = api.Context(0, rows, cols, 2)
+    _, converter, aligner = gpu_objects(ctx, "vga")
+    converter.projector().setImageSize(rows, cols)
+    aligner.projector().setImageSize(rows, cols); aligner.correspondenceFinder().setImageSize(rows, cols)
+    a, b = api.Cloud(ctx, rows * cols), api.Cloud(ctx, rows * cols)
+    f = np.full((rows, cols), 1500, np.uint16)
+    with pytest.raises(PwnHipError) as e:
+        aligner.convertAlignBatch(converter, [a], [b], [f], [f])
+    assert e.value.code == 6
     ctx.close()
