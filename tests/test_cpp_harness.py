@@ -316,6 +316,10 @@ def test_tracker_closer_harness_matches_python_mirror(tmp_path):
                 # the closure transform agrees with the tracked relative pose (same scene, consistent estimates)
                 assert np.abs(m["transform"][:3, 3] - guess[:3, 3]).max() < 0.02
         assert (int(hits_line[3]), int(hits_line[5])) == (cache.hits, cache.misses) and cache.misses > n
+        # the same pass through the multi-GPU form inside the app (flat cloud of `current`: export -> host buffer -> import; results as 288-byte
+        # records: Cloud::exportFlat / importFlat, PwnMatcherBase::matchCloudsBatchRecords of the C++ mirror): equal to the plain calls, record for record
+        rec_line = [l for l in open(str(tmp_path / "run") + "_closures.txt") if l.startswith("# replica_record_calls")][0].split()
+        assert int(rec_line[2]) == n * (n - 1) // 2 and int(rec_line[4]) == 1, rec_line
         assert clos[:, 2].sum() >= 1                 # some closure is accepted
         # statistics and priors
         ca, cb = cache.get(0), cache.get(1)

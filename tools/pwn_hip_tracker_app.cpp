@@ -144,6 +144,9 @@ int main(int argc, char** argv) {
     if (P.count("frameMaxOutliersThreshold")) acceptance.frameMaxOutliersThreshold = (int)P["frameMaxOutliersThreshold"];
     if (P.count("frameMinInliersThreshold")) acceptance.frameMinInliersThreshold = (int)P["frameMinInliersThreshold"];
     const int r = frames[0].rows, c = frames[0].cols;
+    // the multi-GPU form of the same pass: `current` travels as ONE flat buffer, the results come back as 288-byte records.  Here on one
+    // context: the replica of `current` that went through export -> host buffer -> import must give, record for record, what the original gives
+    int recordCalls = 0, recordsEqual = 1;
     for (size_t a = 0; a < keyframes.size(); ++a) {           // processPartition: one `current` against every earlier keyframe
       std::vector<Cloud*> from, to; std::vector<Isometry3f> guesses; std::vector<int> other;
       for (size_t b = 0; b < a; ++b) { other.push_back(keyframes[b]); guesses.push_back(iso_mul(keyPoses[b].inverse(), keyPoses[a])); }
@@ -158,6 +161,27 @@ int main(int argc, char** argv) {
         for (size_t b = b0; b < b1; ++b) { from.push_back(cache.get(other[b])); to.push_back(cur); g.push_back(guesses[b]); }
         std::vector<PwnMatcherBase::MatcherResult> results;
         tracker.matchCloudsBatch(results, from, to, sensorOffset, sensorOffset, cameraMatrix, r, c, g);
+        {
+          std::vector<unsigned char> flat(cur->flatSize());
+          cur->exportFlat(flat.data(), flat.size());
+          Cloud replica(ctx, (int)std::max<size_t>(1, cur->size()));
+          replica.importFlat(flat.data(), flat.size());
+          std::vector<Cloud*> toReplica(to.size(), &replica);
+          std::vector<float> records(from.size() * PWN_HIP_MATCH_RECORD_FLOATS, -1.f);
+          std::vector<int> ids; for (size_t i = 0; i < from.size(); ++i) ids.push_back(other[b0 + i]);
+          std::vector<PwnMatcherBase::MatcherResult> viaRecords;
+          tracker.matchCloudsBatchRecords(records.data(), from, toReplica, sensorOffset, sensorOffset, cameraMatrix, r, c, g, ids, 0, &viaRecords);
+          ++recordCalls;
+          for (size_t i = 0; i < results.size(); ++i) {
+            const float* q = &records[i * PWN_HIP_MATCH_RECORD_FLOATS];
+            const PwnMatcherBase::MatcherResult& m = results[i];
+            bool ok = (int)q[19] == other[b0 + i] && (int)q[17] == m.cloud_inliers && (int)q[64] == m.image_nonZeros && (int)q[65] == m.image_outliers &&
+                      (int)q[66] == m.image_inliers && std::memcmp(&q[67], &m.image_reprojectionDistance, sizeof(float)) == 0 &&
+                      viaRecords[i].image_inliers == m.image_inliers && viaRecords[i].cloud_inliers == m.cloud_inliers;
+            for (int t = 0; t < 16 && ok; ++t) ok = q[t] == (float)m.transform[t];
+            if (!ok) recordsEqual = 0;
+          }
+        }
         for (size_t i = 0; i < results.size(); ++i) {
           const PwnMatcherBase::MatcherResult& m = results[i];
           std::fprintf(fc, "%d %d %d %d %d %d %d %.9g", other[b0 + i], keyframes[a], acceptance.accept(m) ? 1 : 0, m.cloud_inliers, m.image_nonZeros, m.image_outliers,
@@ -168,6 +192,7 @@ int main(int argc, char** argv) {
       }
     }
     std::fprintf(fc, "# cache hits %d misses %d\n", cache.hits, cache.misses);
+    std::fprintf(fc, "# replica_record_calls %d records_equal_results %d\n", recordCalls, recordsEqual);
     std::fclose(fc);
 
     // 3. statistics and priors on the first two keyframes
