@@ -216,3 +216,58 @@ def test_bench_partition_mode_original_and_replica_give_the_same_records(tmp_pat
     assert m["collectives_alone"]["broadcast_ms"] > 0 and m["collectives_alone"]["gather_ms"] > 0
     assert 10e6 < m["collectives_alone"]["flat_cloud_bytes"] <= m["collectives_alone"]["broadcast_bytes"]
     assert set(m["per_rank_stage_ms_per_step"]) >= {"corr_linearize", "project_ref", "solve", "match_score"}
+
+
+def test_native_rccl_partition_app_matches_the_python_mirror(tmp_path):
+    """tools/pwn_hip_partition_app.cpp -- the processPartition flow of INTEGRATION.md in native code: C++ mirror over the C-ABI, RCCL for the broadcast
+    of the flat `current` cloud and the all-gather of the 288-byte records (world size 1 here: one GPU; the ranks of a larger run are forked before
+    any GPU call and meet through an ncclUniqueId passed over pipes).  Its printed records must equal, digit for digit, what the Python mirror's
+    matchCloudsBatch gives for the same frames and guesses on the converted `current` cloud."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from g2o_frontend_amd import api, build, synth
+    build.build_tools()
+    exe = os.path.join(ROOT, "tools", "pwn_hip_partition_app")
+    if not os.path.exists(exe):
+        pytest.skip("no RCCL headers: the app was not built")
+    rows, cols, K = 480, 640, synth.K_VGA
+    n = 6
+    ids = list(range(n))
+    frames = [synth.render_depth_mm(bench.PARTITION_SCENE, np.eye(4), rows, cols, K, hole_stream=0)] + [bench._render_job(j) for j in bench.partition_jobs(ids, rows, cols, K)]
+    names = []
+    for k, f in enumerate(frames):
+        fn = tmp_path / f"f{k}.pgm"
+        with open(fn, "wb") as fh:
+            fh.write(b"P5\n%d %d\n65535\n" % (cols, rows)); fh.write(f.astype(">u2").tobytes())
+        names.append(str(fn))
+    (tmp_path / "frames.txt").write_text("\n".join(names) + "\n")
+    guesses = [np.asarray(g, np.float64).astype(np.float32) for g in bench.partition_guesses(ids)]
+    (tmp_path / "guesses.txt").write_text("\n".join(" ".join("%.9g" % v for v in g.T.reshape(-1)) for g in guesses) + "\n")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([exe, str(tmp_path / "frames.txt"), "1", "2", str(tmp_path / "guesses.txt")], capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, (out.stdout[-500:], out.stderr[-1500:])
+    lines = [l.split() for l in out.stdout.splitlines()]
+    head = [l for l in lines if l and l[0] == "keyframes"][0]
+    assert (int(head[1]), int(head[3])) == (n, 1) and float(head[7]) > 0 and int(head[9]) > 10e6
+    recs = [l for l in lines if l and l[0] == "keyframe"]
+    assert len(recs) == n
+    # the same flow with the Python mirror: sym6 clouds, scale 1, bench.py's VGA tables
+    ctx = api.Context(0, rows, cols, 16, omega_storage="sym6")
+    Kc, conv, alig = bench.conf(rows, cols)
+    converter, aligner = bench.build_objects(ctx, rows, cols, Kc, conv, alig)
+    alproj = api.PinholePointProjector(); alproj.setMinDistance(alig["min_distance"]); alproj.setMaxDistance(alig["max_distance"])
+    aligner.setProjector(alproj)
+    matcher = api.PwnMatcherBase(aligner, converter); matcher.setScale(1)
+    Km = np.array([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]], np.float32); I = np.eye(4, dtype=np.float32)
+    clouds = [api.Cloud(ctx, rows * cols) for _ in range(n + 1)]
+    converter.computeBatch(clouds, frames, raw_scale=0.001)
+    base = matcher.matchCloudsBatch([clouds[0]] * n, clouds[1:], I, I, Km, rows, cols, guesses)
+    acc = api.PwnCloserAcceptance()
+    for k, (l, b) in enumerate(zip(recs, base)):
+        v = np.array(l[1:], np.float64)
+        assert int(v[0]) == k and bool(v[1]) == acc.accept(b)
+        assert (int(v[2]), int(v[3]), int(v[4]), int(v[5])) == (b["cloud_inliers"], b["image_nonZeros"], b["image_outliers"], b["image_inliers"]), (k, v[:7], b)
+        assert np.float32(v[6]) == np.float32(b["image_reprojectionDistance"])
+        assert np.array_equal(v[7:23].astype(np.float32).reshape(4, 4).T, b["align"]["T"]), k
+        assert np.array_equal(v[23:33].astype(np.float32), b["align"]["chi2"][:10]), k
+    ctx.close()
