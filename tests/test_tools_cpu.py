@@ -31,9 +31,11 @@ def test_traffic_json_is_what_the_newest_pmc_summary_gives(tmp_path):
 
 
 def test_bench_line_of_the_round_is_committed_and_self_consistent():
-    d = json.load(open(os.path.join(ROOT, "profiles", "r04_bench_line_e.json")))
-    assert d["config"]["omega_storage"] == "sym6" and d["config"]["step_mode"] == "fused" and d["config"]["workload"].startswith("loop-closure batch: 128 independent 640x480")
+    d = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_line_final.json")))
+    assert d["config"]["omega_storage"] == "sym6" and d["config"]["step_mode"] == "fused" and d["config"]["mode"] == "pairs"
+    assert d["config"]["workload"].startswith("loop-closure batch: 128 independent 640x480")
     assert d["gather"]["records_vs_single_gpu_run"]["equal"] and d["gather"]["records_vs_single_gpu_run"]["checked"] == 128
+    assert d["gather"]["records_vs_single_gpu_run"]["file_is_for_these_kernels"]
     r = d["roofline"]
     assert d["unit"] == "alignments/s" and d["n_gpus"] == 1 and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and r["bound"] == "hbm"
@@ -43,3 +45,19 @@ def test_bench_line_of_the_round_is_committed_and_self_consistent():
     assert set(r["other_kernels"]) == {"k_stats", "k_unproject_integral", "k_project"}
     assert d["chi2_match"]["ok"] and d["chi2_match"]["max_rel_diff"] <= 1e-5 and d["chi2_match"]["free_running_ok"]
     assert d["gather"]["records_equal_local"] and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] >= 1
+    # round 5: the CPU baseline says what its cores are; both omega storages are in the line, each against its own digests; configs[4]'s traffic is
+    # measured at 1280x960, not scaled from VGA
+    c = d["cpu_baseline"]
+    assert {"logical_cpus", "physical_cores", "smt", "cgroup_cpu_quota"} <= set(c) and c["cores"] <= c["logical_cpus"]
+    if c["cgroup_cpu_quota"]:
+        assert c["cores"] <= round(c["cgroup_cpu_quota"])
+    e9 = d["omega_exact9"]
+    assert e9["alignments_per_s"] > 0 and e9["records_vs_single_gpu_run"]["equal"] and e9["records_vs_single_gpu_run"]["file"].endswith("records_crc_pairs_exact9.json")
+    c5 = d["config5_1280x960"]["roofline"]
+    assert c5["traffic_source"]["measured_at_this_frame_size"] is True and c5["traffic_source"]["version"] == "r05_1280x960"
+    assert c5["other_kernels"]["k_stats"]["traffic_over_algorithmic"] > 1.8            # the measured 2.0 x, not VGA's 1.45 x
+    # the processPartition line of the same tree
+    p = json.load(open(os.path.join(ROOT, "profiles", "r05_bench_line_partition_final.json")))
+    assert p["config"]["mode"] == "partition" and p["gather"]["record_bytes"] == 288 and p["gather"]["records_vs_single_gpu_run"]["equal"]
+    assert p["gather"]["records_vs_single_gpu_run"]["file"].endswith("records_crc_partition_sym6.json") and p["partition"]["accepted_by_closer_thresholds_rank0"] > 100
+    assert p["roofline"]["projections_per_pair"] == 10.0 and abs(p["value"] - p["config"]["pairs_per_gpu"] / p["ms_per_step"] * 1e3) < 1e-6 * p["value"]
