@@ -271,3 +271,61 @@ def test_native_rccl_partition_app_matches_the_python_mirror(tmp_path):
         assert np.array_equal(v[7:23].astype(np.float32).reshape(4, 4).T, b["align"]["T"]), k
         assert np.array_equal(v[23:33].astype(np.float32), b["align"]["chi2"][:10]), k
     ctx.close()
+
+
+def test_partition_workload_against_the_oracle(oracle):
+    """The workload of bench.py --mode partition itself (VGA, sym6 clouds, one `current` cloud as the reference of every pair, odometry guesses with the z
+    translation zeroed) against the oracle on sampled keyframes: converter clouds (sym6 comparison), every iteration of the oracle's ten-iteration trace
+    re-run from the oracle's iterate (chi2 1e-5 vs the fp64-accumulated sums, K_i / C_i / inliers_i exact), the batch's own first-iteration counters exact
+    and its final pose within 1e-5 of the oracle's free run, and the depth-agreement score: exact against the oracle's scoring of the GPU's own finder
+    images, within a few pixels of the oracle's own chain."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from g2o_frontend_amd import api, synth
+    from test_gpu_parity import _check_teacher_forced
+    from test_omega_sym6 import compare_clouds_sym6
+    rows, cols, K = 480, 640, synth.K_VGA
+    n = 8
+    ids = list(range(n))
+    cur_mm = synth.render_depth_mm(bench.PARTITION_SCENE, np.eye(4), rows, cols, K, hole_stream=0)
+    others_mm = [bench._render_job(j) for j in bench.partition_jobs(ids, rows, cols, K)]
+    ctx = api.Context(0, rows, cols, 16, omega_storage="sym6")
+    Kc, conv, alig = bench.conf(rows, cols)
+    converter, aligner = bench.build_objects(ctx, rows, cols, Kc, conv, alig)
+    alproj = api.PinholePointProjector(); alproj.setMinDistance(alig["min_distance"]); alproj.setMaxDistance(alig["max_distance"])
+    aligner.setProjector(alproj)
+    matcher = api.PwnMatcherBase(aligner, converter); matcher.setScale(1)
+    Km = np.array([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]], np.float32); I = np.eye(4, dtype=np.float32)
+    clouds = [api.Cloud(ctx, rows * cols) for _ in range(n + 1)]
+    converter.computeBatch(clouds, [cur_mm] + others_mm, raw_scale=0.001)
+    guesses = bench.partition_guesses(ids)
+    rec = np.zeros((n, api.MATCH_RECORD_FLOATS), np.float32)
+    res, sc = matcher.matchCloudsBatchRecords([clouds[0]] * n, clouds[1:], I, I, Km, rows, cols, rec, guesses)
+    cp = oracle.converter_params(K=K, **conv)
+    ocur, _, _ = oracle.convert(cp, oracle.convert_16u_to_32f(cur_mm))
+    compare_clouds_sym6(ocur.arrays(), clouds[0].arrays())
+    worst_chi2 = worst_pose = 0.0
+    for i in (0, 3, 7):
+        ooth, _, _ = oracle.convert(cp, oracle.convert_16u_to_32f(others_mm[i]))
+        compare_clouds_sym6(ooth.arrays(), clouds[1 + i].arrays())
+        g = np.asarray(guesses[i], np.float64).astype(np.float32); g[2, 3] = 0; g[3] = (0, 0, 0, 1)          # matchClouds' conditioning (pwn_matcher_base.cpp:114)
+        ap = oracle.aligner_params(rows, cols, K=K, initial_guess=g, accumulate_fp64=1, **alig)
+        o = oracle.align(ap, ocur, ooth, images=True)
+        it0 = o["iterations"][0]
+        assert (int(res["iter_candidates"][i][0]), int(res["iter_correspondences"][i][0]), int(res["iter_inliers"][i][0])) == (it0["K"], it0["C"], it0["inliers"]), i
+        d = float(np.abs(res["T"][i].reshape(4, 4).T - o["T"]).max()); worst_pose = max(worst_pose, d)
+        assert d <= 1e-5, (i, d)
+        # teacher-forced: the aligner as matchClouds left it configured (projector, finder size), this pair's clouds
+        aligner.setReferenceCloud(clouds[0]); aligner.setCurrentCloud(clouds[1 + i])
+        worst_chi2 = max(worst_chi2, _check_teacher_forced(aligner, o))
+        # score: the oracle's scoring of the GPU's own finder images of this pair is what the record carries
+        aligner.setInitialGuess(g)
+        aligner.align(images=True)
+        f = aligner.correspondenceFinder()
+        ex = oracle.match_score(f.referenceDepthImage(), f.currentDepthImage(), 50.0)
+        assert (int(rec[i, 64]), int(rec[i, 65]), int(rec[i, 66])) == (ex["image_nonZeros"], ex["image_outliers"], ex["image_inliers"]), (i, rec[i, 64:68], ex)
+        assert abs(float(rec[i, 67]) - ex["image_reprojectionDistance"]) <= 1e-3 * ex["image_reprojectionDistance"] + 1e-6
+        os_ = oracle.match_score(o["ref_depth"], o["cur_depth"], 50.0)
+        assert abs(int(rec[i, 64]) - os_["image_nonZeros"]) <= 8 and abs(int(rec[i, 66]) - os_["image_inliers"]) <= 8, (i, rec[i, 64:68], os_)
+    print(f"partition workload, 3 of {n} keyframes vs oracle: worst teacher-forced chi2 rel diff {worst_chi2:.1e}, worst |T - T_oracle| {worst_pose:.1e}")
+    ctx.close()
