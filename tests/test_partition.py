@@ -106,6 +106,41 @@ def test_flat_cloud_round_trip_is_the_cloud_bit_for_bit(storage):
         c.close()
 
 
+def test_flat_cloud_edge_cases_empty_cloud_and_empty_batch():
+    """a frame without a single valid pixel gives an empty cloud: its flat form is header + index image, the replica is empty too and aligns like the
+    original (zero correspondences, pose = guess); a match batch of zero pairs is a no-op"""
+    from g2o_frontend_amd import api
+    from test_gpu_parity import gpu_objects
+    name = "small"
+    rows, cols, K, conv, alig = case_params(name)
+    ref, _, _, _, _ = make_depth_pair(name, 5)
+    ctx = api.Context(0, rows, cols, 4)
+    _, converter, aligner = gpu_objects(ctx, name)
+    N = rows * cols
+    empty, full = api.Cloud(ctx, N), api.Cloud(ctx, N)
+    converter.compute(empty, np.zeros((rows, cols), np.float32)); converter.compute(full, ref)
+    assert empty.size() == 0
+    buf = np.zeros(empty.flatSize(), np.uint8)
+    assert empty.exportFlat(buf) == buf.size and buf.size == 256 + ((N * 4 + 255) // 256) * 256      # header + the (all -1) index image
+    rep = api.Cloud(ctx, N)
+    converter.compute(rep, ref)                      # the destination held something else before
+    rep.importFlat(buf)
+    assert rep.size() == 0
+    aligner.setReferenceCloud(full); aligner.setCurrentCloud(empty)
+    a = aligner.align()
+    aligner.setCurrentCloud(rep)
+    b = aligner.align()
+    assert np.array_equal(_bits(a["T"]), _bits(b["T"])) and np.array_equal(a["C"], b["C"]) and int(a["C"].sum()) == 0
+    alproj = api.PinholePointProjector(); alproj.setMinDistance(alig["min_distance"]); alproj.setMaxDistance(alig["max_distance"])
+    aligner.setProjector(alproj)
+    matcher = api.PwnMatcherBase(aligner, converter); matcher.setScale(1)
+    Km = np.array([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]], np.float32); I = np.eye(4, dtype=np.float32)
+    rec = np.full((1, api.MATCH_RECORD_FLOATS), -5.0, np.float32)
+    out = matcher.matchCloudsBatchRecords([], [], I, I, Km, rows, cols, rec)
+    assert len(out[0]) == 0 and (rec == -5.0).all()
+    ctx.close()
+
+
 def test_flat_cloud_of_an_uploaded_cloud_carries_its_normal_information_planes(oracle):
     """clouds that did not come from the converter hold full normal information matrices instead of a class (pwn_hip_cloud_upload) and no index image"""
     from g2o_frontend_amd import api
