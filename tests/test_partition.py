@@ -364,3 +364,52 @@ def test_partition_workload_against_the_oracle(oracle):
         assert abs(int(rec[i, 64]) - os_["image_nonZeros"]) <= 8 and abs(int(rec[i, 66]) - os_["image_inliers"]) <= 8, (i, rec[i, 64:68], os_)
     print(f"partition workload, 3 of {n} keyframes vs oracle: worst teacher-forced chi2 rel diff {worst_chi2:.1e}, worst |T - T_oracle| {worst_pose:.1e}")
     ctx.close()
+
+
+def test_flat_clouds_and_match_records_on_disturbed_inputs():
+    """The same two properties on inputs the smooth room does not produce (tests/test_gpu_fuzz.py: sensor noise, dropouts, holes, exactly planar and
+    constant patches, out-of-range rows -- clouds with non-finite information matrices and zero normals among them), random destination capacities and
+    buffer kinds, both omega storages: replica == original in every array, and matching against the replica gives the original's records bit for bit."""
+    from g2o_frontend_amd import api
+    from test_gpu_fuzz import disturbed_pair
+    from test_gpu_parity import gpu_objects
+    name = "small"
+    rows, cols, K, conv, alig = case_params(name)
+    N = rows * cols
+    rng = np.random.default_rng(77)
+    for storage in ("exact9", "sym6"):
+        ctx = api.Context(0, rows, cols, 16, omega_storage=storage)
+        _, converter, aligner = gpu_objects(ctx, name)
+        alproj = api.PinholePointProjector(); alproj.setMinDistance(alig["min_distance"]); alproj.setMaxDistance(alig["max_distance"])
+        aligner.setProjector(alproj)
+        matcher = api.PwnMatcherBase(aligner, converter); matcher.setScale(1)
+        Km = np.array([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]], np.float32); I = np.eye(4, dtype=np.float32)
+        frames = []
+        for seed in range(6):
+            a, b, _ = disturbed_pair(seed, name)
+            frames += [a, b]
+        clouds = [api.Cloud(ctx, N) for _ in frames]
+        converter.computeBatch(clouds, frames, raw_scale=0.001)
+        replicas = []
+        for c in clouds:
+            cap = int(rng.integers(max(1, c.size()), 2 * N))
+            r = api.Cloud(ctx, cap)
+            if rng.random() < 0.5:
+                buf = np.zeros(c.flatSize() + int(rng.integers(0, 3)) * 256, np.uint8)       # exact or larger host buffer
+                c.exportFlat(buf); r.importFlat(buf)
+            else:
+                buf = ctx.upload(np.zeros(api.Cloud.flatBound(N, storage, N), np.uint8))
+                c.exportFlat(buf); r.importFlat(buf); buf.free()
+            _same_cloud(c, r)
+            replicas.append(r)
+        n = len(frames) // 2
+        guesses = []
+        for i in range(n):
+            g = np.eye(4); g[:3, 3] = rng.uniform(-0.01, 0.01, 3)
+            guesses.append(g)
+        rec_a = np.zeros((n, api.MATCH_RECORD_FLOATS), np.float32); rec_b = np.zeros_like(rec_a)
+        matcher.matchCloudsBatchRecords(clouds[0::2], clouds[1::2], I, I, Km, rows, cols, rec_a, guesses, want_results=False)
+        matcher.matchCloudsBatchRecords(replicas[0::2], replicas[1::2], I, I, Km, rows, cols, rec_b, guesses, want_results=False)
+        assert np.array_equal(_bits(rec_a), _bits(rec_b)), storage
+        assert (rec_a[:, 18] == 10).all() and (rec_a[:, 64] > 0).all()
+        ctx.close()
