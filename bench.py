@@ -900,12 +900,15 @@ def run_single_pair_cpp():
             names.append(fn)
         with open(os.path.join(d, "list.txt"), "w") as fh:
             fh.write("\n".join(names) + "\n")
-        out = subprocess.run([os.path.join(ROOT, "tools", "pwn_hip_bench"), os.path.join(d, "list.txt"), "1", "300", "10", "0", "0"],
-                             capture_output=True, text=True, timeout=300)
-        m = re.search(r"ms_per_step ([0-9.eE+-]+)", out.stdout)
-        if out.returncode != 0 or not m:
-            raise RuntimeError("pwn_hip_bench failed: " + (out.stderr or out.stdout)[-300:])
-        return float(m.group(1))
+        res = []
+        for mode in ("0", "3"):      # 0: convert, then align (two calls); 3: one submission
+            out = subprocess.run([os.path.join(ROOT, "tools", "pwn_hip_bench"), os.path.join(d, "list.txt"), "1", "300", "10", "0", mode],
+                                 capture_output=True, text=True, timeout=300)
+            m = re.search(r"ms_per_step ([0-9.eE+-]+)", out.stdout)
+            if out.returncode != 0 or not m:
+                raise RuntimeError("pwn_hip_bench failed: " + (out.stderr or out.stdout)[-300:])
+            res.append(float(m.group(1)))
+        return res
 
 
 def run_tracker_replicas(device, frames_mm, replicas=4, scale=1):
@@ -1304,6 +1307,14 @@ def main():
             w.aligner.alignBatch([w.refs[0]], [w.curs[0]])
             lat.append((time.perf_counter() - a) * 1e3)
         extra["single_pair_latency_ms"] = float(np.median(lat))
+        # the same pair as ONE submission (pwn_hip_convert_align_batch_u16 with n = 1: one host wait instead of two; same bits)
+        lat1 = []
+        h1 = w.aligner.convertAlignHandles([w.refs[0]], [w.curs[0]], [w.ref_dev[0]], [w.cur_dev[0]], converter=w.converter)
+        for _ in range(7):
+            torch.cuda.synchronize(); a = time.perf_counter()
+            w.aligner.convertAlignBatch(w.converter, None, None, None, None, raw_scale=0.001, prepared=h1)
+            lat1.append((time.perf_counter() - a) * 1e3)
+        extra["single_pair_latency_ms_one_submission"] = float(np.median(lat1[2:]))
         w.step()                                                                   # clouds of all pairs resident again
     if rank == 0 and traces and not partition:
         extra["chi2_match"] = chi2_match(traces, w.last["res"], w)
@@ -1355,7 +1366,7 @@ def main():
             extra["tracker_config2"] = run_tracker(local, frames_trk, poses)
             extra["tracker_config2"]["replicas_on_one_gpu"] = run_tracker_replicas(local, frames_trk, replicas=4)
             try:
-                extra["single_pair_latency_ms_cpp_mirror"] = run_single_pair_cpp()
+                extra["single_pair_latency_ms_cpp_mirror"], extra["single_pair_latency_ms_cpp_mirror_one_submission"] = run_single_pair_cpp()
             except Exception as e:
                 extra["single_pair_cpp_error"] = repr(e)[:300]
             try:
