@@ -1216,6 +1216,9 @@ def main():
             cpu = json.loads(out.stdout.strip().splitlines()[-1])
             traces = cpu.pop("chi2_traces", None)
             cpu.update(host_cpu_info())
+            if partition:
+                cpu["note"] = ("the sample is the pairs workload (convert 2 frames + align per item); an item of --mode partition is ONE alignment from an odometry "
+                               "guess + the depth-agreement score against a cached cloud: compare with align_only_single_thread_value")
         except Exception:
             cpu = {"error": (out.stderr or out.stdout)[-300:]}
 
