@@ -123,6 +123,9 @@ PROTOTYPES = {
     "pwn_hip_match_batch": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _F, _VP, _VP]),
     "pwn_hip_match_batch_records": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _F, _VP, _I, _VP, _VP, _VP]),
     "pwn_hip_projector_matrices": (None, [_VP, _VP, _VP, _VP, _VP]),
+    "pwn_hip_project_point": (_I, [_VP, _VP, _F, _F, _VP, C.POINTER(_I), C.POINTER(_I), C.POINTER(_F)]),
+    "pwn_hip_unproject_pixel": (_I, [_VP, _VP, _F, _F, _I, _I, _F, _VP]),
+    "pwn_hip_project_interval": (_I, [_VP, _F, _F, _F, _F]),
     "pwn_hip_iso_inverse": (None, [_VP, _VP]),
     "pwn_hip_iso_mul": (None, [_VP, _VP, _VP]),
     "pwn_hip_v2t": (None, [_VP, _VP]),

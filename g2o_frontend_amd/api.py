@@ -435,6 +435,26 @@ class PinholePointProjector:
         _lib.lib().pwn_hip_projector_matrices(_ptr(_colmajor(self._K, 3)), _ptr(_colmajor(self._transform, 4)), _ptr(KRt), _ptr(iKRt), _ptr(iK))
         return KRt.reshape(4, 4).T.copy(), iKRt.reshape(4, 4).T.copy(), iK.reshape(3, 3).T.copy()
 
+    # the single-point forms (pinholepointprojector.h:174,187,200): host code, the kernels' own expressions
+    def projectPoint(self, p):
+        """project(x, y, f, p) -> (valid, x, y, depth); the image bounds are the caller's test, as in the reference"""
+        x, y, d = C.c_int(0), C.c_int(0), C.c_float(0)
+        pt = np.ascontiguousarray(np.asarray(p, np.float32).reshape(-1)[:3])
+        ok = _lib.lib().pwn_hip_project_point(_ptr(_colmajor(self._K, 3)), _ptr(_colmajor(self._transform, 4)), self._minDistance, self._maxDistance,
+                                              _ptr(pt), C.byref(x), C.byref(y), C.byref(d))
+        return bool(ok), x.value, y.value, d.value
+
+    def unProjectPixel(self, x, y, d):
+        """unProject(p, x, y, d) -> (valid, point[3]); x = column, y = row"""
+        out = np.zeros(3, np.float32)
+        ok = _lib.lib().pwn_hip_unproject_pixel(_ptr(_colmajor(self._K, 3)), _ptr(_colmajor(self._transform, 4)), self._minDistance, self._maxDistance,
+                                                int(x), int(y), float(d), _ptr(out))
+        return bool(ok), out
+
+    def projectInterval(self, x, y, d, worldRadius):
+        """projectInterval(x, y, d, worldRadius) -> pixels, -1 for a depth outside [min, max]"""
+        return int(_lib.lib().pwn_hip_project_interval(_ptr(_colmajor(self._K, 3)), self._minDistance, self._maxDistance, float(d), float(worldRadius)))
+
     def project(self, cloud: Cloud):
         """project(indexImage, depthImage, points) (pinholepointprojector.cpp:33-66) -> (index, depth)"""
         ctx = cloud.ctx

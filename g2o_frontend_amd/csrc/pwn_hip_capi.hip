@@ -2050,6 +2050,46 @@ void pwn_hip_projector_matrices(const float K[9], const float T[16], float KRt[1
   if (iKRt) std::memcpy(iKRt, b.m, sizeof(b.m));
   if (iK) std::memcpy(iK, c.m, sizeof(c.m));
 }
+int pwn_hip_project_point(const float K[9], const float T[16], float min_distance, float max_distance, const float p[3], int* x, int* y, float* d) {
+  if (!K || !T || !p) return 0;
+  Mat4 KRt, iKRt; Mat3 iK;
+  projector_matrices(mat3_from(K), mat4_from(T), KRt, iKRt, iK);
+  // _project: ip = KRt * p; d = ip.z; ip *= 1 / d; round (the expressions of z32_insert / project_point in pwn_kernels.h)
+  const float ix = dot4seq(KRt(0,0), p[0], KRt(0,1), p[1], KRt(0,2), p[2], KRt(0,3), 1.0f);
+  const float iy = dot4seq(KRt(1,0), p[0], KRt(1,1), p[1], KRt(1,2), p[2], KRt(1,3), 1.0f);
+  const float dd = dot4seq(KRt(2,0), p[0], KRt(2,1), p[1], KRt(2,2), p[2], KRt(2,3), 1.0f);
+  if (d) *d = dd;
+  if (dd < min_distance || dd > max_distance) return 0;
+  const float inv = 1.0f / dd;
+  const float fx = roundf(ix * inv), fy = roundf(iy * inv);
+  // the reference converts whatever comes out to int (undefined for values an int cannot hold); saturate instead
+  const float lim = 2147483520.0f;
+  if (x) *x = (int)(fx > lim ? lim : (fx < -lim ? -lim : fx));
+  if (y) *y = (int)(fy > lim ? lim : (fy < -lim ? -lim : fy));
+  return 1;
+}
+int pwn_hip_unproject_pixel(const float K[9], const float T[16], float min_distance, float max_distance, int x, int y, float d, float p[3]) {
+  if (!K || !T || !p) return 0;
+  if (d < min_distance || d > max_distance) return 0;
+  Mat4 KRt, iKRt; Mat3 iK;
+  projector_matrices(mat3_from(K), mat4_from(T), KRt, iKRt, iK);
+  const float a = (float)x * d, b = (float)y * d;                      // _unProject: iKRt * (x d, y d, d, 1): the expressions of k_unproject
+  p[0] = dot4seq(iKRt(0,0), a, iKRt(0,1), b, iKRt(0,2), d, iKRt(0,3), 1.0f);
+  p[1] = dot4seq(iKRt(1,0), a, iKRt(1,1), b, iKRt(1,2), d, iKRt(1,3), 1.0f);
+  p[2] = dot4seq(iKRt(2,0), a, iKRt(2,1), b, iKRt(2,2), d, iKRt(2,3), 1.0f);
+  return 1;
+}
+int pwn_hip_project_interval(const float K[9], float min_distance, float max_distance, float d, float world_radius) {
+  if (!K) return -1;
+  if (d < min_distance || d > max_distance) return -1;
+  const Mat3 Km = mat3_from(K);
+  // _projectInterval: p = K * (R, R, 0); p *= 1 / d; the larger of x, y truncated (make_convert_params / k_unproject evaluate the same)
+  const float ivx = dot3seq(Km(0,0), world_radius, Km(0,1), world_radius, Km(0,2), 0.f);
+  const float ivy = dot3seq(Km(1,0), world_radius, Km(1,1), world_radius, Km(1,2), 0.f);
+  const float inv = 1.0f / d;
+  const float px = ivx * inv, py = ivy * inv;
+  return (px > py) ? (int)px : (int)py;
+}
 void pwn_hip_iso_inverse(const float T[16], float out[16]) { const Mat4 r = iso_inverse(mat4_from(T)); std::memcpy(out, r.m, sizeof(r.m)); }
 void pwn_hip_iso_mul(const float A[16], const float B[16], float out[16]) { const Mat4 r = iso_mul(mat4_from(A), mat4_from(B)); std::memcpy(out, r.m, sizeof(r.m)); }
 void pwn_hip_v2t(const float v[6], float T[16]) { const Mat4 t = v2t(v); std::memcpy(T, t.m, sizeof(t.m)); }

@@ -167,6 +167,10 @@ class PinholePointProjector {
   }
   // unProject(points, indexImage, depthImage) (.cpp:68-91 / :93-133 without the Gaussians): fills the cloud's points with this projector's
   // transform, the other fields are reset to "invalid"
+  // the single-point forms (pinholepointprojector.h:174,187,200): host code, the kernels' own expressions
+  bool project(int& x, int& y, float& f, const float p[3]) const { return pwn_hip_project_point(_cameraMatrix.data(), _transform.data(), _minDistance, _maxDistance, p, &x, &y, &f) != 0; }
+  bool unProject(float p[3], int x, int y, float d) const { return pwn_hip_unproject_pixel(_cameraMatrix.data(), _transform.data(), _minDistance, _maxDistance, x, y, d, p) != 0; }
+  int projectInterval(int, int, float d, float worldRadius) const { return pwn_hip_project_interval(_cameraMatrix.data(), _minDistance, _maxDistance, d, worldRadius); }
   void unProject(Context& ctx, Cloud& cloud, IntImage& indexImage, const DepthImage& depthImage) const {
     indexImage.create(depthImage.rows, depthImage.cols);
     const pwn_hip_converter_params p = stageParams(0.1f);

@@ -425,6 +425,15 @@ int pwn_hip_cloud_load(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud, const char* filen
 /* ------------------------------------------------------------------ helpers ------------------ */
 /* PinholePointProjector::_updateMatrices (pinholepointprojector.cpp:17-31): KRt, iKRt (4x4), iK (3x3) */
 void pwn_hip_projector_matrices(const float K[9], const float T[16], float KRt[16], float iKRt[16], float iK[9]);
+/* The single-point forms of the projector (host code; the very expressions the kernels evaluate, so a point projected here lands on the pixel
+ * pwn_hip_project gives it):
+ *   PinholePointProjector::project(x, y, f, p)      (pinholepointprojector.h:174, _project :224-233): 1 = valid (depth inside [min, max]); the image
+ *                                                   bounds are the caller's test, as in the reference (pinholepointprojector.cpp:51-55)
+ *   PinholePointProjector::unProject(p, x, y, d)    (:187, _unProject :246-251): 1 = valid; x = column, y = row (pinholepointprojector.cpp:112)
+ *   PinholePointProjector::projectInterval(x,y,d,R) (:200, _projectInterval :264-274): -1 for a depth outside [min, max] */
+int pwn_hip_project_point(const float K[9], const float T[16], float min_distance, float max_distance, const float p[3], int* x, int* y, float* d);
+int pwn_hip_unproject_pixel(const float K[9], const float T[16], float min_distance, float max_distance, int x, int y, float d, float p[3]);
+int pwn_hip_project_interval(const float K[9], float min_distance, float max_distance, float d, float world_radius);
 /* Eigen::Isometry3f::inverse() and Isometry3f * Isometry3f with the evaluation order the CPU path has (host code) */
 void pwn_hip_iso_inverse(const float T[16], float out[16]);
 void pwn_hip_iso_mul(const float A[16], const float B[16], float out[16]);

@@ -317,3 +317,45 @@ def test_product_sources_carry_no_compile_time_or_environment_switches():
             assert not re.match(r"\s*#\s*(if|ifdef|ifndef|elif|else|endif)\b", line), (f, n, line)
         assert "getenv" not in text, f
     assert not [x for x in build.FLAGS if x.startswith("-D")]
+
+
+def test_single_point_projector_forms_against_the_numpy_model():
+    """PinholePointProjector::project(x, y, f, p) / unProject(p, x, y, d) / projectInterval (pinholepointprojector.h:174,187,200) are host code of the
+    library (no GPU): against the numpy statement of the reference's lines (tests/numpy_reference_model.py), point by point, bit for bit."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy_reference_model as M
+    from g2o_frontend_amd import api, synth
+    K = synth.K_VGA
+    rng = np.random.default_rng(5)
+    T = synth.v2t(np.array([0.04, -0.03, 0.05, 0.01, -0.015, 0.02])).astype(np.float32)
+    proj = api.PinholePointProjector()
+    proj.setCameraMatrix([[K[0], 0, K[2]], [0, K[1], K[3]], [0, 0, 1]]); proj.setTransform(T); proj.setMinDistance(0.5); proj.setMaxDistance(4.5)
+    KRt, iKRt, _ = M.projector_matrices(K, T)
+    # unProject: pixels of a synthetic depth image (out-of-range depths included)
+    depth = rng.uniform(0.2, 5.0, (12, 16)).astype(np.float32)
+    valid, x, y, z = M.unproject(depth, iKRt, 0.5, 4.5)
+    P = []
+    for r in range(12):
+        for c in range(16):
+            ok, p = proj.unProjectPixel(c, r, depth[r, c])
+            assert ok == bool(valid[r, c])
+            if ok:
+                assert np.array_equal(p.view(np.uint32), np.array([x[r, c], y[r, c], z[r, c]], np.float32).view(np.uint32)), (r, c)
+                P.append(p)
+    # project: those points back through the same projector; the model's image is what the single-point results scatter to
+    P = np.array(P, np.float32)
+    x_, y_, z_ = P[:, 0], P[:, 1], P[:, 2]
+    row = lambda k: ((KRt[k, 0] * x_ + KRt[k, 1] * y_) + KRt[k, 2] * z_) + KRt[k, 3] * np.float32(1.0)      # noqa: E731
+    ix, iy, d = row(0), row(1), row(2)
+    for i in range(len(P)):
+        ok, px, py, pd = proj.projectPoint(P[i])
+        assert np.float32(pd).view(np.uint32) == d[i].view(np.uint32)
+        assert ok == (not (d[i] < np.float32(0.5) or d[i] > np.float32(4.5)))
+        if ok:
+            inv = np.float32(1.0) / d[i]
+            assert (px, py) == (int(M.roundf(ix[i] * inv)), int(M.roundf(iy[i] * inv))), i
+    # projectInterval
+    itv = M.intervals(depth, valid, K, 0.1)
+    for r in range(12):
+        for c in range(16):
+            assert proj.projectInterval(c, r, depth[r, c], 0.1) == int(itv[r, c]), (r, c)

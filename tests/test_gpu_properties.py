@@ -280,3 +280,47 @@ def test_index_shortcut_is_the_projection_it_replaces(world):
     c = api.Cloud(ctx, rows * cols)
     conv.compute(c, np.asarray(world["pairs"][5][1], np.float32) * np.float32(0.001))
     assert np.array_equal(conv.indexImage(), on["images"][1]["cur_index"])
+
+
+def test_single_point_projector_forms_are_the_kernels_expressions():
+    """PinholePointProjector::project(x, y, f, p) / unProject(p, x, y, d) / projectInterval (host code of the library) against what the kernels wrote for
+    the same pixels and points: the converter's points and interval image, and the index / depth images of a projection under a non-identity camera pose."""
+    from g2o_frontend_amd import api
+    from conftest import case_params, make_depth_pair
+    from test_gpu_parity import gpu_objects
+    name = "small"
+    rows, cols, K, conv, alig = case_params(name)
+    ref, _, _, _, _ = make_depth_pair(name, 6)
+    ctx = api.Context(0, rows, cols, 2)
+    proj, converter, _ = gpu_objects(ctx, name)
+    cloud = api.Cloud(ctx, rows * cols)
+    converter.compute(cloud, ref)
+    idx, itv = converter.indexImage(), converter.intervalImage()
+    P = cloud.arrays()["points"][:, :3]
+    rng = np.random.default_rng(3)
+    pix = rng.integers(0, rows * cols, 400)
+    seen = 0
+    for q in pix:
+        r, c = divmod(int(q), cols)
+        ok, p = proj.unProjectPixel(c, r, ref[r, c])
+        assert ok == (idx[r, c] >= 0)
+        assert proj.projectInterval(c, r, ref[r, c], conv["world_radius"]) == itv[r, c]
+        if ok:
+            assert np.array_equal(p.view(np.uint32), np.ascontiguousarray(P[idx[r, c]]).view(np.uint32)), (r, c)
+            seen += 1
+    assert seen > 300
+    # a projection from another pose: the pixel and depth a point gets here are where the kernel put it -- unless a nearer point won that pixel
+    from g2o_frontend_amd import synth
+    proj.setTransform(synth.v2t(np.array([0.03, -0.02, 0.04, 0.01, -0.012, 0.015])).astype(np.float32))
+    pidx, pdep = proj.project(cloud)
+    won = 0
+    for i in rng.integers(0, len(P), 400):
+        ok, x, y, d = proj.projectPoint(P[i])
+        if not ok or not (0 <= x < cols and 0 <= y < rows):
+            continue
+        assert pidx[y, x] >= 0 and pdep[y, x] <= np.float32(d)
+        if pidx[y, x] == i:
+            assert np.float32(d).view(np.uint32) == pdep[y, x].view(np.uint32)
+            won += 1
+    assert won > 250
+    ctx.close()
