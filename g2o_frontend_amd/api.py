@@ -358,6 +358,22 @@ class Cloud:
         """pwn_hip_cloud_import: this cloud becomes the cloud `buffer` was exported from (same omega storage, capacity >= its points)"""
         self.ctx.check(self.ctx._L.pwn_hip_cloud_import(self.ctx.h, self.h, _ptr(buffer), _nbytes(buffer)))
 
+    # the reference's per-field accessors (cloud.h:33-131) as host copies: each is one download of that field
+    def _field(self, i, width):
+        n = self.size()
+        out = [None] * 5
+        out[i] = np.empty((n, width) if width > 1 else n, np.float32)
+        self.ctx.check(self.ctx._L.pwn_hip_cloud_download(self.ctx.h, self.h, *[_ptr(x) for x in out]))
+        return out[i]
+
+    def points(self): return self._field(0, 4)                          # n x 4 (x, y, z, 1)
+    def normals(self): return self._field(1, 4)                         # n x 4 (nx, ny, nz, 0)
+    def curvatures(self): return self._field(2, 1)                      # Stats::curvature() per point
+    def pointInformationMatrix(self): return self._field(3, 16)         # n x 16, column-major 4x4
+    def normalInformationMatrix(self): return self._field(4, 16)
+    def stats(self): return self.arrays(stats=True)["stats"]            # n x 16 (needs a conversion with keep_stats)
+    def traversabilityVector(self): return []                           # cloud.h:99: never written on this path (only pwn_viewer code fills it)
+
     def transformInPlace(self, T):
         """pwn_core/cloud.cpp:173-186"""
         self.ctx.check(self.ctx._L.pwn_hip_cloud_transform_in_place(self.ctx.h, self.h, _ptr(_colmajor(T, 4))))
@@ -428,6 +444,8 @@ class PinholePointProjector:
         self._K[:2, :] = self._K[:2, :] * np.float32(s)
         self._imageRows = int(np.float32(self._imageRows) * np.float32(s))
         self._imageCols = int(np.float32(self._imageCols) * np.float32(s))
+
+    def inverseCameraMatrix(self): return self.matrices()[2]                                     # pinholepointprojector.h:61
 
     def matrices(self):
         """_updateMatrices (pinholepointprojector.cpp:17-31): (KRt, iKRt, iK)"""
@@ -504,6 +522,10 @@ class StatsCalculatorIntegralImage:
     def setMinImageRadius(self, v): self._minImageRadius = int(v)
     def setMinPoints(self, v): self._minPoints = int(v)
     def setCurvatureThreshold(self, v): self._curvatureThreshold = float(v)
+    def maxImageRadius(self): return self._maxImageRadius
+    def minImageRadius(self): return self._minImageRadius
+    def minPoints(self): return self._minPoints
+    def curvatureThreshold(self): return self._curvatureThreshold
 
     @staticmethod
     def integralImage(cloud: Cloud, indexImage):
@@ -520,8 +542,11 @@ class _InformationMatrixCalculator:
         self._flat, self._nonflat, self._curvatureThreshold = list(flat), list(nonflat), thr
 
     def setCurvatureThreshold(self, v): self._curvatureThreshold = float(v)
+    def curvatureThreshold(self): return self._curvatureThreshold
     def setFlatInformationMatrix(self, diag): self._flat = [float(x) for x in diag]
     def setNonFlatInformationMatrix(self, diag): self._nonflat = [float(x) for x in diag]
+    def flatInformationMatrix(self): return np.diag(np.asarray(self._flat, np.float32))          # informationmatrixcalculator.h:58,74: diagonal matrices
+    def nonFlatInformationMatrix(self): return np.diag(np.asarray(self._nonflat, np.float32))
 
 
 class PointInformationMatrixCalculator(_InformationMatrixCalculator):
@@ -546,6 +571,13 @@ class DepthImageConverterIntegralImage:
         self._intervalImage = None
 
     def projector(self): return self._projector
+    def setProjector(self, p): self._projector = p
+    def statsCalculator(self): return self._stats                                                # depthimageconverter.h:63-104: the collaborators
+    def setStatsCalculator(self, s): self._stats = s
+    def pointInformationMatrixCalculator(self): return self._pinfo
+    def setPointInformationMatrixCalculator(self, c): self._pinfo = c
+    def normalInformationMatrixCalculator(self): return self._ninfo
+    def setNormalInformationMatrixCalculator(self, c): self._ninfo = c
     def indexImage(self): return self._indexImage
     def intervalImage(self): return self._intervalImage
 
@@ -675,6 +707,11 @@ class CorrespondenceFinder:
     def setInlierNormalAngularThreshold(self, v): self._inlierNormalAngularThreshold = float(v)
     def setFlatCurvatureThreshold(self, v): self._flatCurvatureThreshold = float(v)
     def setInlierCurvatureRatioThreshold(self, v): self._inlierCurvatureRatioThreshold = float(v)
+    def inlierDistanceThreshold(self): return self._inlierDistanceThreshold
+    def squaredThreshold(self): return float(np.float32(self._inlierDistanceThreshold) * np.float32(self._inlierDistanceThreshold))      # correspondencefinder.h:133
+    def inlierNormalAngularThreshold(self): return self._inlierNormalAngularThreshold
+    def flatCurvatureThreshold(self): return self._flatCurvatureThreshold
+    def inlierCurvatureRatioThreshold(self): return self._inlierCurvatureRatioThreshold
     def setImageSize(self, rows, cols): self._rows, self._cols = int(rows), int(cols)
     def imageRows(self): return self._rows
     def imageCols(self): return self._cols
@@ -697,10 +734,14 @@ class Linearizer:
         self._aligner = None
 
     def setAligner(self, a): self._aligner = a
+    def aligner(self): return self._aligner
+    def inlierMaxChi2(self): return self._inlierMaxChi2
+    def robustKernel(self): return self._robustKernel
     def setInlierMaxChi2(self, v): self._inlierMaxChi2 = float(v)
     def setRobustKernel(self, v): self._robustKernel = bool(v)
     def setT(self, T):
         self._T = np.asarray(T, np.float32).reshape(4, 4).copy(); self._T[3] = (0, 0, 0, 1)   # linearizer.h:62-65
+    def T(self): return self._T                                                                  # linearizer.h:55
     def H(self): return self._H
     def b(self): return self._b
     def error(self): return self._error
@@ -737,8 +778,24 @@ class Aligner:
     def correspondenceFinder(self): return self._correspondenceFinder
     def setReferenceCloud(self, c): self._referenceCloud = c; self.clearPriors()     # aligner.h:60-63 (setting a cloud clears the priors)
     def setCurrentCloud(self, c): self._currentCloud = c; self.clearPriors()         # aligner.h:77-80
+    def referenceCloud(self): return self._referenceCloud
+    def currentCloud(self): return self._currentCloud
     def setOuterIterations(self, n): self._outerIterations = int(n)
     def setInnerIterations(self, n): self._innerIterations = int(n)
+    def outerIterations(self): return self._outerIterations
+    def innerIterations(self): return self._innerIterations
+    def initialGuess(self): return self._initialGuess
+    def sensorOffset(self): return self._referenceSensorOffset                                   # aligner.h:141: the reference sensor offset
+    def referenceSensorOffset(self): return self._referenceSensorOffset
+    def currentSensorOffset(self): return self._currentSensorOffset
+    def translationalMinEigenRatio(self): return self._translationalMinEigenRatio
+    def rotationalMinEigenRatio(self): return self._rotationalMinEigenRatio
+    # aligner.h:216-239: _debug only switches the reference's terminal output on, _minInliers is set by the constructor and never read (aligner.cpp:28): both
+    # are kept as inert state so that configuration code written for the reference runs unchanged
+    def debug(self): return getattr(self, "_debug", False)
+    def setDebug(self, v): self._debug = bool(v)
+    def minInliers(self): return getattr(self, "_minInliers", 100)
+    def setMinInliers(self, v): self._minInliers = int(v)
     def setInitialGuess(self, T): self._initialGuess = self._iso(T)
     def setSensorOffset(self, T): self._referenceSensorOffset = self._iso(T); self._currentSensorOffset = self._iso(T)
     def setReferenceSensorOffset(self, T): self._referenceSensorOffset = self._iso(T)

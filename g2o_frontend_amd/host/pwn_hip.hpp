@@ -130,6 +130,10 @@ class Cloud {
   std::vector<float> curvatures() const { std::vector<float> v(size()); _ctx->check(pwn_hip_cloud_download(_ctx->handle(), _h, nullptr, nullptr, v.data(), nullptr, nullptr)); return v; }
   std::vector<float> pointInformationMatrix() const { std::vector<float> v(size() * 16); _ctx->check(pwn_hip_cloud_download(_ctx->handle(), _h, nullptr, nullptr, nullptr, v.data(), nullptr)); return v; }
   std::vector<float> normalInformationMatrix() const { std::vector<float> v(size() * 16); _ctx->check(pwn_hip_cloud_download(_ctx->handle(), _h, nullptr, nullptr, nullptr, nullptr, v.data())); return v; }
+  // n*16 floats: eigenvectors + mean as a column-major 4x4 per point (Stats, stats.h:13); needs a conversion that kept them (scene clouds)
+  std::vector<float> stats() const { std::vector<float> v(size() * 16); _ctx->check(pwn_hip_cloud_download_stats(_ctx->handle(), _h, v.data(), nullptr, nullptr)); return v; }
+  std::vector<int> traversabilityVector() const { return std::vector<int>(); }      // cloud.h:99: never written on this path
+  size_t gaussians() const { return numGaussians(); }                              // cloud.h:131: the sensor-noise Gaussians live on the device (pwn_hip_cloud_download_gaussians)
   void transformInPlace(const Isometry3f& T) { _ctx->check(pwn_hip_cloud_transform_in_place(_ctx->handle(), _h, T.data())); }   // cloud.cpp:173-186
   // scene maintenance (cloud.cpp:11-171)
   void add(const Cloud& cloud, const Isometry3f& T = Isometry3f::Identity()) { _ctx->check(pwn_hip_cloud_add(_ctx->handle(), _h, cloud.handle(), T.data())); }
@@ -167,6 +171,7 @@ class PinholePointProjector {
   }
   // unProject(points, indexImage, depthImage) (.cpp:68-91 / :93-133 without the Gaussians): fills the cloud's points with this projector's
   // transform, the other fields are reset to "invalid"
+  Matrix3f inverseCameraMatrix() const { Matrix3f iK; float a[16], b[16]; pwn_hip_projector_matrices(_cameraMatrix.data(), _transform.data(), a, b, iK.data()); return iK; }   // :61
   // the single-point forms (pinholepointprojector.h:174,187,200): host code, the kernels' own expressions
   bool project(int& x, int& y, float& f, const float p[3]) const { return pwn_hip_project_point(_cameraMatrix.data(), _transform.data(), _minDistance, _maxDistance, p, &x, &y, &f) != 0; }
   bool unProject(float p[3], int x, int y, float d) const { return pwn_hip_unproject_pixel(_cameraMatrix.data(), _transform.data(), _minDistance, _maxDistance, x, y, d, p) != 0; }
@@ -217,6 +222,8 @@ class InformationMatrixCalculator {
   InformationMatrixCalculator(float f0, float f1, float f2) { _flat[0] = f0; _flat[1] = f1; _flat[2] = f2; _nonFlat[0] = _nonFlat[1] = _nonFlat[2] = 1.f; }
   float curvatureThreshold() const { return _curvatureThreshold; } void setCurvatureThreshold(float v) { _curvatureThreshold = v; }
   const float* flatDiagonal() const { return _flat; }  const float* nonFlatDiagonal() const { return _nonFlat; }
+  Matrix3f flatInformationMatrix() const { Matrix3f m; std::memset(m.m, 0, sizeof(m.m)); m(0,0) = _flat[0]; m(1,1) = _flat[1]; m(2,2) = _flat[2]; return m; }        // informationmatrixcalculator.h:58
+  Matrix3f nonFlatInformationMatrix() const { Matrix3f m; std::memset(m.m, 0, sizeof(m.m)); m(0,0) = _nonFlat[0]; m(1,1) = _nonFlat[1]; m(2,2) = _nonFlat[2]; return m; }   // :74
   void setFlatInformationMatrix(float a, float b, float c) { _flat[0] = a; _flat[1] = b; _flat[2] = c; }
   void setNonFlatInformationMatrix(float a, float b, float c) { _nonFlat[0] = a; _nonFlat[1] = b; _nonFlat[2] = c; }
  protected:
@@ -233,7 +240,12 @@ class DepthImageConverter {
       : _ctx(ctx), _projector(projector), _statsCalculator(statsCalculator), _pointInformationMatrixCalculator(pointInfo),
         _normalInformationMatrixCalculator(normalInfo) {}
   virtual ~DepthImageConverter() {}
-  PinholePointProjector* projector() { return _projector; }
+  PinholePointProjector* projector() { return _projector; }                               void setProjector(PinholePointProjector* p) { _projector = p; }
+  StatsCalculatorIntegralImage* statsCalculator() { return _statsCalculator; }            void setStatsCalculator(StatsCalculatorIntegralImage* s) { _statsCalculator = s; }      // depthimageconverter.h:63-104
+  PointInformationMatrixCalculator* pointInformationMatrixCalculator() { return _pointInformationMatrixCalculator; }
+  void setPointInformationMatrixCalculator(PointInformationMatrixCalculator* c) { _pointInformationMatrixCalculator = c; }
+  NormalInformationMatrixCalculator* normalInformationMatrixCalculator() { return _normalInformationMatrixCalculator; }
+  void setNormalInformationMatrixCalculator(NormalInformationMatrixCalculator* c) { _normalInformationMatrixCalculator = c; }
   IntImage& indexImage() { return _indexImage; }
   // The reference fills Cloud::gaussians() inside every compute() (depthimageconverterintegralimage.cpp:39); only Merger::merge reads
   // them, so here they are produced when asked for (clouds that will enter a scene).
@@ -310,6 +322,7 @@ class Merger {
   DepthImageConverter* depthImageConverter() const { return _depthImageConverter; }
   void setDepthImageConverter(DepthImageConverter* c) { _depthImageConverter = c; }
   void setImageSize(int r, int c) { _rows = r; _cols = c; }
+  void imageSize(int& r, int& c) const { r = _rows; c = _cols; }                // merger.h: the size of the merger's index / depth images
   const std::vector<int>& collapsedIndices() const { return _collapsedIndices; }
   // needs the cloud's sensor-noise Gaussians (pwn_hip_cloud_gaussians after every convert that feeds the scene)
   void merge(Cloud* cloud, Isometry3f transform = Isometry3f::Identity()) {
@@ -347,6 +360,7 @@ class CorrespondenceFinder {
   float inlierNormalAngularThreshold() const { return _inlierNormalAngularThreshold; }  void setInlierNormalAngularThreshold(float v) { _inlierNormalAngularThreshold = v; }
   float flatCurvatureThreshold() const { return _flatCurvatureThreshold; }              void setFlatCurvatureThreshold(float v) { _flatCurvatureThreshold = v; }
   float inlierCurvatureRatioThreshold() const { return _inlierCurvatureRatioThreshold; } void setInlierCurvatureRatioThreshold(float v) { _inlierCurvatureRatioThreshold = v; }
+  float squaredThreshold() const { return _inlierDistanceThreshold * _inlierDistanceThreshold; }                          // correspondencefinder.h:133
   void setImageSize(int r, int c) { _rows = r; _cols = c; }
   int imageRows() const { return _rows; }  int imageCols() const { return _cols; }
   int numCorrespondences() const { return _numCorrespondences; }
@@ -368,7 +382,8 @@ class Aligner;
 // linearizer.{h,cpp} (defaults .cpp:9-15)
 class Linearizer {
  public:
-  void setAligner(Aligner* a) { _aligner = a; }
+  void setAligner(Aligner* a) { _aligner = a; }  Aligner* aligner() { return _aligner; }
+  Isometry3f T() const { return _T; }  void setT(Isometry3f T) { T.forceLastRow(); _T = T; }                         // linearizer.h:55,62-65
   float inlierMaxChi2() const { return _inlierMaxChi2; }  void setInlierMaxChi2(float v) { _inlierMaxChi2 = v; }
   bool robustKernel() const { return _robustKernel; }      void setRobustKernel(bool v) { _robustKernel = v; }
   float error() const { return _error; }  int inliers() const { return _inliers; }
@@ -376,7 +391,7 @@ class Linearizer {
  private:
   friend class Aligner;
   Aligner* _aligner = nullptr; float _inlierMaxChi2 = 9e3f; bool _robustKernel = true; float _error = 0.f; int _inliers = 0;
-  Matrix6f _H; Vector6f _b;
+  Matrix6f _H; Vector6f _b; Isometry3f _T;
 };
 
 // aligner.{h,cpp}
@@ -387,6 +402,12 @@ class Aligner {
   void setProjector(PinholePointProjector* p) { _projector = p; }            PinholePointProjector* projector() { return _projector; }
   void setLinearizer(Linearizer* l) { _linearizer = l; if (l) l->setAligner(this); }  Linearizer* linearizer() { return _linearizer; }
   void setCorrespondenceFinder(CorrespondenceFinder* f) { _correspondenceFinder = f; } CorrespondenceFinder* correspondenceFinder() { return _correspondenceFinder; }
+  Cloud* referenceCloud() { return _referenceCloud; }  Cloud* currentCloud() { return _currentCloud; }
+  const Isometry3f& initialGuess() const { return _initialGuess; }
+  const Isometry3f& sensorOffset() const { return _referenceSensorOffset; }                                           // aligner.h:141
+  const Isometry3f& referenceSensorOffset() const { return _referenceSensorOffset; }  const Isometry3f& currentSensorOffset() const { return _currentSensorOffset; }
+  // aligner.h:216-239: _debug only switches the reference's terminal output on, _minInliers is never read (aligner.cpp:28): inert state, kept for configuration code
+  bool debug() const { return _debug; }  void setDebug(bool v) { _debug = v; }  int minInliers() const { return _minInliers; }  void setMinInliers(int v) { _minInliers = v; }
   void setReferenceCloud(Cloud* c) { _referenceCloud = c; clearPriors(); }                                           // aligner.h:60-63: setting a cloud clears the priors
   void setCurrentCloud(Cloud* c) { _currentCloud = c; clearPriors(); }                                               // aligner.h:77-80
   // aligner.cpp:34-47, se3_prior.h
@@ -534,7 +555,7 @@ class Aligner {
   }
   Context* _ctx;
   PinholePointProjector* _projector = nullptr; Linearizer* _linearizer = nullptr; CorrespondenceFinder* _correspondenceFinder = nullptr;
-  Cloud* _referenceCloud = nullptr; Cloud* _currentCloud = nullptr;
+  Cloud* _referenceCloud = nullptr; Cloud* _currentCloud = nullptr; bool _debug = false; int _minInliers = 100;
   std::vector<pwn_hip_prior> _priors;
   bool _computeStatistics = false;
   Matrix6f _omega; Vector6f _mean;

@@ -309,6 +309,12 @@ def test_single_point_projector_forms_are_the_kernels_expressions():
             assert np.array_equal(p.view(np.uint32), np.ascontiguousarray(P[idx[r, c]]).view(np.uint32)), (r, c)
             seen += 1
     assert seen > 300
+    # the per-field accessors of pwn::Cloud (cloud.h:33-131) are the fields of arrays()
+    A = cloud.arrays()
+    for name, got in (("points", cloud.points()), ("normals", cloud.normals()), ("curvature", cloud.curvatures()), ("omega_p", cloud.pointInformationMatrix()),
+                      ("omega_n", cloud.normalInformationMatrix())):
+        assert np.array_equal(got.view(np.uint32), A[name].view(np.uint32)), name
+    assert cloud.traversabilityVector() == []
     # a projection from another pose: the pixel and depth a point gets here are where the kernel put it -- unless a nearer point won that pixel
     from g2o_frontend_amd import synth
     proj.setTransform(synth.v2t(np.array([0.03, -0.02, 0.04, 0.01, -0.012, 0.015])).astype(np.float32))
