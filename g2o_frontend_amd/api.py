@@ -999,6 +999,8 @@ class PwnMatcherBase:
     def setScale(self, s): self._scale = int(s)
     def aligner(self): return self._aligner
     def converter(self): return self._converter
+    def setAligner(self, a): self._aligner = a                                                   # pwn_matcher_base.h:30,33
+    def setConverter(self, c): self._converter = c
 
     def makeCloud(self, cameraMatrix, sensorOffset, depthImage, ctx: Context = None):
         """pwn_matcher_base.cpp:57-86 -> (cloud, r, c, scaledCameraMatrix)"""
@@ -1215,6 +1217,7 @@ class PwnTracker(PwnMatcherBase):
     def globalT(self): return self._globalT
     def numKeyframes(self): return self._numKeyframes
     def setNewFrameInliersFraction(self, v): self._newFrameInliersFraction = float(v)
+    def newFrameInliersFraction(self): return self._newFrameInliersFraction
 
     def init(self):
         """pwn_tracker.cpp:38-49"""

@@ -581,6 +581,7 @@ struct PwnMatcherBase {
   int scale() const { return _scale; }  void setScale(int s) { _scale = s; }
   float frameInlierDepthThreshold() const { return _frameInlierDepthThreshold; }  void setFrameInlierDepthThreshold(float v) { _frameInlierDepthThreshold = v; }
   Aligner* aligner() { return _aligner; }  DepthImageConverter* converter() { return _converter; }
+  void setAligner(Aligner* a) { _aligner = a; }  void setConverter(DepthImageConverter* c) { _converter = c; }      // pwn_matcher_base.h:30,33
 
   // .cpp:57-86: returns a new Cloud owned by the caller; r, c, cameraMatrix receive the scaled values.  DepthImage_scale (:72) and
   // converter->compute (:79) run as one device-side call (no scaled image on the host); same side effects on the converter's projector.

@@ -8,19 +8,21 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = "/root/reference/g2o_frontend/pwn_core"
+TRK = "/root/reference/g2o_frontend/pwn_tracker"
 pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="needs the reference headers under /root/reference")
 
 CLASSES = [("Aligner", "aligner.h"), ("CorrespondenceFinder", "correspondencefinder.h"), ("Linearizer", "linearizer.h"),
            ("DepthImageConverterIntegralImage", "depthimageconverter.h"), ("StatsCalculatorIntegralImage", "statscalculatorintegralimage.h"),
            ("PointInformationMatrixCalculator", "informationmatrixcalculator.h"), ("PinholePointProjector", "pinholepointprojector.h"),
-           ("PinholePointProjector", "pointprojector.h"), ("Cloud", "cloud.h"), ("Merger", "merger.h"), ("VoxelCalculator", "voxelcalculator.h")]
+           ("PinholePointProjector", "pointprojector.h"), ("Cloud", "cloud.h"), ("Merger", "merger.h"), ("VoxelCalculator", "voxelcalculator.h"),
+           ("PwnMatcherBase", "pwn_matcher_base.h"), ("PwnTracker", "pwn_tracker.h")]       # the callers of the path (pwn_tracker/): SURVEY.md 8(f)
 # members whose reference form returns an internal container the device path has no host copy of (documented per class in the mirrors)
 NOT_MIRRORED = {"StatsCalculatorIntegralImage": {"integralImage", "intervalImage"},      # the converter's interval image: DepthImageConverter.intervalImage(); integral planes: StatsCalculatorIntegralImage.integralImage(cloud, indexImage)
                 "PinholePointProjector": {"project", "unProject", "projectInterval"}}      # single-point forms: projectPoint / unProjectPixel / projectInterval in Python (no overloading); same names in C++
 
 
 def _inline_names(header):
-    text = open(os.path.join(REF, header)).read()
+    text = open(os.path.join(TRK if header.startswith("pwn_") else REF, header)).read()
     names = set()
     for m in re.finditer(r"inline\s+[^;{(]*?[\s&*]([A-Za-z]\w*)\s*\(", text):
         n = m.group(1)
