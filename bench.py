@@ -1185,6 +1185,15 @@ def multi_gpu_diagnostics(w, args, rank, world, dt_rank, dt_serial, pinned, n_co
             "collectives_alone": dict(coll, steps=n_collective, note="no compute between the collectives; ms per call, this rank's clock after a device sync")}
 
 
+_T0 = time.time()
+
+
+def _progress(rank, world, msg):
+    """one stderr line per phase and rank in multi-rank runs: the 8-GPU run cannot be repeated, so if a rank stalls the log says where"""
+    if world > 1:
+        print(f"[bench rank {rank}/{world} +{time.time() - _T0:6.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 # ------------------------------------------------------------------------------------------------ main
 def main():
     args = parse()
@@ -1241,7 +1250,9 @@ def main():
         poses = synth.trajectory_sweep(9, args.tracker_frames)
         jobs += [("frame", 9, poses[k].tolist(), 480, 640, synth.K_VGA, k) for k in range(args.tracker_frames)]
     # a pinned rank owns its cores: the pool takes all of them; unpinned ranks share the box (cores // world each)
+    _progress(rank, world, f"pinned to {len(pinned) if pinned else 0} cpus; rendering {len(jobs)} jobs")
     rendered = render_all(jobs, 1 if pinned else world, args.render_workers)
+    _progress(rank, world, "frames rendered; initialising the GPU and the process group")
     nmain = P + 1 if partition else P
     frames_mm = rendered[:nmain]; frames5 = rendered[nmain:nmain + n5]; frames_trk = rendered[nmain + n5:]
 
@@ -1265,13 +1276,16 @@ def main():
             os.dup2(saved_fd, 1)
             os.close(saved_fd)
     n_seen = dist.get_world_size() if use_dist else 1                            # the ranks the process group actually holds
+    _progress(rank, world, f"process group of {n_seen} up; building the workload ({P} items)")
 
     if partition:
         w = PartitionWorkload(args, local, rows, cols, seeds, frames_mm[:P], frames_mm[P], use_dist, world, rank, total)
     else:
         w = BatchWorkload(args, local, rows, cols, P, frames_mm, seeds, use_dist, world)
         w.total = total; w.Pmax = (total + world - 1) // world
+    _progress(rank, world, "workload resident; warm-up + timed region + serial profiled pass")
     dt_rank, dt_serial = w.run(args.steps, args.warmup, profile=not args.no_profile)
+    _progress(rank, world, f"timed region {dt_rank / max(args.steps, 1) * 1e3:.3f} ms per step on this rank")
     dt = dt_rank
     if use_dist:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -1420,6 +1434,7 @@ def main():
         out.update(extra)
         print(json.dumps(out))
     if use_dist:
+        _progress(rank, world, "done; final barrier")
         dist.barrier()
         dist.destroy_process_group()
 
