@@ -413,3 +413,35 @@ def test_flat_clouds_and_match_records_on_disturbed_inputs():
         assert np.array_equal(_bits(rec_a), _bits(rec_b)), storage
         assert (rec_a[:, 18] == 10).all() and (rec_a[:, 64] > 0).all()
         ctx.close()
+
+
+def test_flat_cloud_at_1280x960():
+    """BASELINE configs[4]'s frame size: a 1.2 M-point cloud (sym6: 64 MB flat) through a device buffer into another context; arrays equal, and the
+    replica aligns like the original (one pair, identity guess)."""
+    from g2o_frontend_amd import api, synth
+    from test_gpu_parity import gpu_objects
+    name = "k2"
+    rows, cols, K, conv, alig = case_params(name)
+    ref_mm, cur_mm, _ = synth.make_pair(11, rows, cols, K)
+    ctx = api.Context(0, rows, cols, 2, omega_storage="sym6")
+    _, converter, aligner = gpu_objects(ctx, name)
+    N = rows * cols
+    a, b = api.Cloud(ctx, N), api.Cloud(ctx, N)
+    converter.computeBatch([a, b], [ref_mm, cur_mm], raw_scale=0.001)
+    assert a.size() > 1_000_000
+    flat = ctx.upload(np.zeros(api.Cloud.flatBound(N, "sym6", N), np.uint8))
+    used = a.exportFlat(flat)
+    assert 60e6 < used <= flat.nbytes
+    ctx2 = api.Context(0, rows, cols, 2, omega_storage="sym6")
+    _, _, aligner2 = gpu_objects(ctx2, name)
+    ra, rb = api.Cloud(ctx2, N), api.Cloud(ctx2, N)
+    ra.importFlat(flat)
+    b.exportFlat(flat); rb.importFlat(flat)
+    _same_cloud(a, ra); _same_cloud(b, rb)
+    aligner.setReferenceCloud(a); aligner.setCurrentCloud(b)
+    base = aligner.align()
+    aligner2.setReferenceCloud(ra); aligner2.setCurrentCloud(rb)
+    g = aligner2.align()
+    for k in ("T", "chi2", "C", "K", "iter_inliers"):
+        assert np.array_equal(_bits(g[k]), _bits(base[k])), k
+    flat.free(); ctx2.close(); ctx.close()
