@@ -26,6 +26,15 @@ def test_test_hooks_are_not_in_the_boundary_header():
     assert "debug_" not in src and "pwn_hip_debug_withhold_carry" in open(os.path.join(ROOT, "include", "pwn_hip_testing.h")).read()
 
 
+def test_boundary_headers_are_plain_c():
+    """The boundary is a C ABI (cgo / JNI / ctypes bind it): a C99 compiler takes both headers as they are, warnings on."""
+    import subprocess
+    for h in ("pwn_hip.h", "pwn_hip_testing.h"):
+        r = subprocess.run(["gcc", "-x", "c", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", os.path.join(ROOT, "include", h)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr[-600:]
+
+
 def test_library_exports_every_declared_symbol():
     from g2o_frontend_amd import _lib
     names = declared_symbols()
