@@ -71,6 +71,9 @@ def parse(argv=None):
     ap.add_argument("--write-records-crc", action="store_true",
                     help="N = 1 only: write profiles/records_crc.json (per-pair CRC32 of the result records) -- multi-GPU runs check their assembled records against it")
     ap.add_argument("--check-gather", action="store_true", help="kept for scripts: the `gather` object (backend, records, equality with the local records) is always in the line")
+    ap.add_argument("--partition-serial", action="store_true",
+                    help="--mode partition without the look-ahead: convert `current`, export, broadcast the buffer's bound, import, match -- one after the other "
+                         "(round 5's step; the default converts and broadcasts the next keyframes beside the matches)")
     ap.add_argument("--mode", choices=("pairs", "partition"), default="pairs",
                     help="pairs (default, the headline): independent fresh pairs, convert 2 frames + align each.  partition: PwnCloser::processPartition "
                          "(pwn_tracker/pwn_closer.cpp:85-111; SURVEY.md 8(e)) -- ONE `current` frame against the cached clouds of the other partition: every rank "
@@ -327,12 +330,14 @@ def cpu_baseline_child(args):
 STAGES = ["u16_to_f32", "unproject", "integral", "integral_rows", "integral_cols", "stats", "project_cur", "project_ref", "corr_linearize", "solve"]
 
 
-def align_bytes(N, n_it, res, proj_cur_per_pair, proj_ref_per_pair):
-    """algorithmic bytes per pair from the counters the kernels emit; res: structured result array"""
+def align_bytes(N, n_it, res, proj_cur_per_pair, proj_ref_per_pair, depth_bytes=2.0):
+    """algorithmic bytes per pair from the counters the kernels emit; res: structured result array.
+    depth_bytes: bytes per pixel of the frames the converter reads -- SURVEY's 8N + 64M per frame is 4N of float depth in + 4N of index image out;
+    the benchmark's frames are uint16 millimetres (2N in: 6N + 64M per frame).  Until round 5 the line charged 4N for them."""
     N = float(N)
     Mr = res["n_reference"].astype(np.float64); Mc = res["n_current"].astype(np.float64)
     Ks = res["iter_candidates"].sum(1).astype(np.float64); Cs = res["iter_correspondences"].sum(1).astype(np.float64)
-    convert = 2 * 8.0 * N + 64.0 * (Mr + Mc)                                   # two frames: 8N + 64M each
+    convert = 2 * (depth_bytes + 4.0) * N + 64.0 * (Mr + Mc)                   # two frames: (depth in + 4N index out) + 64M each
     fused = n_it * 8.0 * N + 72.0 * Ks + 28.0 * Cs                             # all iterations
     project = proj_cur_per_pair * (16.0 * Mc + 4.0 * N) + proj_ref_per_pair * (16.0 * Mr + 4.0 * N)      # EXECUTED projections only
     align = project + fused + 8.0 * N
@@ -523,7 +528,8 @@ class BatchWorkload:
                                    "the timed region runs the streams without instrumentation",
                     "serial_pass_alignments_per_s": (self.total * steps / dt_serial) if dt_serial else None}
         return dict(value=self.total * steps / dt, ms_per_step=dt / steps * 1e3, roofline=roofline,
-                    path_roofline={"algorithmic_bytes_per_pair": total_step / P, "achieved_GBps": total_step * steps / dt / 1e9,
+                    path_roofline={"algorithmic_bytes_per_pair": total_step / P, "convert_bytes_per_pair": float(b["convert"].sum()) / P,
+                                   "depth_bytes_per_pixel_charged": 2.0, "achieved_GBps": total_step * steps / dt / 1e9,
                                    "frac_of_peak": total_step * steps / dt / 1e9 / HBM_PEAK_GBS,
                                    "projections_counted_per_pair": pc + pr},
                     stage_ms_per_step={k: self.stage_ms[k] / max(steps, 1) for k in STAGES},
@@ -565,7 +571,22 @@ class PartitionWorkload:
     replicated with ONE broadcast of its flat form (pwn_hip_cloud_export / _import), every rank runs matchFrames' data path (matchClouds:
     align from the odometry guess with the z translation zeroed + depth-agreement score, pwn_matcher_base.cpp:88-183) of `current` against its
     shard, and the 288-byte match records are all-gathered.  `current` is the aligner's REFERENCE cloud of every pair (matchFrames(current, other):
-    from = current, pwn_closer.cpp:102,128-133)."""
+    from = current, pwn_closer.cpp:102,128-133).
+
+    Pipelined (the default).  The reference's outer loop hands the closer one `current` keyframe after the other, and nothing keyframe k's matches
+    produce is needed to make the cloud of keyframe k+1.  A step is ONE library call -- the matches of keyframe k against the shard -- and everything
+    else the step needs is queued from inside that call, after its device work has been queued and before it waits (pwn_hip_ctx_set_enqueued_callback),
+    so the host's share runs while the device works:
+      * rank 0: the helper job that converted keyframe k+3 and wrote its flat form is collected, the job for keyframe k+4 started
+        (pwn_hip_convert_export_begin / _end; flat buffers form a ring of four);
+      * keyframe k+2's flat form is broadcast on a side stream -- only the bytes written; their count reached every rank in the control row of
+        step k-1's record all-gather;
+      * the all-gather of step k's records is queued behind the call's own stream (pwn_hip_ctx_signal_stream), carrying the size of keyframe k+3;
+      * replica (k+1) % 2 is imported from keyframe k+1's flat form (broadcast during step k-1) through a second, small context, next to the matches.
+    Without RCCL (one rank, plain run) the helper converts keyframe k+2 straight into a third replica.
+    --partition-serial: round 5's chain (convert, export, broadcast of the buffer's bound, import, match), kept for the A/B."""
+
+    RING = 4
 
     def __init__(self, args, device, rows, cols, ids, other_frames_mm, current_mm, use_dist, world, rank, total):
         import torch
@@ -584,32 +605,152 @@ class PartitionWorkload:
         self.matcher = api.PwnMatcherBase(self.aligner, self.converter); self.matcher.setScale(1)
         self.Km = np.array([[self.K[0], 0, self.K[2]], [0, self.K[1], self.K[3]], [0, 0, 1]], np.float32)
         self.I = np.eye(4, dtype=np.float32)
+        dev = torch.device("cuda", device)                # the context's device, whatever torch's current device is
         # the cache of the other partition: this rank's shard, converted once (untimed)
-        self.other_dev = [torch.from_numpy(f.view(np.int16)).cuda() for f in other_frames_mm]
+        self.other_dev = [torch.from_numpy(f.view(np.int16)).to(dev) for f in other_frames_mm]
         self.others = [api.Cloud(self.ctx, self.N) for _ in range(self.P)]
         if self.P:
             self.converter.computeBatch(self.others, self.other_dev, raw_scale=0.001)
         self.other_dev = None
-        self.cur_dev = torch.from_numpy(current_mm.view(np.int16)).cuda() if rank == 0 else None
-        self.current = api.Cloud(self.ctx, self.N)        # rank 0: what the converter fills; other ranks: the replica the broadcast fills
-        # rank 0 of a forced one-rank run takes the replica path too (export -> broadcast -> import into a second cloud), so that the byte path is exercised
+        self.cur_dev = torch.from_numpy(current_mm.view(np.int16)).to(dev) if rank == 0 else None
+        self.pipeline = not getattr(args, "partition_serial", False)
+        # rank 0 of a forced one-rank run takes the replica path too (export -> broadcast -> import), so that the byte path is exercised
         self.roundtrip = use_dist and world == 1
-        self.replica = api.Cloud(self.ctx, self.N) if self.roundtrip else None
-        self.flat = torch.empty(api.Cloud.flatBound(self.N, args.omega_storage, self.N), dtype=torch.uint8, device="cuda")
-        self.records = torch.empty((max(self.P, 1), api.MATCH_RECORD_FLOATS), dtype=torch.float32, device="cuda")
+        bound = api.Cloud.flatBound(self.N, args.omega_storage, self.N)
+        # rows [0:P] the records k_pack_records writes, [P:Pmax] padding, row Pmax the rank's control row (pair id -1 like padding: assemble() drops it)
+        # two of them: step k+1 packs its records while step k's all-gather may still be reading
+        self.records2 = [torch.full((self.Pmax + 1, api.MATCH_RECORD_FLOATS), -1.0, dtype=torch.float32, device=dev) for _ in range(2)]
+        self.records = self.records2[0]
         self.ids_np = np.asarray(self.ids, np.int32)
         self.guesses = partition_guesses(self.ids)
-        ref = self.replica if self.roundtrip else self.current
-        self.prep = self.matcher.matchHandles([ref] * self.P, self.others, self.guesses)
         self.stage_ms = {k: 0.0 for k in STAGES + ["match_score"]}; self.stage_n = {k: 0 for k in STAGES + ["match_score"]}
         self.flat_bytes = 0
-        self.last = {}
+        self.rank0_only_host_s = 0.0; self.rank0_job_ms = 0.0; self.import_host_s = 0.0; self.steps_done = 0
+        self.phase_s = {k: 0.0 for k in ("step", "match_call", "inside_callback")}      # host clock per step: the whole step, the library call, the callback inside it
+        self.last = {}; self.io = None; self.ticket = None; self.k = 0
+        if self.pipeline:
+            if use_dist:
+                self.io = api.Context(device=device, max_rows=rows, max_cols=cols, max_batch=1, omega_storage=args.omega_storage)      # imports run here, next to the matches
+                self.rep = [api.Cloud(self.io, self.N) for _ in range(2)]
+                self.flat = [torch.empty(bound, dtype=torch.uint8, device=dev) for _ in range(self.RING)]
+                self.conv_cloud = api.Cloud(self.ctx, self.N) if rank == 0 else None      # what the helper converts into before it exports
+                self.side = torch.cuda.Stream(device=dev); self.imp_stream = torch.cuda.Stream(device=dev)
+                self.gstream = [torch.cuda.Stream(device=dev) for _ in range(2)]      # the all-gathers alternate between two streams: step k+1 waits for step k-1's only
+                self.ctrl_send = [torch.zeros(4, dtype=torch.float32).pin_memory() for _ in range(2)]
+                self.ctrl_host = [torch.zeros(4, dtype=torch.float32).pin_memory() for _ in range(2)]
+                self.ctrl_ev = [torch.cuda.Event() for _ in range(2)]
+                self.size = [0] * self.RING; self.bw = [None] * self.RING
+            else:
+                self.rep = [api.Cloud(self.ctx, self.N) for _ in range(3)]
+                self.flat = [None]
+                self.conv_cloud = None
+            self.prep = [self.matcher.matchHandles([c] * self.P, self.others, self.guesses) for c in self.rep]
+            self._prime()
+            self.ctx.set_enqueued_callback(self._overlap)
+        else:
+            self.current = api.Cloud(self.ctx, self.N)        # rank 0: what the converter fills; other ranks: the replica the broadcast fills
+            self.replica = api.Cloud(self.ctx, self.N) if self.roundtrip else None
+            self.flat = [torch.empty(bound, dtype=torch.uint8, device=dev)]
+            ref = self.replica if self.roundtrip else self.current
+            self.prep = [self.matcher.matchHandles([ref] * self.P, self.others, self.guesses)]
 
     def _collect(self, keys):
         for k in keys:
             ms, n = self.ctx.stage_ms(k); self.stage_ms[k] += ms; self.stage_n[k] += n
 
+    def _prime(self):
+        """fills the pipeline (untimed).  RCCL: keyframes 0-2 converted and exported, their sizes known everywhere; keyframe 0 in replica 0 on every
+        rank, keyframe 1's broadcast in flight, keyframe 3's job running.  Plain: keyframe 0 in replica 0, keyframe 1's job running."""
+        import torch
+        import torch.distributed as dist
+        cv = self.converter
+        if not self.use_dist:
+            cv.computeExportEnd(cv.computeExportBegin(self.rep[0], self.cur_dev))
+            self.ticket = cv.computeExportBegin(self.rep[1], self.cur_dev)
+            return
+        for j in (0, 1, 2):
+            n = torch.zeros(1, dtype=torch.int64, device=self.records.device)
+            if self.rank == 0:
+                w, _ = cv.computeExportEnd(cv.computeExportBegin(self.conv_cloud, self.cur_dev, flat=self.flat[j]))
+                n[0] = w
+            dist.broadcast(n, src=0)
+            self.size[j] = int(n.item())
+        dist.broadcast(self.flat[0][: self.size[0]], src=0)
+        self.io.wait_stream()
+        self.rep[0].importFlat(self.flat[0][: self.size[0]])
+        self.flat_bytes = self.size[0]
+        with torch.cuda.stream(self.side):
+            self.bw[1] = dist.broadcast(self.flat[1][: self.size[1]], src=0, async_op=True)
+        if self.rank == 0:
+            self.ticket = cv.computeExportBegin(self.conv_cloud, self.cur_dev, flat=self.flat[3])
+
+    def _overlap(self):
+        """runs inside step k's match call, after its device work is queued and before it waits"""
+        import torch
+        import torch.distributed as dist
+        from g2o_frontend_amd import shard
+        tc = time.perf_counter()
+        cv = self.converter; k = self.k; R = self.RING
+        if not self.use_dist:
+            w, ms = cv.computeExportEnd(self.ticket)                                  # keyframe k+1 sits in replica (k+1) % 3
+            self.rank0_job_ms += ms
+            self.ticket = cv.computeExportBegin(self.rep[(k + 2) % 3], self.cur_dev)      # keyframe k+2 -> the replica step k-1 matched against
+            self.rank0_only_host_s += time.perf_counter() - tc
+            self.gathered = shard.gather_records(self.records2[k % 2], self.world, self.Pmax + 1, force=False)
+            self.phase_s["inside_callback"] += time.perf_counter() - tc
+            return
+        if self.rank == 0:
+            w, ms = cv.computeExportEnd(self.ticket)                                  # keyframe k+3's flat form is in buffer (k+3) % 4
+            self.rank0_job_ms += ms
+            cs = self.ctrl_send[k % 2]; cs[0] = float(w // 256)                        # its size rides in the control row of this step's all-gather
+            self.ticket = cv.computeExportBegin(self.conv_cloud, self.cur_dev, flat=self.flat[(k + 4) % R])      # buffer k % 4: imported during step k-1
+            self.rank0_only_host_s += time.perf_counter() - tc
+        if k >= 1:                                                                   # size of keyframe k+2: control row of step k-1's all-gather
+            self.ctrl_ev[(k - 1) % 2].synchronize()
+            self.size[(k + 2) % R] = int(self.ctrl_host[(k - 1) % 2][0].item()) * 256
+        j2 = (k + 2) % R
+        with torch.cuda.stream(self.side):                                           # keyframe k+2 travels while keyframe k is matched; only the bytes written
+            self.bw[j2] = dist.broadcast(self.flat[j2][: self.size[j2]], src=0, async_op=True)
+        gs = self.gstream[k % 2]; rec = self.records2[k % 2]
+        with torch.cuda.stream(gs):
+            if self.rank == 0:
+                rec[self.Pmax, :4].copy_(self.ctrl_send[k % 2], non_blocking=True)
+            self.ctx.signal_stream(gs)                                               # the gather's stream continues after this call's records are packed
+            self.gathered = shard.gather_records(rec, self.world, self.Pmax + 1, force=True)      # the records + one control row per rank
+            self.ctrl_host[k % 2].copy_(self.gathered[self.Pmax, :4], non_blocking=True)   # rank 0's control row: the size of keyframe k+3
+            self.ctrl_ev[k % 2].record(gs)
+        ti = time.perf_counter()
+        j1 = (k + 1) % R
+        with torch.cuda.stream(self.imp_stream):
+            self.bw[j1].wait()                                                       # keyframe k+1's broadcast (queued during step k-1)
+        self.io.wait_stream(self.imp_stream)
+        self.rep[(k + 1) % 2].importFlat(self.flat[j1][: self.size[j1]])              # on the small context: waits for the broadcast and its own copies only
+        self.flat_bytes = self.size[j1]
+        self.import_host_s += time.perf_counter() - ti
+        self.phase_s["inside_callback"] += time.perf_counter() - tc
+
     def step(self, profile=False):
+        if not self.pipeline:
+            return self._step_serial(profile)
+        t0 = time.perf_counter()
+        nrep = len(self.rep)
+        rec = self.records2[self.k % 2]
+        if self.use_dist:
+            self.ctx.wait_stream(self.gstream[self.k % 2])      # this records buffer is free again: step k-2's all-gather read it on that stream
+        res = None
+        t1 = time.perf_counter()
+        res = self.matcher.matchCloudsBatchRecords(None, None, self.I, self.I, self.Km, self.rows, self.cols, rec[: self.P], pair_ids=self.ids_np,
+                                                   prepared=self.prep[self.k % nrep])
+        self.phase_s["match_call"] += time.perf_counter() - t1
+        self.ctx.take_callback_error()
+        if profile:
+            self._collect(STAGES[6:] + ["match_score"])
+        self.k += 1; self.steps_done += 1
+        self.last["gathered"] = self.gathered
+        self.last["res"] = res
+        self.phase_s["step"] += time.perf_counter() - t0
+
+    def _step_serial(self, profile=False):
         import torch.distributed as dist
         from g2o_frontend_amd import shard
         if self.rank == 0:
@@ -617,21 +758,22 @@ class PartitionWorkload:
             if profile:
                 self._collect(STAGES[:6])
             if self.use_dist:
-                self.flat_bytes = self.current.exportFlat(self.flat)                               # complete on return
+                self.flat_bytes = self.current.exportFlat(self.flat[0])                            # complete on return
         if self.use_dist:
-            dist.broadcast(self.flat, src=0)                                                      # the only data-path collective: ~17 MB per step over xGMI
+            dist.broadcast(self.flat[0], src=0)                                                   # the whole buffer (the other ranks do not know the size)
             self.ctx.wait_stream()                                                                # the import reads what the broadcast wrote; the records
             if self.rank != 0:                                                                    # buffer is free again (previous all-gather)
-                self.current.importFlat(self.flat)
+                self.current.importFlat(self.flat[0])
             elif self.roundtrip:
-                self.replica.importFlat(self.flat)
+                self.replica.importFlat(self.flat[0])
         res = None
         if self.P:
-            res = self.matcher.matchCloudsBatchRecords(None, None, self.I, self.I, self.Km, self.rows, self.cols, self.records, pair_ids=self.ids_np,
-                                                       prepared=self.prep)
+            res = self.matcher.matchCloudsBatchRecords(None, None, self.I, self.I, self.Km, self.rows, self.cols, self.records[: self.P], pair_ids=self.ids_np,
+                                                       prepared=self.prep[0])
             if profile:
                 self._collect(STAGES[6:] + ["match_score"])
-        self.last["gathered"] = shard.gather_records(self.records[: self.P] if self.P else self.records[:0], self.world, self.Pmax, force=self.use_dist)
+        self.steps_done += 1
+        self.last["gathered"] = shard.gather_records(self.records, self.world, self.Pmax + 1, force=self.use_dist)
         self.last["res"] = res
 
     barrier = BatchWorkload.barrier
@@ -646,14 +788,16 @@ class PartitionWorkload:
         if not self.use_dist:
             return out
         self.barrier(); t0 = time.perf_counter()
+        nbytes = int(self.flat_bytes) if self.pipeline else int(self.flat[0].numel())      # what a step sends: the bytes written / the buffer's bound
+        scratch = torch.empty(int(self.flat[0].numel()), dtype=torch.uint8, device=self.records.device)      # not a buffer of the pipeline
         for _ in range(n):
-            dist.broadcast(self.flat, src=0)
+            dist.broadcast(scratch[:nbytes], src=0)
         torch.cuda.synchronize(); out["broadcast_ms"] = (time.perf_counter() - t0) / n * 1e3
         self.barrier(); t0 = time.perf_counter()
         for _ in range(n):
-            shard.gather_records(self.records[: self.P], self.world, self.Pmax, force=True)
+            shard.gather_records(self.records, self.world, self.Pmax + 1, force=True)
         torch.cuda.synchronize(); out["gather_ms"] = (time.perf_counter() - t0) / n * 1e3
-        out["broadcast_bytes"] = int(self.flat.numel()); out["flat_cloud_bytes"] = int(self.flat_bytes)
+        out["broadcast_bytes"] = nbytes; out["flat_cloud_bytes"] = int(self.flat_bytes); out["flat_buffer_bound_bytes"] = int(self.flat[0].numel())
         return out
 
     def report(self, steps, dt, dt_serial, world):
@@ -665,7 +809,18 @@ class PartitionWorkload:
         pr = self.stage_n["project_ref"] / max(steps, 1) / nsub if dt_serial else float(self.n_it)
         b = align_bytes(self.N, self.n_it, r, pc, pr)
         Mcur = float(r["n_reference"][0]) if P else 0.0
-        step_bytes = float(b["align"].sum()) + (8.0 * self.N + 64.0 * Mcur) / max(world, 1)      # + this rank's share of the one conversion per step
+        step_bytes = float(b["align"].sum()) + (6.0 * self.N + 64.0 * Mcur) / max(world, 1)      # + this rank's share of the one conversion per step (u16 frame)
+        # HBM traffic of the dominant kernel from the PMC passes of THIS workload (profiles/traffic.json: "modes" -> "partition"), per pair-iteration
+        traffic = None; tsrc = None
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+            tm = tj.get("modes", {}).get("partition")
+            e = tm["kernels"]["k_corr_linearize"] if tm else None
+            if e and (self.rows, self.cols) == (480, 640):
+                traffic = e["bytes_per_launch"] / e["items_per_launch"] * (P * self.n_it * steps / launches_of(self))
+                tsrc = {"file": "profiles/traffic.json", "table": "modes.partition", "version": tm.get("version"), "pmc_summary": tm.get("source")}
+        except Exception:
+            traffic = None
         launches = max(self.stage_n["corr_linearize"], 1)
         k_ms = self.stage_ms["corr_linearize"] / launches
         k_bytes = float(b["fused"].sum()) * steps / launches
@@ -674,22 +829,58 @@ class PartitionWorkload:
         accepted = sum(1 for m in sc if acc.accept(dict(image_nonZeros=m.image_non_zeros, image_outliers=m.image_outliers, image_inliers=m.image_inliers)))
         from g2o_frontend_amd import synth
         terr = max(float(np.abs(r["T"][i].reshape(4, 4).T[:3, 3] - synth.pair_pose(PARTITION_POSE0 + k)[:3, 3]).max()) for i, k in enumerate(self.ids)) if P else 0.0
+        nst = max(self.steps_done, 1)
+        pipe = {"pipelined": bool(self.pipeline), "steps_counted": self.steps_done,
+                # host time only rank 0 spends per step: collecting the look-ahead job, the control row, starting the next job.  Pipelined: inside the
+                # match call's callback, i.e. while the device works -- not on the step's critical path
+                "rank0_only_host_ms_per_step": self.rank0_only_host_s / nst * 1e3,
+                # the look-ahead job itself (conversion of one frame + export on the helper thread's streams), beside the matches
+                "rank0_lookahead_job_ms_per_step": self.rank0_job_ms / nst,
+                # every rank: wait for the next keyframe's broadcast + import of the replica (second context), inside the callback as well
+                "import_host_ms_per_step": self.import_host_s / nst * 1e3,
+                "host_ms_per_step": {k: v / nst * 1e3 for k, v in self.phase_s.items()},
+                # what the host adds to a step outside the library call (device idle): step - match_call
+                "host_ms_per_step_outside_the_call": (self.phase_s["step"] - self.phase_s["match_call"]) / nst * 1e3}
         roofline = {"bound": "hbm", "kernel": "k_corr_linearize", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": None, "bytes_per_launch_algorithmic": k_bytes, "avg_launch_ms": k_ms, "launches": self.stage_n["corr_linearize"],
+                    "traffic": traffic, "traffic_over_algorithmic": (traffic / k_bytes) if (traffic and k_bytes) else None,
+                    "traffic_GBps": (traffic / (k_ms * 1e-3) / 1e9) if (traffic and k_ms > 0) else None, "traffic_source": tsrc,
+                    "bytes_served_by_caches": "every pair of the step gathers from the SAME `current` cloud: the algorithmic count charges its points, normals and "
+                                              "information matrices once per pair, HBM delivers them about once per launch and the L2 / Infinity Cache the rest -- "
+                                              "`achieved` and `frac` are algorithmic bytes on an HBM scale, `traffic` is what the counters saw",
+                    "bytes_per_launch_algorithmic": k_bytes, "avg_launch_ms": k_ms, "launches": self.stage_n["corr_linearize"],
                     "path_achieved_GBps": step_bytes * world * steps / dt / 1e9, "path_frac": step_bytes * world * steps / dt / 1e9 / HBM_PEAK_GBS / max(world, 1),
                     "projections_per_pair": pc + pr,
                     "algorithmic_bytes": "per pair: executed projections (16M + 4N each) + 10 x (8N + 72K_i + 28C_i) + 8N (SURVEY.md 8(d) align); per step one "
-                                         "conversion of `current` (8N + 64M); path_frac is per GPU",
+                                         "conversion of `current` (6N + 64M: a uint16 frame); path_frac is per GPU",
                     "measured_in": "serial profiled pass of the same K steps (one stream, hipEvent pair per kernel stage)"}
-        return dict(value=self.total * steps / dt, ms_per_step=dt / steps * 1e3, roofline=roofline,
+        return dict(value=self.total * steps / dt, ms_per_step=dt / steps * 1e3, roofline=roofline, pipeline=pipe,
                     stage_ms_per_step={k: self.stage_ms[k] / max(steps, 1) for k in self.stage_ms},
                     accepted_by_closer_thresholds_rank0=accepted, max_translation_error_m_rank0=terr,
                     counters_mean={"M_current_frame": Mcur, "M_others": float(r["n_current"].mean()) if P else 0.0,
                                    "K_sum": float(b["Ks"].mean()) if P else 0.0, "C_sum": float(b["Cs"].mean()) if P else 0.0})
 
     def close(self):
-        self.others = None; self.current = None; self.replica = None
+        self.ctx.set_enqueued_callback(None)
+        if getattr(self, "ticket", None) is not None:      # the look-ahead job of a step that will not come
+            try:
+                self.converter.computeExportEnd(self.ticket)
+            except Exception:
+                pass
+            self.ticket = None
+        if self.pipeline and self.use_dist:
+            import torch
+            for w_ in self.bw:                            # broadcasts of keyframes that will not be matched
+                if w_ is not None:
+                    w_.wait()
+            torch.cuda.synchronize()
+        self.others = None; self.current = None; self.replica = None; self.rep = None; self.conv_cloud = None
         self.ctx.close()
+        if self.io is not None:
+            self.io.close()
+
+
+def launches_of(w):
+    return max(w.stage_n["corr_linearize"], 1)
 
 
 def closure_guesses(seeds, t_noise=0.01, q_noise=0.004):
@@ -1393,6 +1584,30 @@ def main():
         except Exception as e:
             extra["tracker_error"] = repr(e)[:300]
 
+    if rank == 0 and rep.get("path_roofline"):
+        # the latency configurations against the same peak (BASELINE configs[1], [2]): algorithmic bytes of ONE pair / ONE tracked frame over the
+        # measured latency.  One pair is a chain of ~35 dependent launches of 150-600 workgroups each: it cannot fill the memory system, and the
+        # fraction says by how much (missing #5)
+        pr_ = rep["path_roofline"]; pair_bytes = pr_["algorithmic_bytes_per_pair"]
+        align_bytes_pair = pair_bytes - pr_["convert_bytes_per_pair"]
+        for key in ("single_pair_latency_ms", "single_pair_latency_ms_one_submission", "single_pair_latency_ms_cpp_mirror", "single_pair_latency_ms_cpp_mirror_one_submission"):
+            if isinstance(extra.get(key), (int, float)) and extra[key] > 0:
+                extra[key.replace("latency_ms", "roofline_frac")] = pair_bytes / (extra[key] * 1e-3) / 1e9 / HBM_PEAK_GBS
+        trk = extra.get("tracker_config2")
+        if isinstance(trk, dict) and trk.get("ms_per_frame"):
+            # a tracked frame: one float32 frame converted (2N more input than a u16 frame) + one alignment against the key cloud
+            frame_bytes = pr_["convert_bytes_per_pair"] / 2 + 2.0 * rows * cols + align_bytes_pair
+            trk["algorithmic_bytes_per_frame"] = frame_bytes
+            trk["roofline_frac"] = frame_bytes / (trk["ms_per_frame"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            cm = trk.get("cpp_mirror") if isinstance(trk.get("cpp_mirror"), dict) else {}
+            for q in (trk.get("look_ahead"), cm.get("plain"), cm.get("look_ahead")):
+                if isinstance(q, dict) and q.get("ms_per_frame"):
+                    q["roofline_frac"] = frame_bytes / (q["ms_per_frame"] * 1e-3) / 1e9 / HBM_PEAK_GBS
+            extra["tracker_roofline_frac"] = trk["roofline_frac"]
+            trk["roofline_note"] = ("align term: the headline batch's mean per-pair counters (identity guess, 9 of 11 projections); the tracker's guesses are not the "
+                                    "identity (11 of 11), so the fraction is a lower bound by ~2 projections' bytes (~3 %)")
+        if "single_pair_roofline_frac" in extra:
+            extra["single_pair_roofline_frac_note"] = "algorithmic bytes of one pair (path_roofline.algorithmic_bytes_per_pair) / single_pair_latency_ms / 8 TB/s"
     if rank == 0:
         rep["roofline"]["measured_hbm_read_GBps"] = hbm_read; rep["roofline"]["measured_hbm_copy_GBps"] = hbm_copy
         if "chi2_match" in extra:      # the parity gate travels with the number (flat, so that summaries of the line keep it)
@@ -1429,8 +1644,11 @@ def main():
         if partition:
             out["partition"] = {"accepted_by_closer_thresholds_rank0": rep["accepted_by_closer_thresholds_rank0"], "keyframes_rank0": P,
                                 "max_translation_error_m_rank0": rep["max_translation_error_m_rank0"],
-                                "flat_cloud_bytes": int(w.flat_bytes) if use_dist else None, "broadcast_buffer_bytes": int(w.flat.numel()),
-                                "replica_roundtrip_on_rank0": bool(w.roundtrip)}
+                                "flat_cloud_bytes": int(w.flat_bytes) if use_dist else None,
+                                "broadcast_bytes_per_step": (int(w.flat_bytes) if w.pipeline else int(w.flat[0].numel())) if use_dist else None,
+                                "flat_buffer_bound_bytes": int(w.flat[0].numel()) if w.flat[0] is not None else None,
+                                "replica_roundtrip_on_rank0": bool(w.roundtrip), "pipelined": bool(w.pipeline),
+                                "pipeline": rep.get("pipeline")}
         out.update(extra)
         print(json.dumps(out))
     if use_dist:

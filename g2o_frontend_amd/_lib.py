@@ -71,6 +71,8 @@ PROTOTYPES = {
     "pwn_hip_ctx_set_stream": (_I, [_VP, _VP]),
     "pwn_hip_ctx_synchronize": (_I, [_VP]),
     "pwn_hip_ctx_wait_stream": (_I, [_VP, _VP]),
+    "pwn_hip_ctx_signal_stream": (_I, [_VP, _VP]),
+    "pwn_hip_ctx_set_enqueued_callback": (_I, [_VP, _VP, _VP]),
     "pwn_hip_ctx_set_subbatch": (_I, [_VP, _I, _I]),
     "pwn_hip_ctx_set_concurrency": (_I, [_VP, _I]),
     "pwn_hip_ctx_set_omega_storage": (_I, [_VP, _I]),
@@ -105,6 +107,8 @@ PROTOTYPES = {
     "pwn_hip_convert_scaled": (_I, [_VP, _VP, _VP, _I, _I, _I, _F, _VP]),
     "pwn_hip_convert_scaled_begin": (_I, [_VP, _VP, _VP, _I, _I, _I, _F, _VP]),
     "pwn_hip_convert_end": (_I, [_VP, _VP]),
+    "pwn_hip_convert_export_begin": (_I, [_VP, _VP, _VP, _F, _I, _I, _VP, _VP, C.c_size_t]),
+    "pwn_hip_convert_export_end": (_I, [_VP, _VP, C.POINTER(C.c_size_t), C.POINTER(_F)]),
     "pwn_hip_convert_batch": (_I, [_VP, _VP, _VP, _I, _I, _I, _VP]),
     "pwn_hip_convert_batch_u16": (_I, [_VP, _VP, _VP, _F, _I, _I, _I, _VP]),
     "pwn_hip_project": (_I, [_VP, _VP, _VP, _F, _F, _I, _I, _VP, _VP, _VP]),
@@ -144,6 +148,8 @@ PROTOTYPES = {
     "pwn_hip_debug_withhold_carry": (_I, [_VP, _I, _I, _I, _I, _I]),
     "pwn_hip_debug_set_index_shortcut": (_I, [_VP, _I]),
     "pwn_hip_debug_convert_retries": (_I, [_VP, C.POINTER(_I)]),
+    "pwn_hip_debug_set_settle_guard": (_I, [_VP, _I]),
+    "pwn_hip_debug_projection_fallbacks": (_I, [_VP, C.POINTER(_I)]),
     "pwn_hip_measure_hbm": (_I, [_VP, C.c_size_t, _VP, _VP]),
 }
 

@@ -150,6 +150,26 @@ def _check_records(records, n, floats, ctx=None):
         raise TypeError(type(records))
 
 
+def _check_flat(buffer, ctx, writable: bool):
+    """A flat-cloud byte buffer handed to pwn_hip_cloud_export / _import (whose section copies are kernels on the context's device): a strided
+    view, another element type, a read-only array as destination or a tensor on another GPU would be read or written out of bounds."""
+    if isinstance(buffer, DeviceBuffer):
+        return
+    if hasattr(buffer, "data_ptr"):
+        import torch
+        if buffer.dtype != torch.uint8 or not buffer.is_contiguous():
+            raise ValueError("a flat cloud buffer must be a contiguous uint8 tensor")
+        if buffer.is_cuda and buffer.device.index not in (None, ctx.device):
+            raise ValueError(f"the flat cloud buffer lives on cuda:{buffer.device.index}, the context on device {ctx.device}")
+    elif isinstance(buffer, np.ndarray):
+        if buffer.dtype != np.uint8 or not buffer.flags["C_CONTIGUOUS"]:
+            raise ValueError("a flat cloud buffer must be a C-contiguous uint8 array")
+        if writable and not buffer.flags["WRITEABLE"]:
+            raise ValueError("export needs a writable buffer")
+    else:
+        raise TypeError(type(buffer))
+
+
 def _colmajor(M, n):
     return np.ascontiguousarray(np.asarray(M, dtype=np.float32).reshape(n, n).T.reshape(-1))
 
@@ -232,6 +252,44 @@ class Context:
     def upload(self, array):
         """DeviceBuffer holding a copy of a host array (pwn_hip_device_alloc + pwn_hip_copy): a frame resident in HBM without torch"""
         return DeviceBuffer(self, array)
+
+    @staticmethod
+    def _stream_ptr(stream):
+        if stream is None:
+            try:
+                import torch
+                stream = torch.cuda.current_stream().cuda_stream
+            except Exception:
+                stream = 0
+        return int(getattr(stream, "cuda_stream", stream))
+
+    def signal_stream(self, stream=None):
+        """pwn_hip_ctx_signal_stream: what the caller queues on `stream` (default: torch's current stream) from now on runs after everything
+        the context has queued so far."""
+        sp = self._stream_ptr(stream)
+        self.check(self._L.pwn_hip_ctx_signal_stream(self.h, C.c_void_p(sp) if sp else None))
+
+    def set_enqueued_callback(self, fn):
+        """pwn_hip_ctx_set_enqueued_callback: fn() runs inside every alignment batch call after its device work is queued and before the call
+        waits for it (None switches it off).  An exception raised by fn is kept and re-raised by take_callback_error()."""
+        self._cb_error = None
+        if fn is None:
+            self._cb = None
+            self.check(self._L.pwn_hip_ctx_set_enqueued_callback(self.h, None, None))
+            return
+
+        def trampoline(_user):
+            try:
+                fn()
+            except BaseException as e:      # must not propagate through the C frames
+                self._cb_error = e
+        self._cb = C.CFUNCTYPE(None, C.c_void_p)(trampoline)      # kept alive as long as it is installed
+        self.check(self._L.pwn_hip_ctx_set_enqueued_callback(self.h, C.cast(self._cb, C.c_void_p), None))
+
+    def take_callback_error(self):
+        e, self._cb_error = getattr(self, "_cb_error", None), None
+        if e is not None:
+            raise e
 
     def wait_stream(self, stream=None):
         """pwn_hip_ctx_wait_stream: what the context queues from now on runs after the work the caller's stream holds now.  stream: a raw
@@ -350,12 +408,14 @@ class Cloud:
 
     def exportFlat(self, buffer) -> int:
         """pwn_hip_cloud_export into `buffer` (uint8 numpy array or CUDA tensor, >= flatSize() bytes); returns the bytes used"""
+        _check_flat(buffer, self.ctx, writable=True)
         w = C.c_size_t(0)
         self.ctx.check(self.ctx._L.pwn_hip_cloud_export(self.ctx.h, self.h, _ptr(buffer), _nbytes(buffer), C.byref(w)))
         return int(w.value)
 
     def importFlat(self, buffer):
         """pwn_hip_cloud_import: this cloud becomes the cloud `buffer` was exported from (same omega storage, capacity >= its points)"""
+        _check_flat(buffer, self.ctx, writable=False)
         self.ctx.check(self.ctx._L.pwn_hip_cloud_import(self.ctx.h, self.h, _ptr(buffer), _nbytes(buffer)))
 
     # the reference's per-field accessors (cloud.h:33-131) as host copies: each is one download of that field
@@ -607,6 +667,26 @@ class DepthImageConverterIntegralImage:
         self._indexImage, self._intervalImage = idx, itv
         if gaussians:      # the Gaussian half of unProject (pinholepointprojector.cpp:104-123); the reference always computes it
             ctx.check(ctx._L.pwn_hip_cloud_gaussians(ctx.h, C.byref(p), _ptr(depth), rows, cols, cloud.h, self._projector._baseline, self._projector._alpha))
+
+    def computeExportBegin(self, cloud: Cloud, rawFrame, raw_scale=0.001, flat=None, sensorOffset=None):
+        """The look-ahead of a sharded PwnCloser::processPartition (pwn_hip_convert_export_begin): returns at once; the library's helper thread
+        converts the uint16 frame into `cloud` and then writes the cloud's flat form into `flat` (uint8 CUDA tensor / numpy array, or None)
+        while the caller goes on using the context.  computeExportEnd(ticket) -> (bytes written, job milliseconds)."""
+        ctx = cloud.ctx
+        rows, cols = rawFrame.shape
+        p = self.params(sensorOffset)
+        if flat is not None:
+            _check_flat(flat, ctx, writable=True)
+        ctx.check(ctx._L.pwn_hip_convert_export_begin(ctx.h, C.byref(p), _ptr(rawFrame), raw_scale, rows, cols, cloud.h, _ptr(flat), _nbytes(flat) if flat is not None else 0))
+        return dict(ctx=ctx, cloud=cloud, frame=rawFrame, flat=flat)
+
+    @staticmethod
+    def computeExportEnd(ticket):
+        ctx, cloud = ticket["ctx"], ticket["cloud"]
+        w, ms = C.c_size_t(0), C.c_float(0)
+        ctx.check(ctx._L.pwn_hip_convert_export_end(ctx.h, cloud.h, C.byref(w), C.byref(ms)))
+        ticket["frame"] = None
+        return int(w.value), float(ms.value)
 
     @staticmethod
     def batchHandles(clouds, depthImages):

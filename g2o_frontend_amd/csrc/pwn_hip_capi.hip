@@ -14,8 +14,10 @@
 #include "pwn_stats.h"
 
 #include <algorithm>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <cstddef>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -44,6 +46,9 @@ struct AsyncConvert {
   bool has_job = false, done = true, quit = false;
   pwn_hip_converter_params p;
   const float* depth = nullptr; int rows = 0, cols = 0, step = 1; float max_depth_cov = 0.f;
+  const uint16_t* raw = nullptr; float raw_scale = 0.f;      // pwn_hip_convert_export_begin: a raw uint16 frame instead of `depth`
+  void* flat_dst = nullptr; size_t flat_bytes = 0, flat_written = 0;      // ... and the cloud's flat form written behind the conversion
+  float job_ms = 0.f;                                        // wall time of the job on the helper thread (conversion + export, waits included)
   pwn_hip_cloud* cloud = nullptr;
   int rc = 0; std::string err;
 };
@@ -136,8 +141,17 @@ struct pwn_hip_ctx {
   // conversion of a frame.  Bounded by kCloudPoolBytes.
   std::vector<pwn_hip_cloud*> cloud_pool; size_t cloud_pool_bytes = 0;
   AsyncConvert* async = nullptr;           // pwn_hip_convert_scaled_begin: created on first use
+  void* flat_hdr_host = nullptr;           // page-locked staging of a flat cloud's 256-byte header (pwn_hip_cloud_export / _import)
   float* records_ws = nullptr; int records_cap = 0;      // result records of a batch on their way to host memory (k_pack_records)
   int* ids_dev = nullptr; int ids_cap = 0;               // the caller's pair ids of those records
+  // Projection fault path (z32_settle): a page-locked word the projection kernels raise when a pixel's settle loop gave up; the call is then
+  // repeated with the two-pass projection (k_project_robust) and its depth images (allocated on first use)
+  void (*enqueued_cb)(void*) = nullptr; void* enqueued_user = nullptr;      // pwn_hip_ctx_set_enqueued_callback
+  int* align_fault_host = nullptr;
+  unsigned* zdepth_ws = nullptr;
+  int settle_guard = kSettleGuard;                       // pwn_hip_debug_set_settle_guard (test hook)
+  int last_align_fault = 0;                              // the last alignment call ended with the fault word raised
+  int projection_fallbacks = 0;                          // calls repeated with the two-pass projection so far (pwn_hip_debug_projection_fallbacks)
 };
 
 namespace {
@@ -167,13 +181,6 @@ void launch_corr_linearize(const pwn_hip_ctx* ctx, int sym, int nb, int m, hipSt
   else launch_corr_linearize_s<SAME_T, FULL_H, false>(ctx, nb, m, st, pr, ap, tag, usePrevTc, ownRef);
 }
 
-// projection of one cloud of each of the m pairs (which: 0 = reference, 1 = current): four points per thread when the launch is large
-constexpr int kProjectPPT = 4;
-void launch_project(int capacity, int m, hipStream_t st, const PairDesc* pr, const AlignParams& ap, int which, unsigned tag) {
-  if (m >= 8) hipLaunchKernelGGL((k_project<kProjectPPT>), dim3((capacity + 256 * kProjectPPT - 1) / (256 * kProjectPPT), m), dim3(256), 0, st, pr, ap, which, tag);
-  else hipLaunchKernelGGL((k_project<1>), dim3((capacity + 255) / 256, m), dim3(256), 0, st, pr, ap, which, tag);
-}
-
 int fail(pwn_hip_ctx* ctx, int code, const std::string& msg) {
   if (ctx) ctx->err = msg;
   g_err = msg;
@@ -190,6 +197,21 @@ void cloud_changes(pwn_hip_ctx* ctx, const pwn_hip_cloud* c) {
     if (e_ != hipSuccess) return fail(ctx, code, std::string(#call) + ": " + hipGetErrorString(e_));           \
   } while (0)
 
+// projection of one cloud of each of the m pairs (which: 0 = reference, 1 = current): four points per thread when the launch is large
+constexpr int kProjectPPT = 4;
+// zd: the depth images of the m pairs' workspace slots (contiguous, ctx->N words each) when the call runs the two-pass projection, else nullptr
+int launch_project(pwn_hip_ctx* ctx, int capacity, int m, hipStream_t st, const PairDesc* pr, const AlignParams& ap, int which, unsigned tag, unsigned* zd = nullptr) {
+  if (zd) {
+    HIPCHK(ctx, hipMemsetAsync(zd, 0xFF, (size_t)m * ctx->N * sizeof(unsigned), st), PWN_HIP_ERR_COPY);
+    for (int pass = 0; pass < 2; ++pass)
+      hipLaunchKernelGGL(k_project_robust, dim3((capacity + 255) / 256, m), dim3(256), 0, st, pr, ap, which, tag, pass);
+    return PWN_HIP_OK;
+  }
+  if (m >= 8) hipLaunchKernelGGL((k_project<kProjectPPT>), dim3((capacity + 256 * kProjectPPT - 1) / (256 * kProjectPPT), m), dim3(256), 0, st, pr, ap, which, tag);
+  else hipLaunchKernelGGL((k_project<1>), dim3((capacity + 255) / 256, m), dim3(256), 0, st, pr, ap, which, tag);
+  return PWN_HIP_OK;
+}
+
 bool is_device_ptr(const void* p) {
   if (!p) return false;
   hipPointerAttribute_t attr;
@@ -202,20 +224,31 @@ hipError_t copy_any(void* dst, const void* src, size_t bytes, hipStream_t s) {
   return hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, s);
 }
 
-// device-to-device section copies of the flat cloud: a kernel (hipMemcpyAsync between device buffers goes through the DMA engines at a fraction
-// of the HBM rate: 0.3 ms per 17 MB cloud measured, against ~10 us); sizes and offsets are multiples of 4 bytes
+// device-to-device section copies of the flat cloud: a kernel (hipMemcpyAsync between device buffers is a blit kernel of the runtime's with a
+// launch of its own per call: 0.3 ms per 17 MB cloud measured, against ~10 us); sizes and offsets are multiples of 4 bytes.
+// The grid is SMALL on purpose (at most kCopyBlocks workgroups, four independent 16-byte accesses in flight per thread: ~2 TB/s alone, a 5 MB
+// section in a few microseconds): these copies run beside a batch alignment (export in the look-ahead job, import on a second context), where a
+// grid that fills the device (2048 workgroups until round 6) displaced the batch's own workgroups for ~80 us per section -- measured as +2.5 % on the
+// sum of the batch's kernel times for 0.25 % more bytes.
+constexpr unsigned kCopyBlocks = 96;
 template <typename V> __global__ void __launch_bounds__(256) k_copy_words(const V* __restrict__ src, V* __restrict__ dst, size_t n) {
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+  const size_t stride = (size_t)gridDim.x * 256;
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n; i += 4 * stride) {
+    const V a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+  }
+  for (; i < n; i += stride) dst[i] = src[i];
 }
 hipError_t copy_section(void* dst, const void* src, size_t bytes, hipStream_t st) {
   if (bytes == 0) return hipSuccess;
   if (!is_device_ptr(dst) || !is_device_ptr(src) || (bytes & 3) || (((uintptr_t)dst | (uintptr_t)src) & 3)) return copy_any(dst, src, bytes, st);
   if (((((uintptr_t)dst | (uintptr_t)src) | bytes) & 15) == 0) {
     const size_t n = bytes / 16;
-    hipLaunchKernelGGL(k_copy_words<uint4>, dim3((unsigned)std::min<size_t>((n + 255) / 256, 2048)), dim3(256), 0, st, (const uint4*)src, (uint4*)dst, n);
+    hipLaunchKernelGGL(k_copy_words<uint4>, dim3((unsigned)std::min<size_t>((n + 1023) / 1024, kCopyBlocks)), dim3(256), 0, st, (const uint4*)src, (uint4*)dst, n);
   } else {
     const size_t n = bytes / 4;
-    hipLaunchKernelGGL(k_copy_words<unsigned>, dim3((unsigned)std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, (const unsigned*)src, (unsigned*)dst, n);
+    hipLaunchKernelGGL(k_copy_words<unsigned>, dim3((unsigned)std::min<size_t>((n + 1023) / 1024, 2 * kCopyBlocks)), dim3(256), 0, st, (const unsigned*)src, (unsigned*)dst, n);
   }
   return hipGetLastError();
 }
@@ -366,8 +399,9 @@ int cloud_store_records(pwn_hip_ctx* ctx, const CloudDev& d, int n, const std::v
   HIPCHK(ctx, hipMemcpy(d.Nc, nc.data(), nc.size() * 4, hipMemcpyHostToDevice), PWN_HIP_ERR_COPY);
   return PWN_HIP_OK;
 }
-AlignParams make_align_params(const pwn_hip_aligner_params* p) {
+AlignParams make_align_params(const pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p) {
   AlignParams ap;
+  ap.settleGuard = ctx ? ctx->settle_guard : kSettleGuard;
   ap.rows = p->rows; ap.cols = p->cols;
   ap.K = mat3_from(p->K);
   ap.refOffset = mat4_from(p->reference_sensor_offset);
@@ -414,6 +448,19 @@ int take_tags32(pwn_hip_ctx* ctx, unsigned need, unsigned* first) {
   ctx->z32tag_next -= need;
   return PWN_HIP_OK;
 }
+// the two-pass projection's depth images: one per workspace slot, allocated when a call first needs them
+int ensure_zdepth(pwn_hip_ctx* ctx) {
+  if (!ctx->zdepth_ws) HIPCHK(ctx, hipMalloc((void**)&ctx->zdepth_ws, (size_t)ctx->max_batch * ctx->N * sizeof(unsigned)), PWN_HIP_ERR_ALLOCATION);
+  return PWN_HIP_OK;
+}
+// after the wait that ends an alignment call: did a projection of it give up on a pixel?  (the word is host memory the kernels store to)
+bool take_align_fault(pwn_hip_ctx* ctx) {
+  const bool f = ctx->align_fault_host && *(volatile int*)ctx->align_fault_host != 0;
+  if (f) *(volatile int*)ctx->align_fault_host = 0;
+  ctx->last_align_fault = f ? 1 : 0;
+  return f;
+}
+const char* const kSettleMessage = "projection: a pixel's z-buffer settle loop gave up (too many points of one cloud in one pixel)";
 int align_nblocks(int N) { return (N + kAlignBlock * kPixPerThread - 1) / (kAlignBlock * kPixPerThread); }
 
 // descriptor / state arrays for a batch of n items
@@ -787,7 +834,20 @@ void pwn_hip_default_aligner_params(pwn_hip_aligner_params* p) {
   std::memcpy(p->initial_guess, I.m, sizeof(I.m));
 }
 
-int pwn_hip_ctx_create(pwn_hip_ctx** out, int device, int max_rows, int max_cols, int max_batch) {
+// high_priority: the streams of a look-ahead helper context (AsyncConvert).  Its one-frame jobs run beside a batch whose streams hold hundreds of
+// queued launches; on the default priority a stream of the helper can share a hardware queue with one of those and is then served when that
+// queue has drained -- at the end of the batch instead of beside it.
+static int ctx_create(pwn_hip_ctx** out, int device, int max_rows, int max_cols, int max_batch, bool high_priority);
+int pwn_hip_ctx_create(pwn_hip_ctx** out, int device, int max_rows, int max_cols, int max_batch) { return ctx_create(out, device, max_rows, max_cols, max_batch, false); }
+static hipError_t make_stream(hipStream_t* s, bool high_priority) {
+  if (high_priority) {
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && greatest != least && hipStreamCreateWithPriority(s, hipStreamNonBlocking, greatest) == hipSuccess) return hipSuccess;
+    (void)hipGetLastError();
+  }
+  return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+}
+static int ctx_create(pwn_hip_ctx** out, int device, int max_rows, int max_cols, int max_batch, bool high_priority) {
   if (!out || max_rows <= 0 || max_cols <= 0 || max_batch <= 0) return fail(nullptr, PWN_HIP_ERR_INVALID_ARGUMENT, "bad ctx_create argument");
   *out = nullptr;
   int ndev = 0;
@@ -802,10 +862,10 @@ int pwn_hip_ctx_create(pwn_hip_ctx** out, int device, int max_rows, int max_cols
   ctx->nblocks_max = align_nblocks((int)N);
 #define ALLOC(ptr, bytes) do { hipError_t e_ = hipMalloc((void**)&(ptr), (bytes)); if (e_ != hipSuccess) { std::string m = std::string("hipMalloc ") + #ptr + ": " + hipGetErrorString(e_); pwn_hip_ctx_destroy(ctx); return fail(nullptr, PWN_HIP_ERR_ALLOCATION, m); } } while (0)
 #define HALLOC(ptr, bytes) do { hipError_t e_ = hipHostMalloc((void**)&(ptr), (bytes)); if (e_ != hipSuccess) { std::string m = std::string("hipHostMalloc ") + #ptr + ": " + hipGetErrorString(e_); pwn_hip_ctx_destroy(ctx); return fail(nullptr, PWN_HIP_ERR_ALLOCATION, m); } } while (0)
-  if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return fail(nullptr, PWN_HIP_ERR_ALLOCATION, "hipStreamCreate failed"); }
+  if (make_stream(&ctx->own_stream, high_priority) != hipSuccess) { delete ctx; return fail(nullptr, PWN_HIP_ERR_ALLOCATION, "hipStreamCreate failed"); }
   ctx->stream = ctx->own_stream;
-  (void)hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
-  for (int k = 0; k < 2; ++k) { (void)hipStreamCreateWithFlags(&ctx->extra[k], hipStreamNonBlocking); (void)hipEventCreateWithFlags(&ctx->join_extra[k], hipEventDisableTiming); }
+  (void)make_stream(&ctx->stream2, high_priority);
+  for (int k = 0; k < 2; ++k) { (void)make_stream(&ctx->extra[k], high_priority); (void)hipEventCreateWithFlags(&ctx->join_extra[k], hipEventDisableTiming); }
   (void)hipEventCreateWithFlags(&ctx->fork_ev, hipEventDisableTiming); (void)hipEventCreateWithFlags(&ctx->join_ev, hipEventDisableTiming);
   (void)hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking);
   (void)hipEventCreateWithFlags(&ctx->copy_ev, hipEventDisableTiming);
@@ -823,6 +883,9 @@ int pwn_hip_ctx_create(pwn_hip_ctx** out, int device, int max_rows, int max_cols
   ALLOC(ctx->rowoff_ws, B * ctx->rowoff_slot * sizeof(int));
   ALLOC(ctx->carry_ws, B * ctx->carry_slot * sizeof(unsigned long long));
   ALLOC(ctx->fault_dev, sizeof(int));
+  HALLOC(ctx->align_fault_host, sizeof(int));
+  HALLOC(ctx->flat_hdr_host, 256);
+  *ctx->align_fault_host = 0;
   if (hipMemset(ctx->carry_ws, 0, B * ctx->carry_slot * sizeof(unsigned long long)) != hipSuccess || hipMemset(ctx->fault_dev, 0, sizeof(int)) != hipSuccess) {
     pwn_hip_ctx_destroy(ctx); return fail(nullptr, PWN_HIP_ERR_ALLOCATION, "hipMemset of the hand-over workspace failed"); }
   ALLOC(ctx->zref_ws, N * sizeof(unsigned long long));
@@ -874,6 +937,9 @@ int pwn_hip_ctx_destroy(pwn_hip_ctx* ctx) {
   if (ctx->scene_total) (void)hipFree(ctx->scene_total);
   if (ctx->records_ws) (void)hipFree(ctx->records_ws);
   if (ctx->ids_dev) (void)hipFree(ctx->ids_dev);
+  if (ctx->zdepth_ws) (void)hipFree(ctx->zdepth_ws);
+  if (ctx->align_fault_host) (void)hipHostFree(ctx->align_fault_host);
+  if (ctx->flat_hdr_host) (void)hipHostFree(ctx->flat_hdr_host);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
   if (ctx->stream2) (void)hipStreamDestroy(ctx->stream2);
   for (int k = 0; k < 2; ++k) { if (ctx->extra[k]) (void)hipStreamDestroy(ctx->extra[k]); if (ctx->join_extra[k]) (void)hipEventDestroy(ctx->join_extra[k]); }
@@ -900,6 +966,21 @@ int pwn_hip_ctx_wait_stream(pwn_hip_ctx* ctx, void* hip_stream) {
   // everything the context queues from now on (its other streams fork from ctx->stream) runs after what the caller's stream holds now
   HIPCHK(ctx, hipEventRecord(ctx->foreign_ev, (hipStream_t)hip_stream), PWN_HIP_ERR_LAUNCH);
   HIPCHK(ctx, hipStreamWaitEvent(ctx->stream, ctx->foreign_ev, 0), PWN_HIP_ERR_LAUNCH);
+  return PWN_HIP_OK;
+}
+int pwn_hip_ctx_signal_stream(pwn_hip_ctx* ctx, void* hip_stream) {
+  if (!ctx) return fail(nullptr, PWN_HIP_ERR_INVALID_ARGUMENT, "null ctx");
+  if (!ctx->foreign_ev) return fail(ctx, PWN_HIP_ERR_ALLOCATION, "no event");
+  HIPCHK(ctx, hipSetDevice(ctx->device), PWN_HIP_ERR_NO_DEVICE);
+  // the mirror image of pwn_hip_ctx_wait_stream: what the caller queues on its stream from now on runs after everything the context has queued
+  // so far (every batch call joins its streams back into ctx->stream before it packs its records)
+  HIPCHK(ctx, hipEventRecord(ctx->foreign_ev, ctx->stream), PWN_HIP_ERR_LAUNCH);
+  HIPCHK(ctx, hipStreamWaitEvent((hipStream_t)hip_stream, ctx->foreign_ev, 0), PWN_HIP_ERR_LAUNCH);
+  return PWN_HIP_OK;
+}
+int pwn_hip_ctx_set_enqueued_callback(pwn_hip_ctx* ctx, void (*fn)(void*), void* user) {
+  if (!ctx) return fail(nullptr, PWN_HIP_ERR_INVALID_ARGUMENT, "null ctx");
+  ctx->enqueued_cb = fn; ctx->enqueued_user = fn ? user : nullptr;
   return PWN_HIP_OK;
 }
 int pwn_hip_ctx_synchronize(pwn_hip_ctx* ctx) {
@@ -951,6 +1032,18 @@ int pwn_hip_debug_convert_retries(pwn_hip_ctx* ctx, int* retries) {
 int pwn_hip_debug_set_index_shortcut(pwn_hip_ctx* ctx, int enabled) {
   if (!ctx) return fail(nullptr, PWN_HIP_ERR_INVALID_ARGUMENT, "null ctx");
   ctx->index_shortcut = enabled ? 1 : 0;
+  return PWN_HIP_OK;
+}
+// Test hooks of the projection's fault path: the rounds a thread of k_project spends on a contended pixel before it gives up (0 = every
+// collision gives up at once; < 0 = the default), and how many alignment calls were repeated with the two-pass projection so far.
+int pwn_hip_debug_set_settle_guard(pwn_hip_ctx* ctx, int rounds) {
+  if (!ctx) return fail(nullptr, PWN_HIP_ERR_INVALID_ARGUMENT, "null ctx");
+  ctx->settle_guard = rounds < 0 ? kSettleGuard : rounds;
+  return PWN_HIP_OK;
+}
+int pwn_hip_debug_projection_fallbacks(pwn_hip_ctx* ctx, int* calls) {
+  if (!ctx || !calls) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
+  *calls = ctx->projection_fallbacks;
   return PWN_HIP_OK;
 }
 int pwn_hip_set_profiling(pwn_hip_ctx* ctx, int enabled) {
@@ -1229,7 +1322,9 @@ int pwn_hip_cloud_export(pwn_hip_ctx* ctx, const pwn_hip_cloud* c, void* dst, si
   if (!ctx || !c || (!dst && !written)) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   HIPCHK(ctx, hipSetDevice(ctx->device), PWN_HIP_ERR_NO_DEVICE);
   const size_t n = (size_t)std::min(c->n_host, c->d.capacity), cap = (size_t)c->d.capacity;
-  CloudFlatHeader h; std::memset(&h, 0, sizeof(h));
+  // the header is staged in page-locked memory of the context: the copy below is asynchronous, and an error return further down must not
+  // leave it reading a dead stack frame
+  CloudFlatHeader& h = *(CloudFlatHeader*)ctx->flat_hdr_host; std::memset(&h, 0, sizeof(h));
   h.magic = kFlatMagic; h.version = 1; h.n = (int32_t)n; h.omSym = c->d.omSym; h.hasOmN = c->d.OmN ? 1 : 0;
   h.clsThr = c->d.clsThr; std::memcpy(h.omN, c->d.omN, sizeof(h.omN));
   const bool idx = c->idx_valid && c->idximg && (size_t)c->idx_rows * c->idx_cols <= c->idx_cap;
@@ -1251,7 +1346,7 @@ int pwn_hip_cloud_export(pwn_hip_ctx* ctx, const pwn_hip_cloud* c, void* dst, si
       HIPCHK(ctx, copy_section(out + h.offOmN + (size_t)r * up256(n * 12), c->d.OmN + (size_t)r * cap * 3, n * 12, st), PWN_HIP_ERR_COPY);
   }
   if (npx > 0) HIPCHK(ctx, copy_section(out + h.offIdx, c->idximg, npx * 4, st), PWN_HIP_ERR_COPY);
-  HIPCHK(ctx, hipStreamSynchronize(st), PWN_HIP_ERR_COPY);      // the header is a stack object; the buffer is complete on return
+  HIPCHK(ctx, hipStreamSynchronize(st), PWN_HIP_ERR_COPY);      // the buffer is complete on return
   return PWN_HIP_OK;
 }
 int pwn_hip_cloud_import(pwn_hip_ctx* ctx, pwn_hip_cloud* c, const void* src, size_t src_bytes) {
@@ -1275,6 +1370,11 @@ int pwn_hip_cloud_import(pwn_hip_ctx* ctx, pwn_hip_cloud* c, const void* src, si
   if ((h.omSym ? 1 : 0) != c->d.omSym) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "flat cloud and destination cloud differ in omega storage (exact9 / sym6)");
   cloud_changes(ctx, c);
   c->has_stats = false; c->n_gauss = 0; c->idx_valid = false;
+  // from here on the destination's previous content is being overwritten: it reads as EMPTY (host size and device count) until every section
+  // has arrived, so that a copy that fails half way leaves an empty cloud behind, not a mixture with the old sizes
+  c->n_host = 0;
+  HIPCHK(ctx, hipMemsetAsync(c->d.count, 0, sizeof(int), st), PWN_HIP_ERR_COPY);
+  CloudFlatHeader& hp = *(CloudFlatHeader*)ctx->flat_hdr_host; hp = h;      // page-locked copy: source of the asynchronous count copy below
   if (h.hasOmN && !c->d.OmN) HIPCHK(ctx, hipMalloc((void**)&c->d.OmN, cap * 9 * sizeof(float)), PWN_HIP_ERR_ALLOCATION);
   if (!h.hasOmN && c->d.OmN) { (void)hipFree(c->d.OmN); c->d.OmN = nullptr; }      // the stream is idle (synchronised above)
   if (idx && c->idx_cap < npx) {
@@ -1293,7 +1393,7 @@ int pwn_hip_cloud_import(pwn_hip_ctx* ctx, pwn_hip_cloud* c, const void* src, si
       HIPCHK(ctx, copy_section(c->d.OmN + (size_t)r * cap * 3, in + h.offOmN + (size_t)r * up256(n * 12), n * 12, st), PWN_HIP_ERR_COPY);
   }
   if (idx) HIPCHK(ctx, copy_section(c->idximg, in + h.offIdx, npx * 4, st), PWN_HIP_ERR_COPY);
-  HIPCHK(ctx, copy_any(c->d.count, &h.n, sizeof(int), st), PWN_HIP_ERR_COPY);
+  HIPCHK(ctx, copy_any(c->d.count, &hp.n, sizeof(int), st), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipStreamSynchronize(st), PWN_HIP_ERR_COPY);
   c->d.clsThr = h.clsThr; std::memcpy(c->d.omN, h.omN, sizeof(h.omN));
   c->n_host = h.n;
@@ -1446,22 +1546,58 @@ static void async_convert_loop(AsyncConvert* a, int device) {
     a->cv.wait(lk, [a] { return a->has_job || a->quit; });
     if (!a->has_job) return;                                    // quit, nothing pending
     lk.unlock();
-    const int rc = pwn_hip_convert_scaled(a->helper, &a->p, a->depth, a->rows, a->cols, a->step, a->max_depth_cov, a->cloud);
+    const auto t_begin = std::chrono::steady_clock::now();
+    int rc;
+    if (a->raw) {
+      const uint16_t* frames[1] = { a->raw }; pwn_hip_cloud* clouds[1] = { a->cloud };
+      rc = convert_batch_impl<uint16_t>(a->helper, &a->p, frames, a->raw_scale, 1, a->rows, a->cols, clouds, 0);
+    } else {
+      rc = pwn_hip_convert_scaled(a->helper, &a->p, a->depth, a->rows, a->cols, a->step, a->max_depth_cov, a->cloud);
+    }
+    size_t written = 0;
+    if (rc == PWN_HIP_OK && a->flat_dst) rc = pwn_hip_cloud_export(a->helper, a->cloud, a->flat_dst, a->flat_bytes, &written);
+    const float job_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     lk.lock();
+    a->flat_written = written; a->job_ms = job_ms;
     a->rc = rc; a->err = rc == PWN_HIP_OK ? std::string() : a->helper->err;
     a->has_job = false; a->done = true;
     lk.unlock();
     a->cv.notify_all();
   }
 }
+// one job for the helper thread: a float frame through DepthImage_scale + the converter, or a raw uint16 frame through the converter; then
+// (flat_dst != nullptr) the cloud's flat form
+static int async_convert_begin(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float* depth, const uint16_t* raw, float raw_scale, int rows, int cols,
+                               int step, float max_depth_cov, pwn_hip_cloud* cloud, void* flat_dst, size_t flat_bytes);
 int pwn_hip_convert_scaled_begin(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float* depth, int rows, int cols, int step, float max_depth_cov,
                                  pwn_hip_cloud* cloud) {
   if (!ctx || !p || !depth || !cloud || step <= 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "bad argument");
+  return async_convert_begin(ctx, p, depth, nullptr, 0.f, rows, cols, step, max_depth_cov, cloud, nullptr, 0);
+}
+int pwn_hip_convert_export_begin(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const uint16_t* raw_frame, float depth_scale, int rows, int cols,
+                                 pwn_hip_cloud* cloud, void* flat_dst, size_t flat_bytes) {
+  if (!ctx || !p || !raw_frame || !cloud) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "bad argument");
+  if (flat_dst) {      // checked here, where the caller can still act on it: the largest flat form this frame can have must fit
+    const size_t need = pwn_hip_cloud_export_bound(std::min(cloud->d.capacity, rows * cols), cloud->d.omSym ? PWN_HIP_OMEGA_SYM6 : PWN_HIP_OMEGA_EXACT9, rows * cols, 0);
+    if (flat_bytes < need) return fail(ctx, PWN_HIP_ERR_CAPACITY, "flat cloud buffer too small for a frame of this size (pwn_hip_cloud_export_bound)");
+  }
+  return async_convert_begin(ctx, p, nullptr, raw_frame, depth_scale, rows, cols, 1, 0.f, cloud, flat_dst, flat_bytes);
+}
+int pwn_hip_convert_export_end(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud, size_t* written, float* job_ms) {
+  const int rc = pwn_hip_convert_end(ctx, cloud);
+  if (ctx && ctx->async) {
+    if (written) *written = rc == PWN_HIP_OK ? ctx->async->flat_written : 0;
+    if (job_ms) *job_ms = ctx->async->job_ms;
+  }
+  return rc;
+}
+static int async_convert_begin(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float* depth, const uint16_t* raw, float raw_scale, int rows, int cols,
+                               int step, float max_depth_cov, pwn_hip_cloud* cloud, void* flat_dst, size_t flat_bytes) {
   if (int rc = check_image(ctx, rows, cols)) return rc;
   if (rows / step <= 0 || cols / step <= 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "scaled image has zero size");
   if (!ctx->async) {
     AsyncConvert* a = new AsyncConvert();
-    if (int rc = pwn_hip_ctx_create(&a->helper, ctx->device, ctx->max_rows, ctx->max_cols, 1)) { const std::string m = g_err; delete a; return fail(ctx, rc, "helper context: " + m); }
+    if (int rc = ctx_create(&a->helper, ctx->device, ctx->max_rows, ctx->max_cols, 1, true)) { const std::string m = g_err; delete a; return fail(ctx, rc, "helper context: " + m); }
     a->worker = std::thread(async_convert_loop, a, ctx->device);
     ctx->async = a;
   }
@@ -1471,8 +1607,12 @@ int pwn_hip_convert_scaled_begin(pwn_hip_ctx* ctx, const pwn_hip_converter_param
     if (a->cloud || !a->done) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "a conversion is already in flight on this context (pwn_hip_convert_end first)");
     // the caller's copies (pwn_hip_copy_async into a device frame) must have landed before the helper's stream reads the frame
     if (int rc = absorb_copies(ctx)) return rc;
-    if (is_device_ptr(depth)) HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
+    // a device frame the context's own stream may still be writing (pwn_hip_copy_async above): wait for it.  The raw-frame form does not wait --
+    // it is what a caller queues from inside pwn_hip_ctx_set_enqueued_callback while the context's stream is busy with a batch -- and asks for a
+    // frame that is complete when the call is made (include/pwn_hip.h)
+    if (depth && is_device_ptr(depth)) HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
     cloud_changes(ctx, cloud);
+    a->raw = raw; a->raw_scale = raw_scale; a->flat_dst = flat_dst; a->flat_bytes = flat_bytes; a->flat_written = 0; a->job_ms = 0.f;
     a->p = *p; a->depth = depth; a->rows = rows; a->cols = cols; a->step = step; a->max_depth_cov = max_depth_cov; a->cloud = cloud;
     a->rc = PWN_HIP_OK; a->err.clear();
     a->done = false; a->has_job = true;
@@ -1527,7 +1667,7 @@ int pwn_hip_correspondences(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, c
   if (!ctx || !p || !ref || !cur || !ref_index || !cur_index || !T || !corr || !n_corr) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if (int rc = check_image(ctx, p->rows, p->cols)) return rc;
   const size_t N = (size_t)p->rows * p->cols;
-  const AlignParams ap = make_align_params(p);
+  const AlignParams ap = make_align_params(ctx, p);
   int* ri = ctx->index_ws; int* ci = ctx->interval_ws;
   if (int rc = absorb_copies(ctx)) return rc;      // caller pointers may be the destination of a queued pwn_hip_copy_async
   HIPCHK(ctx, copy_any(ri, ref_index, N * 4, ctx->stream), PWN_HIP_ERR_COPY);
@@ -1551,7 +1691,7 @@ int pwn_hip_linearize(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, const p
                       int C, const float T[16], float* H, float* b, float* error, int* inliers) {
   if (!ctx || !p || !ref || !cur || (!corr && C > 0) || !T || C < 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if ((size_t)C > ctx->N) return fail(ctx, PWN_HIP_ERR_CAPACITY, "more correspondences than pixels");
-  const AlignParams ap = make_align_params(p);
+  const AlignParams ap = make_align_params(ctx, p);
   if (int rc = absorb_copies(ctx)) return rc;      // caller pointers may be the destination of a queued pwn_hip_copy_async
   if (C > 0) HIPCHK(ctx, copy_any(ctx->corr_ws, corr, (size_t)C * sizeof(int2), ctx->stream), PWN_HIP_ERR_COPY);
   const int nb = std::max(1, align_nblocks(C));
@@ -1585,12 +1725,15 @@ struct AlignHooks {
 };
 // records (optional): n * PWN_HIP_RECORD_FLOATS floats, device or host, written by k_pack_records; pair_ids (optional, host): the id in
 // record word 19 (else first_pair_id + i).  results may be NULL when records are asked for.
-static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* refs, pwn_hip_cloud* const* curs,
+// robust: every projection of the call by the two-pass kernels (what align_batch_impl repeats a call with whose k_project gave up on a pixel)
+static int align_batch_once(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* refs, pwn_hip_cloud* const* curs,
                             const float* guesses, pwn_hip_align_result* results, pwn_hip_match_result* scores, float match_threshold,
-                            pwn_hip_align_statistics* statistics = nullptr, const AlignHooks* hooks = nullptr, float* records = nullptr,
-                            const int* pair_ids = nullptr, int first_pair_id = 0, bool match_records = false) {
+                            pwn_hip_align_statistics* statistics, const AlignHooks* hooks, float* records,
+                            const int* pair_ids, int first_pair_id, bool match_records, bool robust) {
   if (!ctx || !p || !refs || !curs || (!results && !records) || n < 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null argument");
   if (int rc = check_image(ctx, p->rows, p->cols)) return rc;
+  ctx->last_align_fault = 0;
+  if (robust) { if (int rc = ensure_zdepth(ctx)) return rc; }
   ctx->img_valid = false;                 // whatever happens below, the finder images of an earlier alignment are gone (set again on success)
   const bool want_scores = scores != nullptr || (records && match_records);      // the score words of the long records come from the same accumulators
   if (p->min_distance < 0.f) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "min_distance must be >= 0");
@@ -1598,7 +1741,7 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
   if (p->outer_iterations < 0 || p->inner_iterations < 0 || nit > PWN_HIP_MAX_ITERATIONS)
     return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "outer*inner iterations exceeds PWN_HIP_MAX_ITERATIONS");
   const int N = p->rows * p->cols;
-  const AlignParams ap = make_align_params(p);
+  const AlignParams ap = make_align_params(ctx, p);
   const int nb = align_nblocks(N);
   ctx->stages.clear();
   const StreamPlan plan = make_plan(ctx, ctx->sub_pairs, n);
@@ -1613,7 +1756,11 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
   const bool ident_ref = is_identity(forced(p->reference_sensor_offset));
   const bool direct_state = n <= 4;
   const int omSym = (n > 0 && curs[0]) ? curs[0]->d.omSym : 0;      // the linearizer reads the CURRENT cloud's information matrices (linearizer.cpp:52-53)
-  // descriptors + initial states of all pairs; workspace slots are reused round-robin across sub-batches
+  // descriptors + initial states of all pairs; workspace slots are reused round-robin across sub-batches.  This loop runs with the device
+  // idle (the call's first launch comes after it): what does not depend on the pair is computed once, and only the head of a state is cleared
+  // (the traces behind `it` are written before they are read: k_solve_update stores entry `it`, every reader stops at `it`)
+  Mat4 KRtCur0;
+  { Mat4 iKRt0; Mat3 iK0; projector_matrices(ap.K, mat4_from(p->current_sensor_offset), KRtCur0, iKRt0, iK0); }
   for (int i = 0; i < n; ++i) {
     const pwn_hip_cloud* r = refs[i]; const pwn_hip_cloud* c = curs[i];
     if (!r || !c) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "null cloud in batch");
@@ -1636,9 +1783,11 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
     // a few pairs (latency path): k_solve_update writes the pose and the traces into the page-locked host copy itself, no copy back at the end;
     // batches copy the states back in one transfer (64 workgroups storing across PCIe in every solve launch cost more than that: 16 against 11 us per launch)
     pd.state_out = direct_state ? ctx->state_host + i : nullptr;
+    pd.fault = ctx->align_fault_host;
+    pd.zdepth = robust ? ctx->zdepth_ws + (size_t)slot * ctx->N : nullptr;
     // initial state: aligner.cpp:60-64,72-73,79,84
     PairState& st = ctx->state_host[i];
-    std::memset(&st, 0, sizeof(st));
+    std::memset(&st, 0, offsetof(PairState, chi2));
     Mat4 T = mat4_from(guesses ? guesses + 16 * (size_t)i : p->initial_guess);
     set_last_row(T);
     // first reference projection with an identity pose (identity guess and reference offset): it returns the reference cloud's own index
@@ -1651,7 +1800,7 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
     Mat4 iKRt; Mat3 iK;
     projector_matrices(ap.K, iso_mul(T, ap.refOffset), st.KRt, iKRt, iK);
     st.KRtLast = st.KRt;
-    projector_matrices(ap.K, mat4_from(p->current_sensor_offset), st.KRtCur, iKRt, iK);
+    st.KRtCur = KRtCur0;
     st.it = 0;
   }
   // a sub-batch skips the projection kernels only if every pair of it can
@@ -1700,13 +1849,13 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
     if (hooks && hooks->pre_sub) { if (int rc = hooks->pre_sub(base, m, kk, st)) return rc; }
     if (!sub_own[kk]) {
       StageTimer t(ctx, "project_cur", st);
-      launch_project(maxcap_cur, m, st, pr, ap, 1, subTag0);
+      if (int rc = launch_project(ctx, maxcap_cur, m, st, pr, ap, 1, subTag0, robust ? ctx->zdepth_ws + s0 * ctx->N : nullptr)) return rc;
       hipLaunchKernelGGL(k_resolve_cur, dim3(std::min((N + 255) / 256, 1024), m), dim3(256), 0, st, pr, N, subTag0); }
     for (int i = 0; i < p->outer_iterations; ++i) {
       const unsigned tag = subTag0 - (unsigned)i;      // epoch of this outer iteration's reference projection
       const int ownRef = (i == 0 && sub_ownref[kk]) ? 1 : 0;
       if (!ownRef) { StageTimer t(ctx, "project_ref", st);
-        launch_project(maxcap_ref, m, st, pr, ap, 0, tag); }
+        if (int rc = launch_project(ctx, maxcap_ref, m, st, pr, ap, 0, tag, robust ? ctx->zdepth_ws + s0 * ctx->N : nullptr)) return rc; }
       for (int k = 0; k < p->inner_iterations; ++k) {
         const bool lastInner = (k == p->inner_iterations - 1);
         { StageTimer t(ctx, "corr_linearize", st);
@@ -1766,8 +1915,13 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
   // iterations it still holds the initial state
   if (n > 0 && !direct_state && results) HIPCHK(ctx, hipMemcpyAsync(ctx->state_host, ctx->state_ws, sizeof(PairState) * n, hipMemcpyDeviceToHost, ctx->stream), PWN_HIP_ERR_COPY);
   HIPCHK(ctx, hipEventRecord(ctx->t1, ctx->stream), PWN_HIP_ERR_LAUNCH);      // before the wait: recording it afterwards costs a second round trip per call
+  // everything of the call is queued, nothing has been waited for: the caller's moment to queue what depends on it on other streams, or to prepare
+  // the next call, while the device works (pwn_hip_ctx_set_enqueued_callback)
+  if (ctx->enqueued_cb && n > 0) ctx->enqueued_cb(ctx->enqueued_user);
   HIPCHK(ctx, hipStreamSynchronize(ctx->stream), PWN_HIP_ERR_LAUNCH);
   if (hooks && hooks->after_sync) { if (int rc = hooks->after_sync()) return rc; }
+  if (take_align_fault(ctx)) return fail(ctx, PWN_HIP_ERR_LAUNCH, kSettleMessage);
+  for (int i = 0; i < n && scores; ++i) finish_match(ctx->match_host[i], &scores[i]);      // with or without `results` (pwn_hip_match_batch_records)
   for (int i = 0; i < n && results; ++i) {
     const PairState& st = ctx->state_host[i];
     pwn_hip_align_result& r = results[i];
@@ -1779,7 +1933,6 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
     }
     if (st.it > 0) { r.error = st.chi2[st.it - 1]; r.inliers = st.inliers[st.it - 1]; }
     r.n_reference = refs[i]->n_host; r.n_current = curs[i]->n_host;
-    if (scores) finish_match(ctx->match_host[i], &scores[i]);
     if (statistics) {
       pwn_hip_align_statistics& q = statistics[i];
       std::memset(&q, 0, sizeof(q));
@@ -1799,6 +1952,20 @@ static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, i
   collect_stage_times(ctx);
   return PWN_HIP_OK;
 }
+// The call; and once more with the two-pass projection if one of its projections gave up on a pixel (z32_settle): nothing of the failed
+// attempt is kept (states and descriptors are rebuilt, z-buffer tags move on; the hooks of a fused step convert the same frames into the same
+// clouds again).  A fault in the repeat cannot happen (k_project_robust has no loop) and would be reported.
+static int align_batch_impl(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* refs, pwn_hip_cloud* const* curs,
+                            const float* guesses, pwn_hip_align_result* results, pwn_hip_match_result* scores, float match_threshold,
+                            pwn_hip_align_statistics* statistics = nullptr, const AlignHooks* hooks = nullptr, float* records = nullptr,
+                            const int* pair_ids = nullptr, int first_pair_id = 0, bool match_records = false) {
+  int rc = align_batch_once(ctx, p, n, refs, curs, guesses, results, scores, match_threshold, statistics, hooks, records, pair_ids, first_pair_id, match_records, false);
+  if (rc == PWN_HIP_ERR_LAUNCH && ctx && ctx->last_align_fault) {
+    ++ctx->projection_fallbacks;
+    rc = align_batch_once(ctx, p, n, refs, curs, guesses, results, scores, match_threshold, statistics, hooks, records, pair_ids, first_pair_id, match_records, true);
+  }
+  return rc;
+}
 int pwn_hip_align_batch(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, int n, pwn_hip_cloud* const* refs, pwn_hip_cloud* const* curs,
                         const float* guesses, pwn_hip_align_result* results) {
   return align_batch_impl(ctx, p, n, refs, curs, guesses, results, nullptr, 0.f);
@@ -1812,8 +1979,19 @@ int pwn_hip_align_with_priors(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p,
                               const pwn_hip_prior* priors, pwn_hip_align_result* result) {
   return pwn_hip_align_with_priors_ex(ctx, p, ref, cur, n_priors, priors, result, nullptr);
 }
+static int align_with_priors_once(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, const pwn_hip_cloud* ref, const pwn_hip_cloud* cur, int n_priors,
+                                  const pwn_hip_prior* priors, pwn_hip_align_result* result, pwn_hip_align_statistics* statistics, bool robust);
 int pwn_hip_align_with_priors_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, const pwn_hip_cloud* ref, const pwn_hip_cloud* cur, int n_priors,
                                  const pwn_hip_prior* priors, pwn_hip_align_result* result, pwn_hip_align_statistics* statistics) {
+  int rc = align_with_priors_once(ctx, p, ref, cur, n_priors, priors, result, statistics, false);
+  if (rc == PWN_HIP_ERR_LAUNCH && n_priors > 0 && ctx && ctx->last_align_fault) {      // see align_batch_impl (which handles the prior-less case itself)
+    ++ctx->projection_fallbacks;
+    rc = align_with_priors_once(ctx, p, ref, cur, n_priors, priors, result, statistics, true);
+  }
+  return rc;
+}
+static int align_with_priors_once(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, const pwn_hip_cloud* ref, const pwn_hip_cloud* cur, int n_priors,
+                                  const pwn_hip_prior* priors, pwn_hip_align_result* result, pwn_hip_align_statistics* statistics, bool robust) {
   if (n_priors <= 0) {
     pwn_hip_cloud* r[1] = { const_cast<pwn_hip_cloud*>(ref) };
     pwn_hip_cloud* c[1] = { const_cast<pwn_hip_cloud*>(cur) };
@@ -1834,13 +2012,17 @@ int pwn_hip_align_with_priors_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params*
   if (std::min(ref->n_host, ref->d.capacity) > kMaxAlignerPoints || std::min(cur->n_host, cur->d.capacity) > kMaxAlignerPoints)
     return fail(ctx, PWN_HIP_ERR_CAPACITY, "Aligner::align: a cloud holds more than 2^21 points (index field of the aligner's z-buffer word)");
   const int N = p->rows * p->cols;
-  const AlignParams ap = make_align_params(p);
+  const AlignParams ap = make_align_params(ctx, p);
   const int nb = align_nblocks(N);
   hipStream_t st = ctx->stream;
   PairDesc& pd = ctx->pairs_host[0];
   pd.ref = ref->d; pd.cur = cur->d;
   pd.zref = ctx->z32ref_ws; pd.zcur = ctx->z32cur_ws; pd.curidx = ctx->curidx_ws; pd.partials = ctx->partials_ws; pd.state = ctx->state_ws;
   pd.refidx0 = nullptr; pd.state_out = nullptr;
+  ctx->last_align_fault = 0;
+  if (robust) { if (int rc = ensure_zdepth(ctx)) return rc; }
+  pd.fault = ctx->align_fault_host; pd.zdepth = robust ? ctx->zdepth_ws : nullptr;
+  ctx->img_valid = false;
   ctx->img_pair = 0; ctx->img_ref_cloud = ref; ctx->img_cur_cloud = cur;
   PairState& hs = ctx->state_host[0];
   std::memset(&hs, 0, sizeof(hs));
@@ -1854,7 +2036,7 @@ int pwn_hip_align_with_priors_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params*
   // leave words behind that beat a later call's)
   unsigned tag0 = kZ32Tag0;
   if (int rc = take_tags32(ctx, (unsigned)std::max(1, p->outer_iterations), &tag0)) return rc;
-  launch_project(cur->d.capacity, 1, st, ctx->pairs_dev, ap, 1, tag0);
+  if (int rc = launch_project(ctx, cur->d.capacity, 1, st, ctx->pairs_dev, ap, 1, tag0, pd.zdepth)) return rc;
   hipLaunchKernelGGL(k_resolve_cur, dim3(std::min((N + 255) / 256, 1024), 1), dim3(256), 0, st, ctx->pairs_dev, N, tag0);
   std::memset(result, 0, sizeof(*result));
   int it = 0;
@@ -1869,7 +2051,7 @@ int pwn_hip_align_with_priors_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params*
       set_last_row(invT);                                                            // :86
       hs.invT = invT;
       HIPCHK(ctx, hipMemcpyAsync(ctx->state_ws, &hs, sizeof(PairState), hipMemcpyHostToDevice, st), PWN_HIP_ERR_COPY);
-      if (k == 0) launch_project(ref->d.capacity, 1, st, ctx->pairs_dev, ap, 0, tag);
+      if (k == 0) { if (int rc = launch_project(ctx, ref->d.capacity, 1, st, ctx->pairs_dev, ap, 0, tag, pd.zdepth)) return rc; }
       if (k == 0) launch_corr_linearize<true, true>(ctx, cur->d.omSym, nb, 1, st, ctx->pairs_dev, ap, tag, 0, 0);
       else launch_corr_linearize<false, true>(ctx, cur->d.omSym, nb, 1, st, ctx->pairs_dev, ap, tag, 0, 0);
       hipLaunchKernelGGL(k_reduce_pairs, dim3(1), dim3(256), 0, st, ctx->pairs_dev, nb, ctx->stats_dev);
@@ -1913,6 +2095,7 @@ int pwn_hip_align_with_priors_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params*
   }
   HIPCHK(ctx, hipEventRecord(ctx->t1, st), PWN_HIP_ERR_LAUNCH);
   HIPCHK(ctx, hipEventSynchronize(ctx->t1), PWN_HIP_ERR_LAUNCH);
+  if (take_align_fault(ctx)) return fail(ctx, PWN_HIP_ERR_LAUNCH, kSettleMessage);
   float ms = 0.f; (void)hipEventElapsedTime(&ms, ctx->t0, ctx->t1);
   std::memcpy(result->T, T.m, sizeof(result->T));
   result->iterations = it; result->total_time_ms = ms;
@@ -2023,7 +2206,12 @@ int pwn_hip_align_images(pwn_hip_ctx* ctx, int* ref_index, float* ref_depth, int
   if (!ctx->img_valid) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "no alignment has run on this context");
   const size_t N = (size_t)ctx->img_rows * ctx->img_cols;
   if (ctx->img_cur_lazy && (cur_index || cur_depth)) {      // the projection the alignment skipped, with the tag it had reserved for it
-    launch_project(ctx->img_cur_capacity, 1, ctx->stream, ctx->pairs_dev + ctx->img_pair, ctx->img_ap, 1, ctx->img_cur_tag);
+    // two-pass form straight away: one projection of one cloud, off the hot path, and no repeat to arrange (the pair's descriptor on the device
+    // gets the depth image's address first)
+    if (int rc = ensure_zdepth(ctx)) return rc;
+    ctx->pairs_host[ctx->img_pair].zdepth = ctx->zdepth_ws;
+    HIPCHK(ctx, hipMemcpyAsync(&ctx->pairs_dev[ctx->img_pair].zdepth, &ctx->pairs_host[ctx->img_pair].zdepth, sizeof(unsigned*), hipMemcpyHostToDevice, ctx->stream), PWN_HIP_ERR_COPY);
+    if (int rc = launch_project(ctx, ctx->img_cur_capacity, 1, ctx->stream, ctx->pairs_dev + ctx->img_pair, ctx->img_ap, 1, ctx->img_cur_tag, ctx->zdepth_ws)) return rc;
     HIPCHK(ctx, hipGetLastError(), PWN_HIP_ERR_LAUNCH);
     ctx->img_cur_lazy = false;
   }

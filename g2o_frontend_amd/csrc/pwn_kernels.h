@@ -155,6 +155,8 @@ struct PairDesc {
   double* partials;        // [nblocks][kAccN]
   PairState* state;
   PairState* state_out;    // optional: page-locked host copy that k_solve_update keeps up to date in what the host reads back (T, it, the traces)
+  int* fault;              // page-locked host word of the call: k_project stores 1 when a pixel's settle loop gave up (z32_settle)
+  unsigned* zdepth;        // depth image of the two-pass projection (k_project_robust), nullptr unless the call runs in that mode
 };
 
 struct AlignParams {
@@ -165,6 +167,7 @@ struct AlignParams {
   float sqDist, normalThr, flatThr, minRatio, maxRatio;
   float maxChi2;
   int robust;
+  int settleGuard;         // rounds of z32_settle's compare-and-swap loop before a thread gives up (kSettleGuard)
 };
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -1148,23 +1151,30 @@ __device__ __forceinline__ Z32Pending z32_insert(const Mat4& KRt, float minD, fl
 // z32_settle: nothing to do for the first point of this projection in its pixel (older tags and the empty word are larger than any key of
 // the current tag); otherwise make sure the word ends up with the nearest of every point this thread gets to see, ties to the lower index.
 // P: the cloud's points (to evaluate the depth of a point met in the pixel).
-__device__ __forceinline__ void z32_settle(const Z32Pending& q, const Mat4& KRt, const float* __restrict__ P3, unsigned tag) {
-  if (!q.w || (q.old >> kZIndexBits) != tag) return;
+// The loop is lock-free (a failed compare-and-swap means another thread's write went through, and the word only changes a bounded number of
+// times: one insert per point, and every successful swap installs a strictly nearer point), but its length has no useful bound when tens of
+// thousands of points of one projection share a pixel.  A thread that has not settled after guardLimit rounds gives up and raises the
+// call's fault word (page-locked host memory, PairDesc::fault): the host then repeats the call with the two-pass projection below, so a
+// pixel is never silently left with the wrong point (pinholepointprojector.cpp:54-63).
+constexpr int kSettleGuard = 4096;
+__device__ __forceinline__ bool z32_settle(const Z32Pending& q, const Mat4& KRt, const float* __restrict__ P3, unsigned tag, int guardLimit) {
+  if (!q.w || (q.old >> kZIndexBits) != tag) return true;
   int best = (int)(q.key & kZ32IndexMask); float dbest = q.d;
   unsigned cur = q.old < q.key ? q.old : q.key;       // what the word holds after the atomicMin, unless someone changed it since
   unsigned seen = q.old;
-  for (int guard = 0; guard < 1024; ++guard) {
+  for (int guard = 0; guard < guardLimit; ++guard) {
     const int j = (int)(seen & kZ32IndexMask);
     if (j != best) {
       const float dj = point_depth(KRt, load_xyz(P3, j));
       if (dj < dbest || (dj == dbest && j < best)) { best = j; dbest = dj; }
     }
     const unsigned want = z32key(tag, best);
-    if (cur == want) break;
+    if (cur == want) return true;
     const unsigned r = atomicCAS(q.w, cur, want);
-    if (r == cur) break;                              // installed
+    if (r == cur) return true;                        // installed
     seen = r; cur = r;                                // somebody else wrote (same tag): weigh its point too and try again
   }
+  return false;
 }
 // PPT points per thread: all loads first, then all atomicMin's, then the (rare) collisions -- with one point per thread the wave waits
 // for every returned word before it does anything else (measured per 64-pair launch: 134 us with 1 point per thread, 104 with 2, 101
@@ -1189,8 +1199,39 @@ __global__ void __launch_bounds__(256) k_project(const PairDesc* __restrict__ pa
     const int i = i0 + 256 * j;
     if (i < n) q[j] = z32_insert(KRt, ap.minD, ap.maxD, ap.rows, ap.cols, p[j], i, z, tag); else q[j].w = nullptr;
   }
+  bool settled = true;
 #pragma unroll
-  for (int j = 0; j < kProjectPointsPerThread; ++j) z32_settle(q[j], KRt, cl.P3, tag);
+  for (int j = 0; j < kProjectPointsPerThread; ++j) settled = z32_settle(q[j], KRt, cl.P3, tag, ap.settleGuard) && settled;
+  if (!settled) __hip_atomic_store(pd.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// The same projection without a retry loop, for calls whose k_project gave up (and for nothing else: it reads the points twice and clears a
+// depth image per projection).  Pass 1: the nearest depth per pixel by atomicMin on the depth's bit pattern (depths are >= 0: min_distance >= 0
+// is checked by the host, so the patterns order like the values; -0 counts as 0) in the pair's own depth image PairDesc::zdepth, cleared to ~0
+// by the host before the launch.  Pass 2: every point that has its pixel's nearest depth enters the 32-bit word by atomicMin on tag | index:
+// the nearest point, ties to the lowest index -- the reference's sequential strict '>' (pinholepointprojector.cpp:61), the word k_project leaves.
+__device__ __forceinline__ bool project_pixel(const Mat4& KRt, const AlignParams& ap, const float4 p, int& pix, unsigned& dbits) {
+  const float ix = dot4seq(KRt(0,0), p.x, KRt(0,1), p.y, KRt(0,2), p.z, KRt(0,3), 1.0f);
+  const float iy = dot4seq(KRt(1,0), p.x, KRt(1,1), p.y, KRt(1,2), p.z, KRt(1,3), 1.0f);
+  const float d  = dot4seq(KRt(2,0), p.x, KRt(2,1), p.y, KRt(2,2), p.z, KRt(2,3), 1.0f);
+  if (d < ap.minD || d > ap.maxD) return false;
+  const float inv = 1.0f / d;
+  const float fx = roundf(ix * inv), fy = roundf(iy * inv);
+  if (!(fx >= 0.f && fx < (float)ap.cols && fy >= 0.f && fy < (float)ap.rows)) return false;
+  pix = (int)fy * ap.cols + (int)fx;
+  dbits = __float_as_uint(d) & 0x7fffffffu;
+  return true;
+}
+__global__ void __launch_bounds__(256) k_project_robust(const PairDesc* __restrict__ pairs, AlignParams ap, int which, unsigned tag, int pass) {
+  const PairDesc& pd = pairs[blockIdx.y];
+  const CloudDev& cl = which ? pd.cur : pd.ref;
+  const int n = min(*cl.count, cl.capacity);
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const Mat4 KRt = uniform_iso(which ? pd.state->KRtCur : pd.state->KRt);
+  int pix; unsigned dbits;
+  if (!project_pixel(KRt, ap, load_xyz(cl.P3, i), pix, dbits)) return;
+  if (pass == 0) atomicMin(&pd.zdepth[pix], dbits);
+  else if (pd.zdepth[pix] == dbits) atomicMin(&(which ? pd.zcur : pd.zref)[pix], z32key(tag, i));
 }
 // current-cloud z-buffer -> int index image, once per alignment.  grid = (blocks, pairs)
 __global__ void k_resolve_cur(const PairDesc* __restrict__ pairs, int n, unsigned tag) {
@@ -1834,7 +1875,10 @@ __global__ void __launch_bounds__(256) k_solve_update(const PairDesc* __restrict
 }
 // The result record of a pair as it travels between ranks (include/pwn_hip.h: PWN_HIP_RECORD_FLOATS): 64 floats =
 //   [0:16] T column-major  [16] chi2 of the last iteration  [17] its inliers  [18] iterations  [19] the caller's pair id
-//   [20:30] chi2_i  [30:40] inliers_i  [40:50] C_i  [50:60] K_i (first 10 iterations)  [60] M_ref  [61] M_cur  [62] iterations in the traces  [63] 0
+//   [20:30] chi2_i  [30:40] inliers_i  [40:50] C_i  [50:60] K_i (first 10 iterations)  [60] M_ref  [61] M_cur  [62] iterations in the traces
+//   [63] 0, or 1 when a projection of the call gave up on a pixel (z32_settle): the library repeats such a call and the records it returns are the
+//        repeat's, but a reader that takes the records off the device BEFORE the call has returned (pwn_hip_ctx_set_enqueued_callback) sees the
+//        first attempt's and must drop them
 // written on the device from the pair's state, so that a gather of records needs no trip through the host.  Counts travel as float
 // (exact below 2^24).  grid = pairs, block = 64
 // match != nullptr: a record has kMatchRecordFloats words, [64:68] = PwnMatcherBase::MatcherResult's image fields of the pair (nonZeros, outliers,
@@ -1867,6 +1911,7 @@ __global__ void __launch_bounds__(128) k_pack_records(const PairDesc* __restrict
   else if (t == 60) v = (float)*pd.ref.count;
   else if (t == 61) v = (float)*pd.cur.count;
   else if (t == 62) v = (float)m;
+  else if (t == 63) v = (float)__hip_atomic_load(pd.fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // 1 = the call's fault word is up (see the layout above)
   out[(size_t)blockIdx.x * len + t] = v;
 }
 // reduction only, one record per pair (Aligner::_computeStatistics' 11th update).  grid = pairs, block = 256

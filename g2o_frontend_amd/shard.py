@@ -13,7 +13,8 @@ import numpy as np
 # One result record per pair, 64 floats = 256 bytes ({T, chi2[10], inliers[10], C[10], flags}):
 #   [0:16]  T, column-major 4x4                      [16] chi2 of the last iteration   [17] inliers   [18] iterations   [19] global pair id
 #   [20:30] chi2 per iteration   [30:40] inliers per iteration   [40:50] correspondences C_i   [50:60] candidates K_i   (first TRACE iterations)
-#   [60] points of the reference cloud   [61] points of the current cloud   [62] iterations carried in the traces   [63] 0
+#   [60] points of the reference cloud   [61] points of the current cloud   [62] iterations carried in the traces
+#   [63] 0 (1 = records of a call that is being repeated, see include/pwn_hip.h)
 # Integers travel as float32 (exact: every count is < 2^24).
 TRACE = 10
 RECORD_FLOATS = 64
@@ -84,4 +85,6 @@ def assemble(gathered: np.ndarray, n_pairs: int) -> np.ndarray:
     rec, ids = gathered[keep], ids[keep]
     if len(ids) != n_pairs or len(np.unique(ids)) != n_pairs:
         raise RuntimeError(f"gather incomplete: {len(ids)} records for {n_pairs} pairs")
+    if rec.shape[1] >= RECORD_FLOATS and np.any(rec[:, 63] != 0):
+        raise RuntimeError("records of a call that was being repeated (word 63): taken off the device before the call returned")
     return rec[np.argsort(ids, kind="stable")]

@@ -148,6 +148,19 @@ int pwn_hip_ctx_synchronize(pwn_hip_ctx* ctx);
  *     (pwn_hip_cloud_import, convert*): call it after queueing the writer.
  * The other direction needs nothing: every call is complete on return (outputs valid), pwn_hip_copy_async excepted (see there). */
 int pwn_hip_ctx_wait_stream(pwn_hip_ctx* ctx, void* hip_stream);
+/* The other direction: what the caller queues on `hip_stream` from now on runs after everything the context has queued so far.  With
+ * pwn_hip_ctx_set_enqueued_callback this lets a collective that sends a call's device `records` be queued while the call's kernels still run. */
+int pwn_hip_ctx_signal_stream(pwn_hip_ctx* ctx, void* hip_stream);
+/* fn(user) is called on the calling thread by every alignment batch call of the context (pwn_hip_align_batch*, pwn_hip_match_batch*,
+ * pwn_hip_convert_align_batch_u16; n > 0) after ALL device work of the call has been queued -- records packed, copies back queued -- and before
+ * the call waits for it.  The reference's closer loop (pwn_tracker/pwn_closer.cpp:85-111) is sequential; on a GPU the host's share of a step
+ * (queueing the exchange of the results, fetching and replicating the next `current` cloud) would otherwise run with the device idle between two
+ * calls.  Inside fn: other streams and other contexts freely; on THIS context only pwn_hip_ctx_signal_stream, pwn_hip_ctx_wait_stream,
+ * pwn_hip_convert_export_begin / _end, pwn_hip_convert_scaled_begin / pwn_hip_convert_end -- no call that converts, aligns or waits on it.  The
+ * results the call returns (and host `records`) are not valid inside fn; device `records` are valid for work ordered with
+ * pwn_hip_ctx_signal_stream.  If the call has to be repeated (word 63 of the records, PWN_HIP_RECORD_FLOATS) fn runs again for the repeat.
+ * fn = NULL switches it off. */
+int pwn_hip_ctx_set_enqueued_callback(pwn_hip_ctx* ctx, void (*fn)(void* user), void* user);
 /* Batch calls are executed in sub-batches of at most this many frames / pairs (default 64, capped by
  * max_batch), which bounds the workspace the temporaries (integral images, z-buffers) need.  Measured on
  * MI355X: larger sub-batches are faster (fewer, fuller launches) -- as long as every stream has one: a call of
@@ -285,6 +298,18 @@ int pwn_hip_convert_scaled(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, 
 int pwn_hip_convert_scaled_begin(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float* depth, int rows, int cols, int step,
                                  float max_depth_cov, pwn_hip_cloud* cloud);
 int pwn_hip_convert_end(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud);
+/* The look-ahead of a sharded PwnCloser::processPartition (pwn_tracker/pwn_closer.cpp:85-111): the outer loop hands the closer one `current`
+ * keyframe after the other, and _cache->get(current) of keyframe k+1 (:92-93; PwnCache::makeCloud, pwn_tracker_cache.cpp:24-51) depends on nothing
+ * keyframe k's matches produce.  _begin returns at once; a helper thread converts the raw uint16 frame (depth = depth_scale * raw, as
+ * pwn_hip_convert_batch_u16) into `cloud` and then, with flat_dst != NULL, writes the cloud's flat form (pwn_hip_cloud_export) into flat_dst (device
+ * or host; at least pwn_hip_cloud_export_bound(min(capacity, rows*cols), storage, rows*cols, 0) bytes, checked by _begin) -- what the rank that owns
+ * `current` broadcasts while every rank still matches the previous keyframe.  _end waits for the job, returns its status and reports the bytes
+ * written (what to broadcast) and the job's wall time on the helper thread in milliseconds; both optional.  Same rules as
+ * pwn_hip_convert_scaled_begin between the two calls (frame, cloud AND flat_dst belong to the job; one job in flight per context); the cloud holds
+ * the bits pwn_hip_convert_batch_u16 gives, the buffer the bytes pwn_hip_cloud_export gives. */
+int pwn_hip_convert_export_begin(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const uint16_t* raw_frame, float depth_scale, int rows, int cols,
+                                 pwn_hip_cloud* cloud, void* flat_dst, size_t flat_bytes);
+int pwn_hip_convert_export_end(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud, size_t* written, float* job_ms);
 /* n independent frames of equal size in one call.  depth[i] -> clouds[i].
  * depth_frames: n pointers (host array) to rows*cols floats each (each host or device). */
 int pwn_hip_convert_batch(pwn_hip_ctx* ctx, const pwn_hip_converter_params* p, const float* const* depth_frames,
@@ -348,7 +373,9 @@ int pwn_hip_align_batch_ex(pwn_hip_ctx* ctx, const pwn_hip_aligner_params* p, in
  * pwn_tracker/pwn_closer.cpp:92-111):
  *   [0:16] T (column-major)   [16] chi2 of the last iteration   [17] its inliers   [18] iterations   [19] pair id
  *   [20:30] chi2_i   [30:40] inliers_i   [40:50] correspondences C_i   [50:60] candidates K_i   (first 10 iterations; 0 beyond the last)
- *   [60] points of the reference cloud   [61] of the current cloud   [62] iterations carried in the traces   [63] 0
+ *   [60] points of the reference cloud   [61] of the current cloud   [62] iterations carried in the traces
+ *   [63] 0; 1 = a projection of the call gave up on a pixel and the call is being repeated (the records a call RETURNS always carry 0: only a reader
+ *        that takes device records inside pwn_hip_ctx_set_enqueued_callback can meet a 1, and drops those records)
  * Counts travel as float (exact below 2^24).  The records are written by a kernel from the pairs' device state: `records` may be a DEVICE
  * buffer (n * PWN_HIP_RECORD_FLOATS floats; e.g. the tensor an all-gather sends -- no trip through the host) or host memory.
  * pair_ids (host, may be NULL: then record i carries first_pair_id + i).  results may be NULL when only the records are wanted.

@@ -25,6 +25,15 @@ int pwn_hip_debug_convert_retries(pwn_hip_ctx* ctx, int* retries);
  * hold the shortcut against the projection it replaces; 1 (the default) switches it back on. */
 int pwn_hip_debug_set_index_shortcut(pwn_hip_ctx* ctx, int enabled);
 
+/* PinholePointProjector::project (pinholepointprojector.cpp:54-63) keeps the nearest point per pixel, ties to the lowest index.  The aligner's
+ * projection kernel settles two points of one projection that meet in a pixel with a compare-and-swap loop; a thread that has not settled after
+ * `rounds` rounds (default 4096: tens of thousands of points in one pixel) raises the call's fault word, and the library repeats the whole call
+ * with a two-pass projection (nearest depth per pixel, then the lowest index among the points that have it) that needs no loop -- the images are
+ * the reference's either way.  rounds = 0 makes every collision give up, so that the repeat can be watched; rounds < 0 restores the default.
+ * Number of calls repeated so far: */
+int pwn_hip_debug_set_settle_guard(pwn_hip_ctx* ctx, int rounds);
+int pwn_hip_debug_projection_fallbacks(pwn_hip_ctx* ctx, int* calls);
+
 #ifdef __cplusplus
 }
 #endif

@@ -204,6 +204,18 @@ def test_match_batch_records_carry_the_matcher_results():
         # the alignments found the relative pose of the views (same scene, <= 5 cm / 2.3 deg apart, guess 1 cm / 0.5 deg off)
         assert np.abs(b["align"]["T"][:3, 3] - synth.pair_pose(bench.PARTITION_POSE0 + i)[:3, 3]).max() < 2e-2, i
         assert b["image_nonZeros"] > N // 2
+    # include/pwn_hip.h: results and scores may be NULL independently -- scores without results are filled in all the same
+    import ctypes as C
+    from g2o_frontend_amd._lib import MatchResult
+    refs, curs, g, _ = matcher.matchHandles([current] * n, others, guesses)
+    only = (MatchResult * n)()
+    rec3 = np.zeros((n, api.MATCH_RECORD_FLOATS), np.float32)
+    p = aligner.params()
+    ctx.check(ctx._L.pwn_hip_match_batch_records(ctx.h, C.byref(p), n, refs, curs, g.ctypes.data_as(C.c_void_p), 50.0, None, 100, None, only, rec3.ctypes.data_as(C.c_void_p)))
+    assert np.array_equal(_bits(rec3), _bits(rec))
+    for i in range(n):
+        assert (only[i].image_non_zeros, only[i].image_inliers, only[i].image_outliers) == (sc[i].image_non_zeros, sc[i].image_inliers, sc[i].image_outliers)
+        assert np.float32(only[i].image_reprojection_distance).view(np.uint32) == np.float32(sc[i].image_reprojection_distance).view(np.uint32)
     # a records buffer that is too small or of the wrong type never reaches the library
     with pytest.raises(ValueError):
         matcher.matchCloudsBatchRecords([current] * n, others, I, I, Km, rows, cols, ctx.upload(np.zeros((n, 64), np.float32)), guesses)
