@@ -80,6 +80,10 @@ def parse(argv=None):
                          "converts and caches its shard of --pairs keyframes per GPU once (untimed); a step = rank 0 converts `current`, its cloud is replicated "
                          "to every GPU by one broadcast (RCCL), every rank runs matchClouds (align from an odometry guess + depth-agreement score) of `current` "
                          "against its shard, 288-byte records all-gathered")
+    ap.add_argument("--one-device", action="store_true",
+                    help="rehearsal of N > 1 on ONE GPU: every rank is a process of its own on device 0 and the collectives go through gloo (RCCL refuses two "
+                         "ranks on one device).  Same steps, same ordering calls (pwn_hip_ctx_wait_stream / _signal_stream), the ranks contend for the device; "
+                         "the rate is not a scaling figure and the line says so (config.rehearsal)")
     ap.add_argument("--dry-run-cpu", action="store_true",
                     help="launcher / sharding / gather plumbing only, on the CPU with the gloo backend (no GPU, no kernels): used by tests")
     return ap.parse_args(argv)
@@ -1367,7 +1371,8 @@ def multi_gpu_diagnostics(w, args, rank, world, dt_rank, dt_serial, pinned, n_co
     mine += [w.stage_ms[k] / max(args.steps, 1) for k in keys]
     t = torch.tensor(mine, dtype=torch.float64, device="cuda")
     allt = torch.empty((world, len(mine)), dtype=torch.float64, device="cuda")
-    dist.all_gather_into_tensor(allt, t)
+    from g2o_frontend_amd import shard
+    shard.all_gather_into(allt, t)
     coll = w.time_collectives(n_collective)
     a = allt.cpu().numpy()
     return {"per_rank_ms_per_step": [float(x) for x in a[:, 0]], "per_rank_serial_pass_ms_per_step": [float(x) for x in a[:, 1]],
@@ -1394,7 +1399,11 @@ def main():
         # `python bench.py --gpus N`: become the launcher; the ranks are children started before any GPU call (this process makes none)
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", 0)); world = int(os.environ.get("WORLD_SIZE", 1)); local = int(os.environ.get("LOCAL_RANK", 0))
-    pinned = pin_rank(local, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if world > 1 else None      # before the render pool and before any GPU call
+    if args.one_device:
+        local_cpu, local = local, 0           # the rank's block of host cores still follows LOCAL_RANK; its GPU is device 0
+    else:
+        local_cpu = local
+    pinned = pin_rank(local_cpu, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if world > 1 else None      # before the render pool and before any GPU call
     if world != args.gpus:
         print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to report a number for a different GPU count", file=sys.stderr)
         sys.exit(2)
@@ -1459,7 +1468,10 @@ def main():
         saved_fd = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            if args.one_device:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -1497,7 +1509,8 @@ def main():
                 mine[i, 64:68] = (m.image_non_zeros, m.image_outliers, m.image_inliers, m.image_reprojection_distance)
         else:
             mine = shard.pack_results_raw(w.last["res"], seeds)                    # this rank's own records as they left the C-ABI
-        gather_info = {"backend": "nccl (RCCL), all_gather_into_tensor on device tensors" if use_dist else "none (one rank: the local records)",
+        gather_info = {"backend": ("gloo on device tensors (--one-device rehearsal)" if args.one_device else "nccl (RCCL), all_gather_into_tensor on device tensors") if use_dist
+                       else "none (one rank: the local records)",
                        "forced": bool(use_dist and world == 1), "world": n_seen, "records": int(allrec.shape[0]), "record_bytes": int(4 * allrec.shape[1]),
                        "records_equal_local": bool(np.array_equal(allrec[np.asarray(seeds)].view(np.uint32), mine.view(np.uint32)))}
         # determinism gate of the multi-GPU leg: a pair's record does not depend on which GPU aligned it, in which sub-batch or next to which
@@ -1631,6 +1644,8 @@ def main():
                        "pairs_per_gpu": P, "total_pairs": total, "rows": rows, "cols": cols, "sub_frames": args.sub_frames, "sub_pairs": args.sub_pairs,
                        "streams": args.streams, "omega_storage": args.omega_storage, "step_mode": args.step_mode if not partition else None,
                        "parallelism": parallelism,
+                       "rehearsal": (f"{n_seen} rank processes on ONE device, collectives through gloo: a correctness rehearsal of the multi-rank step, "
+                                     f"not a scaling measurement") if args.one_device else None,
                        "cpus_of_rank0": (len(pinned) if pinned else None)},
             "roofline": rep["roofline"],
             "cpu_baseline": cpu,

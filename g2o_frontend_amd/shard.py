@@ -61,6 +61,16 @@ def pack_results_raw(results: np.ndarray, pair_ids) -> np.ndarray:
     return out
 
 
+def all_gather_into(out: "torch.Tensor", local: "torch.Tensor"):
+    """dist.all_gather_into_tensor; with the gloo backend (CPU tests, the one-device rehearsal) the list form on views of `out`, which gloo
+    implements for host and device tensors alike"""
+    import torch.distributed as dist
+    if dist.get_backend() == "gloo":
+        dist.all_gather(list(out.view(dist.get_world_size(), *local.shape).unbind(0)), local.contiguous())
+    else:
+        dist.all_gather_into_tensor(out, local)
+
+
 def gather_records(local: "torch.Tensor", world: int, max_per_rank: int, force: bool = False):
     """All-gather of the per-rank record blocks (padded to max_per_rank rows); returns [world*max_per_rank, R].
     Rows whose pair id (column 19) is negative are padding."""
@@ -74,7 +84,7 @@ def gather_records(local: "torch.Tensor", world: int, max_per_rank: int, force: 
     if world == 1 and not force:
         return pad
     out = torch.empty((world * max_per_rank, local.shape[1]), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, pad)
+    all_gather_into(out, pad)
     return out
 
 
