@@ -204,7 +204,9 @@ class Context:
     """One per (GPU, host thread): owns the stream and the device workspaces
     (cf. pwn_cuda createContext, pwn_cuda/cudaaligner.h:59)."""
 
-    def __init__(self, device: int = 0, max_rows: int = 480, max_cols: int = 640, max_batch: int = 1, omega_storage: str = "exact9"):
+    DEFAULT_OMEGA_STORAGE = "sym6"            # what pwn_hip_ctx_create sets (include/pwn_hip.h; tests/test_omega_sym6.py holds the two together)
+
+    def __init__(self, device: int = 0, max_rows: int = 480, max_cols: int = 640, max_batch: int = 1, omega_storage: str = None):
         self._L = _lib.lib()
         h = C.c_void_p()
         rc = self._L.pwn_hip_ctx_create(C.byref(h), device, max_rows, max_cols, max_batch)
@@ -213,8 +215,8 @@ class Context:
         self.h = h
         self.device = int(device)
         self.max_rows, self.max_cols, self.max_batch = max_rows, max_cols, max_batch
-        self.omega_storage = "exact9"
-        if omega_storage != "exact9":
+        self.omega_storage = self.DEFAULT_OMEGA_STORAGE
+        if omega_storage is not None and omega_storage != self.omega_storage:
             self.set_omega_storage(omega_storage)
 
     def check(self, rc):

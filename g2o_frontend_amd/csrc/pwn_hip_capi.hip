@@ -89,7 +89,7 @@ struct pwn_hip_ctx {
   size_t N = 0;
   int sub_frames = 64, sub_pairs = 64;
   int concurrency = 4;
-  int omega_sym = 0;                       // pwn_hip_ctx_set_omega_storage: storage of the point information matrices of clouds created from now on
+  int omega_sym = 1;                       // pwn_hip_ctx_set_omega_storage: storage of the point information matrices of clouds created from now on (default: sym6)
   // convert workspaces (per slot)
   float* depth_ws = nullptr; int* index_ws = nullptr; int* interval_ws = nullptr; float* integral_ws = nullptr; int* rowoff_ws = nullptr;
   uint16_t* raw_ws = nullptr;

@@ -97,10 +97,13 @@ class Context {
   // batch calls: frames / pairs per kernel launch and the number of HIP streams the sub-batches are dealt over (include/pwn_hip.h)
   void setSubbatch(int frames, int pairs) { check(pwn_hip_ctx_set_subbatch(_ctx, frames, pairs)); }
   void setConcurrency(int streams) { check(pwn_hip_ctx_set_concurrency(_ctx, streams)); }
-  // PWN_HIP_OMEGA_EXACT9 (default) / PWN_HIP_OMEGA_SYM6: storage of the point information matrices of clouds created from now on
+  // PWN_HIP_OMEGA_SYM6 (default) / PWN_HIP_OMEGA_EXACT9 (every entry of Omega_p bit-identical to pwn_core's): storage of the point information matrices of clouds created from now on
   void setOmegaStorage(int mode) { check(pwn_hip_ctx_set_omega_storage(_ctx, mode)); }
   void synchronize() { check(pwn_hip_ctx_synchronize(_ctx)); }
   void waitStream(void* hipStream) { check(pwn_hip_ctx_wait_stream(_ctx, hipStream)); }      // what the context queues from now on runs after that stream's work
+  void signalStream(void* hipStream) { check(pwn_hip_ctx_signal_stream(_ctx, hipStream)); }  // what that stream gets from now on runs after everything the context has queued
+  // fn(user) runs inside every alignment batch call, after its device work is queued and before the call waits (include/pwn_hip.h); nullptr = off
+  void setEnqueuedCallback(void (*fn)(void*), void* user) { check(pwn_hip_ctx_set_enqueued_callback(_ctx, fn, user)); }
  private:
   pwn_hip_ctx* _ctx = nullptr;
 };
@@ -298,6 +301,18 @@ class DepthImageConverterIntegralImage : public DepthImageConverter {
     std::vector<pwn_hip_cloud*> h(clouds.size());
     for (size_t i = 0; i < h.size(); ++i) h[i] = clouds[i]->handle();
     _ctx->check(pwn_hip_convert_batch_u16(_ctx->handle(), &p, rawFrames.data(), depthScale, (int)h.size(), rows, cols, h.data()));
+  }
+  // the look-ahead of a sharded PwnCloser::processPartition (pwn_hip_convert_export_begin / _end): returns at once; the helper thread converts the raw
+  // frame into `cloud` and then writes the cloud's flat form into flatDst (may be nullptr); computeExportEnd waits and returns the bytes written
+  void computeExportBegin(Cloud& cloud, const uint16_t* rawFrame, float depthScale, int rows, int cols, void* flatDst, size_t flatBytes,
+                          const Isometry3f& sensorOffset = Isometry3f::Identity()) {
+    const pwn_hip_converter_params p = params(sensorOffset);
+    _ctx->check(pwn_hip_convert_export_begin(_ctx->handle(), &p, rawFrame, depthScale, rows, cols, cloud.handle(), flatDst, flatBytes));
+  }
+  size_t computeExportEnd(Cloud& cloud, float* jobMs = nullptr) {
+    size_t w = 0;
+    _ctx->check(pwn_hip_convert_export_end(_ctx->handle(), cloud.handle(), &w, jobMs));
+    return w;
   }
   void compute(Cloud& cloud, const DepthImage& depthImage, const Isometry3f& sensorOffset = Isometry3f::Identity()) override {
     if (depthImage.rows <= 0 || depthImage.cols <= 0) throw Error(PWN_HIP_ERR_INVALID_ARGUMENT, "DepthImageConverterIntegralImage: depthImage has zero size");

@@ -177,13 +177,15 @@ int pwn_hip_ctx_set_concurrency(pwn_hip_ctx* ctx, int streams);
 /* Storage of the point information matrices (InformationMatrix, informationmatrix.h:13; PointInformationMatrixCalculator::compute,
  * informationmatrixcalculator.cpp:9-36) of the clouds created on the context FROM NOW ON (existing clouds keep theirs;
  * pwn_hip_cloud_omega_storage tells).  The clouds of one convert batch and the current clouds of one align batch must share one.
- *   PWN_HIP_OMEGA_EXACT9 (default): all nine entries of U diag U^t as the reference evaluates them, 36 bytes per point; every
- *     converter output is bit-identical to the CPU path.
- *   PWN_HIP_OMEGA_SYM6: the upper triangle as the reference evaluates it, 24 bytes per point (the size SURVEY.md 8(d) counts);
- *     readers -- the Linearizer (linearizer.cpp:66-67,84-88), cloud_download, the scene stage -- mirror it.  The reference's nine
- *     entries are symmetric only up to the rounding of each entry's own products, so the lower triangle differs from it by
- *     <= 1 ulp of the entry's largest term: Omega_p within 1e-6 |Omega_p|, chi2 / H / b within 1e-5, everything else unchanged.
- *     12 of the 30 bytes the fused correspondence + linearize pass gathers per correspondence, and 12 of k_stats' 64 stored bytes. */
+ *   PWN_HIP_OMEGA_SYM6 (the default since round 6): the upper triangle as the reference evaluates it, 24 bytes per point (the size
+ *     SURVEY.md 8(d) counts); readers -- the Linearizer (linearizer.cpp:66-67,84-88), cloud_download, the scene stage -- mirror it.  The
+ *     reference's nine entries are symmetric only up to the rounding of each entry's own products, so the lower triangle differs from it by
+ *     <= 1 ulp of the entry's largest term: Omega_p within 1e-6 |Omega_p| (measured 1.7e-7), chi2 / H / b within 1e-5 (measured 6e-8 from the
+ *     same iterate), every other converter output bit-identical.  12 of the 30 bytes the fused correspondence + linearize pass gathers per
+ *     correspondence and 12 of k_stats' 64 stored bytes less: the 128-pair step runs 11-13 % faster than with exact9.
+ *   PWN_HIP_OMEGA_EXACT9: all nine entries of U diag U^t as the reference evaluates them, 36 bytes per point; EVERY converter output,
+ *     the lower triangle of Omega_p included, is bit-identical to the CPU path.  The mode to select when a caller compares clouds bit for
+ *     bit with pwn_core's (the parity tests do), at the cost above. */
 #define PWN_HIP_OMEGA_EXACT9 0
 #define PWN_HIP_OMEGA_SYM6 1
 int pwn_hip_ctx_set_omega_storage(pwn_hip_ctx* ctx, int mode);

@@ -47,7 +47,7 @@ def rigs():
     def get(name):
         if name not in made:
             rows, cols, _, _, _ = case_params(name)
-            ctx = api.Context(0, rows, cols, 4)
+            ctx = api.Context(0, rows, cols, 4, omega_storage="exact9")
             _, converter, aligner = gpu_objects(ctx, name)
             made[name] = (ctx, converter, aligner)
         return made[name]

@@ -35,7 +35,7 @@ POSE_RTOL = 1e-5        # rotation-matrix entries (~rad)
 @pytest.fixture(scope="module")
 def ctx():
     from g2o_frontend_amd import api
-    c = api.Context(device=0, max_rows=480, max_cols=640, max_batch=4)
+    c = api.Context(device=0, max_rows=480, max_cols=640, max_batch=4, omega_storage="exact9")
     yield c
     c.close()
 
@@ -455,7 +455,7 @@ def test_full_pipeline_1280x960(oracle):
     cp, ap = oracle_params(oracle, name, accumulate_fp64=1)
     oref, oidx, _ = oracle.convert(cp, ref); ocur, _, _ = oracle.convert(cp, cur)
     o = oracle.align(ap, oref, ocur)
-    big = api.Context(0, rows, cols, 2)
+    big = api.Context(0, rows, cols, 2, omega_storage="exact9")
     _, converter, aligner = gpu_objects(big, name)
     gref, gcur = api.Cloud(big, rows * cols), api.Cloud(big, rows * cols)
     converter.compute(gref, ref)
@@ -619,7 +619,7 @@ def test_odd_image_sizes(oracle, rows, cols):
     K = synth.scaled_K(synth.K_VGA, scale)
     K = (K[0], K[1], (cols - 1) / 2.0, (rows - 1) / 2.0)
     conv, alig = dict(oracle.QVGA4_CONF_CONVERTER), dict(oracle.QVGA4_CONF_ALIGNER)
-    ctx = api.Context(0, rows, cols, 32)
+    ctx = api.Context(0, rows, cols, 32, omega_storage="exact9")
     try:
         proj, converter, aligner = gpu_objects(ctx, "small")
         for p in (proj, aligner.projector()):
@@ -671,7 +671,7 @@ def test_aligner_finder_images_bit_exact_and_collisions(oracle, shrink):
     from g2o_frontend_amd import api, synth
     rows, cols, K, conv, alig = case_params("vga")
     ref, cur, _, _, _ = make_depth_pair("vga", 3)
-    ctx = api.Context(0, rows, cols, 16)
+    ctx = api.Context(0, rows, cols, 16, omega_storage="exact9")
     try:
         _, converter, aligner = gpu_objects(ctx, "vga")
         gref, gcur = api.Cloud(ctx, rows * cols), api.Cloud(ctx, rows * cols)
@@ -776,7 +776,7 @@ def test_gpu_converter_against_float64_brute_force():
     rows, cols, K, conv, _ = case_params(name)
     depth_mm = synth.render_depth_mm(21, np.eye(4), rows, cols, K)
     depth = depth_mm.astype(np.float32) * np.float32(0.001); depth[depth_mm == 0] = 0
-    c = api.Context(0, rows, cols, 2)
+    c = api.Context(0, rows, cols, 2, omega_storage="exact9")
     _, converter, _ = gpu_objects(c, name)
     g = api.Cloud(c, rows * cols)
     converter.compute(g, depth, keep_stats=True)
@@ -857,7 +857,7 @@ def test_gpu_projector_against_a_numpy_zbuffer():
     from g2o_frontend_amd import api, synth
     name = "small"
     rows, cols, K, conv, _ = case_params(name)
-    c = api.Context(0, rows, cols, 2)
+    c = api.Context(0, rows, cols, 2, omega_storage="exact9")
     proj, converter, _ = gpu_objects(c, name)
     depth_mm = synth.render_depth_mm(23, np.eye(4), rows, cols, K)
     g = api.Cloud(c, rows * cols)
@@ -904,7 +904,7 @@ def test_gpu_correspondence_finder_against_numpy():
     from g2o_frontend_amd import api, synth
     name = "small"
     rows, cols, K, conv, alig = case_params(name)
-    c = api.Context(0, rows, cols, 2)
+    c = api.Context(0, rows, cols, 2, omega_storage="exact9")
     proj, converter, aligner = gpu_objects(c, name)
     ref_mm, cur_mm, _ = synth.make_pair(31, rows, cols, K)
     gr, gc = api.Cloud(c, rows * cols), api.Cloud(c, rows * cols)
@@ -948,7 +948,7 @@ def test_gpu_unproject_and_integral_image_against_numpy_fp32():
     from g2o_frontend_amd import api, synth
     name = "vga"
     rows, cols, K, conv, _ = case_params(name)
-    c = api.Context(0, rows, cols, 2)
+    c = api.Context(0, rows, cols, 2, omega_storage="exact9")
     proj, _, _ = gpu_objects(c, name)
     depth = c.DepthImage_convert_16UC1_to_32FC1(synth.render_depth_mm(33, np.eye(4), rows, cols, K))
     cloud = api.Cloud(c, rows * cols)
@@ -987,7 +987,7 @@ def test_gpu_stats_against_numpy_fp32_sums_and_lapack():
     from g2o_frontend_amd import api, synth
     name = "small"
     rows, cols, K, conv, _ = case_params(name)
-    c = api.Context(0, rows, cols, 2)
+    c = api.Context(0, rows, cols, 2, omega_storage="exact9")
     proj, converter, _ = gpu_objects(c, name)
     depth = c.DepthImage_convert_16UC1_to_32FC1(synth.render_depth_mm(35, np.eye(4), rows, cols, K))
     g = api.Cloud(c, rows * cols)
@@ -1072,7 +1072,7 @@ def test_gpu_alignment_against_the_numpy_model(name, seed):
     from g2o_frontend_amd import api, synth
     import numpy_reference_model as M
     rows, cols, K, conv, alig = case_params(name)
-    c = api.Context(0, rows, cols, 2)
+    c = api.Context(0, rows, cols, 2, omega_storage="exact9")
     proj, converter, aligner = gpu_objects(c, name)
     ref_mm, cur_mm, Ttrue = synth.make_pair(seed, rows, cols, K)
     gr, gc = api.Cloud(c, rows * cols), api.Cloud(c, rows * cols)
@@ -1124,7 +1124,7 @@ def test_gpu_depth_helpers_and_match_score_against_the_numpy_model():
     import numpy_reference_model as M
     name = "small"
     rows, cols, K, conv, alig = case_params(name)
-    big = api.Context(0, 480, 640, 2)
+    big = api.Context(0, 480, 640, 2, omega_storage="exact9")
     raw = synth.render_depth_mm(43, np.eye(4), 480, 640, synth.K_VGA)
     d = big.DepthImage_convert_16UC1_to_32FC1(raw)
     assert np.array_equal(d.view(np.uint32), M.depth_16u_to_32f(raw).view(np.uint32))
@@ -1133,7 +1133,7 @@ def test_gpu_depth_helpers_and_match_score_against_the_numpy_model():
     for step in (2, 3, 4):
         assert np.array_equal(big.DepthImage_scale(d, step).view(np.uint32), M.depth_scale(d, step).view(np.uint32)), step
     big.close()
-    c = api.Context(0, rows, cols, 2)
+    c = api.Context(0, rows, cols, 2, omega_storage="exact9")
     _, converter, aligner = gpu_objects(c, name)
     ref_mm, cur_mm, _ = synth.make_pair(45, rows, cols, K)
     gr, gc = api.Cloud(c, rows * cols), api.Cloud(c, rows * cols)
@@ -1161,7 +1161,7 @@ def test_gpu_whole_converter_against_the_numpy_model(name):
     from test_oracle_vs_numpy_model import _frames, _nz
     rows, cols, K, conv, alig, ref_mm, cur_mm = _frames(name)
     case = "vga" if name == "kinect" else name
-    c = api.Context(0, rows, cols, 32)
+    c = api.Context(0, rows, cols, 32, omega_storage="exact9")
     _, converter, _ = gpu_objects(c, case)
     want = [M.convert(M.depth_16u_to_32f(f), K, conv) for f in (ref_mm, cur_mm)]
     g = api.Cloud(c, rows * cols)
@@ -1188,7 +1188,7 @@ def test_gpu_alignment_with_priors_against_the_numpy_model(kind):
     import numpy_reference_model as M
     name = "small"
     rows, cols, K, conv, alig = case_params(name)
-    c = api.Context(0, rows, cols, 2)
+    c = api.Context(0, rows, cols, 2, omega_storage="exact9")
     proj, converter, aligner = gpu_objects(c, name)
     ref_mm, cur_mm, Ttrue = synth.make_pair(41, rows, cols, K)
     gr, gc = api.Cloud(c, rows * cols), api.Cloud(c, rows * cols)

@@ -37,7 +37,7 @@ pytest_gpu = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def ctx():
     from g2o_frontend_amd import api
-    c = api.Context(device=0, max_rows=480, max_cols=640, max_batch=4)
+    c = api.Context(device=0, max_rows=480, max_cols=640, max_batch=4, omega_storage="exact9")
     yield c
     c.close()
 

@@ -193,6 +193,11 @@ def test_mixed_storage_is_rejected_and_exact9_is_untouched(oracle):
     name = "small"
     rows, cols, _, _, _ = case_params(name)
     ctx = api.Context(0, rows, cols, 4)
+    # the library's default (pwn_hip_ctx_create) is sym6, and the Python mirror knows it
+    d = api.Cloud(ctx, rows * cols)
+    assert d.omega_storage() == "sym6" == api.Context.DEFAULT_OMEGA_STORAGE == ctx.omega_storage
+    del d
+    ctx.set_omega_storage("exact9")
     _, converter, aligner = gpu_objects(ctx, name)
     depth, cur, _, _, _ = make_depth_pair(name, 1)
     a = api.Cloud(ctx, rows * cols)

@@ -169,7 +169,7 @@ def _same_cloud(o, g, gauss=True, stats=True):
 @pytest.fixture(scope="module")
 def gctx():
     from g2o_frontend_amd import api
-    c = api.Context(device=0, max_rows=480, max_cols=640, max_batch=2)
+    c = api.Context(device=0, max_rows=480, max_cols=640, max_batch=2, omega_storage="exact9")
     yield c
     c.close()
 
@@ -393,7 +393,7 @@ def test_scene_above_two_million_points_1280x960(oracle):
         oclouds = [oracle.convert(cp, d)[0] for d in depths]
     finally:
         oracle.set_gaussians(False)
-    ctx = api.Context(0, rows, cols, 2)
+    ctx = api.Context(0, rows, cols, 2, omega_storage="exact9")
     proj, converter, aligner = gpu_objects(ctx, name)
     gclouds = []
     for d in depths:
