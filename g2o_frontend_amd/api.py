@@ -965,6 +965,9 @@ class Aligner:
         self._T, self._error, self._inliers = self._result["T"], r.error, r.inliers
         self._totalTime = r.total_time_ms
         self._linearizer._error, self._linearizer._inliers = r.error, r.inliers
+        # Aligner::align hands the linearizer the inverse transform of every iteration and, in _computeStatistics, of the result
+        # (aligner.cpp:90,165-167): after align(), linearizer()->T() is the final T^-1 with its last row forced
+        self._linearizer.setT(iso_inverse(self._T))
         if images:
             f = self._correspondenceFinder
             ri = np.empty((p.rows, p.cols), np.int32); ci = np.empty((p.rows, p.cols), np.int32)

@@ -60,13 +60,13 @@ def build_tools(force: bool = False) -> str:
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-I", root, src4, "-o", out4, "-L", _HERE, "-lpwn_hip",
                                "-Wl,-rpath,$ORIGIN/../g2o_frontend_amd"])
     # PwnCloser::processPartition over the GPUs of a node in native code: the mirror + RCCL (broadcast of the flat `current` cloud, all-gather of the
-    # match records); rccl.h pulls in the HIP API headers (declarations only: the program calls no HIP function itself)
+    # match records); the program's own streams and events come from the HIP runtime
     src5 = os.path.join(root, "tools", "pwn_hip_partition_app.cpp")
     out5 = os.path.join(root, "tools", "pwn_hip_partition_app")
     deps5 = [src5] + deps[1:]
     if os.path.exists("/opt/rocm/include/rccl/rccl.h") and (force or (not os.path.exists(out5)) or any(os.path.getmtime(d) > os.path.getmtime(out5) for d in deps5)):
         subprocess.check_call(["g++", "-O2", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-I", root, "-I", "/opt/rocm/include", src5, "-o", out5, "-L", _HERE, "-lpwn_hip",
-                               "-L", "/opt/rocm/lib", "-lrccl", "-Wl,-rpath,$ORIGIN/../g2o_frontend_amd", "-Wl,-rpath,/opt/rocm/lib"])
+                               "-L", "/opt/rocm/lib", "-lrccl", "-lamdhip64", "-Wl,-rpath,$ORIGIN/../g2o_frontend_amd", "-Wl,-rpath,/opt/rocm/lib"])
     return out
 
 

@@ -490,6 +490,7 @@ class Aligner {
     }
     _T = Isometry3f(_result.T); _error = _result.error; _inliers = _result.inliers; _totalTime = _result.total_time_ms;
     _linearizer->_error = _error; _linearizer->_inliers = _inliers;
+    _linearizer->setT(_T.inverse());      // what the reference leaves there: _linearizer->setT(_T.inverse()) in _computeStatistics (aligner.cpp:165-167)
     _correspondenceFinder->_numCorrespondences = _result.iterations > 0 ? _result.iter_correspondences[_result.iterations - 1] : 0;
     if (fetchImages) {
       CorrespondenceFinder& f = *_correspondenceFinder;

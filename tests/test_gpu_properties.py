@@ -6,7 +6,7 @@ import hashlib
 import numpy as np
 import pytest
 
-from conftest import case_params
+from conftest import case_params, make_depth_pair
 
 pytestmark = pytest.mark.gpu
 
@@ -330,3 +330,25 @@ def test_single_point_projector_forms_are_the_kernels_expressions():
             won += 1
     assert won > 250
     ctx.close()
+
+
+def test_linearizer_T_after_align_is_the_inverse_of_the_result():
+    """Aligner::align leaves the linearizer with the inverse of the final transform (aligner.cpp:90 per iteration, :165-167 in _computeStatistics):
+    code ported from the reference that reads linearizer()->T() after align gets that, not the identity it was constructed with."""
+    from g2o_frontend_amd import api
+    from test_gpu_parity import gpu_objects
+    rows, cols, K, conv, alig = case_params("small")
+    ref, cur, _, _, _ = make_depth_pair("small", 2)
+    ctx = api.Context(0, rows, cols, 2)
+    try:
+        _, converter, aligner = gpu_objects(ctx, "small")
+        a, b = api.Cloud(ctx, rows * cols), api.Cloud(ctx, rows * cols)
+        converter.compute(a, ref); converter.compute(b, cur)
+        assert np.array_equal(aligner.linearizer().T(), np.eye(4, dtype=np.float32))
+        aligner.setReferenceCloud(a); aligner.setCurrentCloud(b)
+        g = aligner.align()
+        want = api.iso_inverse(g["T"]); want[3] = (0, 0, 0, 1)
+        assert np.array_equal(aligner.linearizer().T().view(np.uint32), want.view(np.uint32))
+        assert not np.array_equal(want, np.eye(4, dtype=np.float32))
+    finally:
+        ctx.close()

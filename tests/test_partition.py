@@ -265,7 +265,8 @@ def test_bench_partition_mode_original_and_replica_give_the_same_records(tmp_pat
     assert set(m["per_rank_stage_ms_per_step"]) >= {"corr_linearize", "project_ref", "solve", "match_score"}
 
 
-def test_native_rccl_partition_app_matches_the_python_mirror(tmp_path):
+@pytest.mark.parametrize("mode", ["pipelined", "serial"])
+def test_native_rccl_partition_app_matches_the_python_mirror(tmp_path, mode):
     """tools/pwn_hip_partition_app.cpp -- the processPartition flow of INTEGRATION.md in native code: C++ mirror over the C-ABI, RCCL for the broadcast
     of the flat `current` cloud and the all-gather of the 288-byte records (world size 1 here: one GPU; the ranks of a larger run are forked before
     any GPU call and meet through an ncclUniqueId passed over pipes).  Its printed records must equal, digit for digit, what the Python mirror's
@@ -291,11 +292,14 @@ def test_native_rccl_partition_app_matches_the_python_mirror(tmp_path):
     guesses = [np.asarray(g, np.float64).astype(np.float32) for g in bench.partition_guesses(ids)]
     (tmp_path / "guesses.txt").write_text("\n".join(" ".join("%.9g" % v for v in g.T.reshape(-1)) for g in guesses) + "\n")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([exe, str(tmp_path / "frames.txt"), "1", "2", str(tmp_path / "guesses.txt")], capture_output=True, text=True, timeout=300, env=env)
+    out = subprocess.run([exe, str(tmp_path / "frames.txt"), "1", "3", str(tmp_path / "guesses.txt")] + (["serial"] if mode == "serial" else []),
+                         capture_output=True, text=True, timeout=300, env=env)
     assert out.returncode == 0, (out.stdout[-500:], out.stderr[-1500:])
     lines = [l.split() for l in out.stdout.splitlines()]
     head = [l for l in lines if l and l[0] == "keyframes"][0]
-    assert (int(head[1]), int(head[3])) == (n, 1) and float(head[7]) > 0 and int(head[9]) > 10e6
+    assert (int(head[1]), int(head[3])) == (n, 1) and float(head[7]) > 0 and int(head[9]) > 10e6 and head[13] == mode
+    # pipelined: only the bytes written travel; serial: the buffer's bound
+    assert (int(head[11]) == int(head[9])) if mode == "pipelined" else (int(head[11]) >= int(head[9]))
     recs = [l for l in lines if l and l[0] == "keyframe"]
     assert len(recs) == n
     # the same flow with the Python mirror: sym6 clouds, scale 1, bench.py's VGA tables
@@ -457,3 +461,37 @@ def test_flat_cloud_at_1280x960():
     for k in ("T", "chi2", "C", "K", "iter_inliers"):
         assert np.array_equal(_bits(g[k]), _bits(base[k])), k
     flat.free(); ctx2.close(); ctx.close()
+
+
+def test_native_partition_app_does_not_hang_when_a_rank_fails(tmp_path):
+    """ranks = 2 on a box with ONE GPU: rank 1 finds no device of its own and exits before the communicator exists, rank 0 waits for it in
+    ncclCommInitRank.  The parent reaps the failed rank and terminates the other instead of waiting for ever (advisor finding, round 5); the
+    run ends with the failed rank's code within seconds.  Same for a keyframe file only rank 1 reads that does not exist."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    from g2o_frontend_amd import api, build, synth
+    build.build_tools()
+    exe = os.path.join(ROOT, "tools", "pwn_hip_partition_app")
+    if not os.path.exists(exe):
+        pytest.skip("no RCCL headers: the app was not built")
+    if api.device_count() != 1:
+        pytest.skip("needs a box with exactly one GPU")
+    rows, cols, K = 120, 160, synth.scaled_K(synth.K_VGA, 4)
+    f = synth.render_depth_mm(bench.PARTITION_SCENE, np.eye(4), rows, cols, K, hole_stream=0)
+    names = []
+    for k in range(3):
+        fn = tmp_path / f"f{k}.pgm"
+        with open(fn, "wb") as fh:
+            fh.write(b"P5\n%d %d\n65535\n" % (cols, rows)); fh.write(f.astype(">u2").tobytes())
+        names.append(str(fn))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PWN_PARTITION_TIMEOUT_S="60")
+    (tmp_path / "frames.txt").write_text("\n".join(names) + "\n")
+    t0 = time.time()
+    out = subprocess.run([exe, str(tmp_path / "frames.txt"), "2", "1"], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 1 and time.time() - t0 < 45, (out.returncode, out.stderr[-800:])
+    assert "one GPU per rank" in out.stderr
+    (tmp_path / "frames2.txt").write_text("\n".join(names[:2] + [str(tmp_path / "missing.pgm")]) + "\n")
+    t0 = time.time()
+    out = subprocess.run([exe, str(tmp_path / "frames2.txt"), "2", "1"], capture_output=True, text=True, timeout=120, env=env)
+    assert out.returncode == 1 and time.time() - t0 < 45 and "cannot read" in out.stderr, (out.returncode, out.stderr[-800:])

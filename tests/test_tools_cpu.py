@@ -5,6 +5,8 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -61,3 +63,30 @@ def test_bench_line_of_the_round_is_committed_and_self_consistent():
     assert p["config"]["mode"] == "partition" and p["gather"]["record_bytes"] == 288 and p["gather"]["records_vs_single_gpu_run"]["equal"]
     assert p["gather"]["records_vs_single_gpu_run"]["file"].endswith("records_crc_partition_sym6.json") and p["partition"]["accepted_by_closer_thresholds_rank0"] > 100
     assert p["roofline"]["projections_per_pair"] == 10.0 and abs(p["value"] - p["config"]["pairs_per_gpu"] / p["ms_per_step"] * 1e3) < 1e-6 * p["value"]
+
+
+def test_partition_app_reaps_failed_ranks_instead_of_hanging(tmp_path):
+    """tools/pwn_hip_partition_app with two ranks where no rank can start (no GPU here; on a GPU box: tests/test_partition.py runs the case where only
+    ONE rank fails and the other already waits in ncclCommInitRank): the parent returns the ranks' error within seconds.  Also: usage errors."""
+    import subprocess
+    import time
+    import numpy as np
+    from g2o_frontend_amd import _lib, build
+    build.build_tools()
+    exe = os.path.join(ROOT, "tools", "pwn_hip_partition_app")
+    if not os.path.exists(exe):
+        pytest.skip("no RCCL headers: the app was not built")
+    if _lib.lib().pwn_hip_device_count() > 0:
+        pytest.skip("a GPU is present: covered by tests/test_partition.py")
+    names = []
+    for k in range(3):
+        fn = tmp_path / f"f{k}.pgm"
+        with open(fn, "wb") as fh:
+            fh.write(b"P5\n8 6\n65535\n"); fh.write(np.full((6, 8), 1000, ">u2").tobytes())
+        names.append(str(fn))
+    (tmp_path / "frames.txt").write_text("\n".join(names) + "\n")
+    t0 = time.time()
+    out = subprocess.run([exe, str(tmp_path / "frames.txt"), "2", "1"], capture_output=True, text=True, timeout=60, env=dict(os.environ, PWN_PARTITION_TIMEOUT_S="30"))
+    assert out.returncode == 1 and time.time() - t0 < 20 and "one GPU per rank" in out.stderr, (out.returncode, out.stderr[-500:])
+    out = subprocess.run([exe, str(tmp_path / "frames.txt"), "3", "1"], capture_output=True, text=True, timeout=60)      # more ranks than keyframes
+    assert out.returncode == 1 and "at least one keyframe per rank" in out.stderr
