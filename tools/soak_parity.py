@@ -1,7 +1,13 @@
 #!/usr/bin/env python3
 """Parity soak: many seeded pairs, random sensor offsets and converter settings -- converter arrays bit for bit, first-iteration
 counters exactly, chi2 from the same iterate to 1e-5, free-running pose; scene add + merge bit for bit.  Prints a summary line per case
-and a final JSON; exits non-zero on the first mismatch.  (The committed tests cover fixed seeds; this is the wide net.)"""
+and a final JSON; exits non-zero on the first mismatch.  (The committed tests cover fixed seeds; this is the wide net.)
+
+Round 6: per case also the DECISIONS the reference's callers take from a free-running alignment, on both sides -- PwnCloser::matchFrames' acceptance
+(pwn_tracker/pwn_closer.cpp:138-141: image_nonZeros < 3000 || image_outliers > 100 || image_inliers < 1000 -> rejected, on the matchClouds score of the
+finder's depth images, pwn_matcher_base.cpp:153-182) and PwnTracker::processFrame's two (pwn_tracker.cpp:146-151 transform found = inliers > 0;
+:162-164 new key frame = inliers / (rows * cols) < 0.4).  Free-running poses differ in their last digits (summation order); what a caller does with
+them should not.  A flip is reported with the numbers on both sides, not asserted."""
 import argparse
 import json
 import os
@@ -39,7 +45,11 @@ def main():
     if sym:
         from test_omega_sym6 import compare_clouds_sym6
     rng = np.random.default_rng(2024 + args.seed0 - 1000)
-    stats = dict(cases=0, worst_chi2_rel=0.0, worst_pose=0.0, points=0, merged=0)
+    stats = dict(cases=0, worst_chi2_rel=0.0, worst_pose=0.0, points=0, merged=0, decisions=0, closer_accepted=0, tracker_new_keyframe=0, worst_score_diff=0,
+                 worst_inliers_diff=0)
+    flips = []
+    import ctypes as C
+    from g2o_frontend_amd._lib import MatchResult
     for name, count in (("small", args.small), ("vga", args.vga)):
         rows, cols, K, conv0, alig = case_params(name)
         kept = []          # (aligner params key, gref, gcur, single result) of the default-configuration cases: re-run as one batch below
@@ -78,9 +88,24 @@ def main():
                 og, gg = o.gaussians(), g.gaussians()
                 assert np.array_equal(bits(og["cov"]), bits(gg["cov"])) and np.array_equal(bits(og["mean"]), bits(gg["mean"])), (name, seed, "gaussians")
             apar = O.aligner_params(rows, cols, K=K, accumulate_fp64=1, reference_sensor_offset=offset, current_sensor_offset=offset, **alig)
-            o = O.align(apar, oref, ocur)
+            o = O.align(apar, oref, ocur, images=True)
             aligner.setReferenceCloud(gref); aligner.setCurrentCloud(gcur)
             g = aligner.align()
+            # the callers' decisions, both sides
+            gm = MatchResult()
+            ctx.check(ctx._L.pwn_hip_match_score(ctx.h, 50.0, C.byref(gm)))
+            om = O.match_score(o["ref_depth"], o["cur_depth"], 50.0)
+            dec_o = (not (om["image_nonZeros"] < 3000 or om["image_outliers"] > 100 or om["image_inliers"] < 1000), o["inliers"] > 0, o["inliers"] / float(rows * cols) < 0.4)
+            dec_g = (not (gm.image_non_zeros < 3000 or gm.image_outliers > 100 or gm.image_inliers < 1000), g["inliers"] > 0, g["inliers"] / float(rows * cols) < 0.4)
+            stats["decisions"] += 3
+            stats["closer_accepted"] += int(dec_o[0]); stats["tracker_new_keyframe"] += int(dec_o[2])
+            stats["worst_score_diff"] = max(stats["worst_score_diff"], abs(om["image_nonZeros"] - gm.image_non_zeros), abs(om["image_outliers"] - gm.image_outliers),
+                                            abs(om["image_inliers"] - gm.image_inliers))
+            stats["worst_inliers_diff"] = max(stats["worst_inliers_diff"], abs(int(o["inliers"]) - int(g["inliers"])))
+            if dec_o != dec_g:
+                flips.append(dict(case=name, seed=seed, oracle=dict(score=om, inliers=int(o["inliers"]), decisions=dec_o),
+                                  gpu=dict(score=dict(image_nonZeros=gm.image_non_zeros, image_outliers=gm.image_outliers, image_inliers=gm.image_inliers),
+                                           inliers=int(g["inliers"]), decisions=dec_g)))
             it0 = o["iterations"][0]
             assert (int(g["K"][0]), int(g["C"][0]), int(g["iter_inliers"][0])) == (it0["K"], it0["C"], it0["inliers"]), (name, seed, "counters")
             if offset is None and conv == conv0 and len(kept) < 16:
@@ -106,7 +131,10 @@ def main():
                 assert np.array_equal(bits(oa[k]), bits(ga[k])), (name, seed, "scene", k)
             stats["cases"] += 1; stats["worst_chi2_rel"] = max(stats["worst_chi2_rel"], rel); stats["worst_pose"] = max(stats["worst_pose"], pose)
             stats["points"] += len(oref) + len(ocur); stats["merged"] += int(((ocol >= 0) & (ocol != np.arange(len(ocol)))).sum())
-            print(f"{name} seed {seed}: M {len(oref)}/{len(ocur)} offset {offset is not None} noise {noisy} chi2 rel {rel:.1e} pose {pose:.1e} merged {ok}", flush=True)
+            print(f"{name} seed {seed}: M {len(oref)}/{len(ocur)} offset {offset is not None} noise {noisy} chi2 rel {rel:.1e} pose {pose:.1e} merged {ok} | closer "
+                  f"{'accept' if dec_o[0] else 'reject'}/{'accept' if dec_g[0] else 'reject'} (nz {om['image_nonZeros']}/{gm.image_non_zeros} out {om['image_outliers']}/{gm.image_outliers} "
+                  f"inl {om['image_inliers']}/{gm.image_inliers}) tracker found {int(dec_o[1])}/{int(dec_g[1])} newkey {int(dec_o[2])}/{int(dec_g[2])} (inliers {o['inliers']}/{g['inliers']})"
+                  f"{'  <-- DECISION FLIP' if dec_o != dec_g else ''}", flush=True)
         # the batch path (own index images instead of two of the eleven projections, two streams) against the single alignments: bitwise
         if len(kept) > 1:
             _, _, aligner = gpu_objects(ctx, name)
@@ -121,6 +149,9 @@ def main():
             print(f"{name}: batch of {len(kept)} pairs bitwise equal to the single alignments", flush=True)
         del kept
     stats["omega_storage"] = args.omega_storage
+    stats["decision_flips"] = len(flips)
+    for f in flips:
+        print("DECISION FLIP", json.dumps(f, default=lambda x: bool(x) if isinstance(x, (np.bool_,)) else float(x)))
     print(json.dumps(stats))
     ctx.close()
 
