@@ -80,6 +80,9 @@ def parse(argv=None):
                          "converts and caches its shard of --pairs keyframes per GPU once (untimed); a step = rank 0 converts `current`, its cloud is replicated "
                          "to every GPU by one broadcast (RCCL), every rank runs matchClouds (align from an odometry guess + depth-agreement score) of `current` "
                          "against its shard, 288-byte records all-gathered")
+    ap.add_argument("--gather-after-call", action="store_true",
+                    help="pairs mode, N > 1: queue the records' all-gather after the step's library call has returned (rounds 1-5) instead of from inside it "
+                         "(pwn_hip_ctx_set_enqueued_callback); for the A/B")
     ap.add_argument("--one-device", action="store_true",
                     help="rehearsal of N > 1 on ONE GPU: every rank is a process of its own on device 0 and the collectives go through gloo (RCCL refuses two "
                          "ranks on one device).  Same steps, same ordering calls (pwn_hip_ctx_wait_stream / _signal_stream), the ranks contend for the device; "
@@ -370,7 +373,12 @@ class BatchWorkload:
         self.cur_dev = [torch.from_numpy(f[1].view(np.int16)).cuda() for f in frames_mm]
         self.refs = [api.Cloud(self.ctx, self.N) for _ in range(P)]
         self.curs = [api.Cloud(self.ctx, self.N) for _ in range(P)]
-        self.records = torch.empty((P, shard.RECORD_FLOATS), dtype=torch.float32, device="cuda")
+        dev = torch.device("cuda", device)
+        # two record buffers: step k+1 packs into one while step k's all-gather may still read the other
+        self.records2 = [torch.empty((P, shard.RECORD_FLOATS), dtype=torch.float32, device=dev) for _ in range(2)]
+        self.records = self.records2[0]
+        self.k = 0
+        self.gstream = [torch.cuda.Stream(device=dev) for _ in range(2)] if use_dist else None
         self.ids = np.asarray(self.seeds, np.int32)                                  # global pair ids: word 19 of the records
         self.conv_prep = self.converter.batchHandles(self.refs + self.curs, self.ref_dev + self.cur_dev)
         self.align_prep = ((C.c_void_p * P)(*[c.h for c in self.refs]), (C.c_void_p * P)(*[c.h for c in self.curs]), P)
@@ -378,17 +386,41 @@ class BatchWorkload:
         self.fused = getattr(args, "step_mode", "fused") == "fused"
         self.stage_ms = {k: 0.0 for k in STAGES}; self.stage_n = {k: 0 for k in STAGES}
         self.last = {}
+        self.gathered = None
+        self._in_step = False
+        self.inside = use_dist and not getattr(args, "gather_after_call", False)
+        self.cb_s = 0.0; self.call_s = 0.0
+        if self.inside:
+            self.ctx.set_enqueued_callback(self._queue_gather)
+
+    def _queue_gather(self):
+        """inside the step's (last) library call, after its device work is queued and before it waits (pwn_hip_ctx_set_enqueued_callback): the
+        all-gather of this step's records is queued behind the call's own stream (pwn_hip_ctx_signal_stream), so that neither its enqueue nor its
+        latency sits between two steps"""
+        import torch
+        from g2o_frontend_amd import shard
+        if not self._in_step:              # another call on this context (the extra lines of a forced one-rank run): not a step, nothing to gather
+            return
+        t0 = time.perf_counter()
+        gs = self.gstream[self.k % 2]
+        with torch.cuda.stream(gs):
+            self.ctx.signal_stream(gs)
+            self.gathered = shard.gather_records(self.records2[self.k % 2], self.world, self.Pmax, force=True)      # the only collective of the path
+        self.cb_s += time.perf_counter() - t0
 
     def step(self, profile=False):
         """one pass of the hot path over the rank's pairs; the 256-byte result records are written by a kernel straight into the device tensor the
         all-gather sends (no trip through the host), the caller's own copy of the results comes back beside them"""
         from g2o_frontend_amd import shard
+        rec = self.records2[self.k % 2]
+        self._in_step = True
         if self.use_dist:
-            # k_pack_records writes self.records on the library's own stream; the all-gather of the previous step read it on torch's: the
-            # context's work of this step is ordered after what torch's current stream holds (pwn_hip_ctx_wait_stream)
-            self.ctx.wait_stream()
+            # k_pack_records writes this buffer on the library's own stream; the all-gather of step k-2 read it on gstream[k % 2]: the context's
+            # work of this step is ordered after what that stream holds (pwn_hip_ctx_wait_stream)
+            self.ctx.wait_stream(self.gstream[self.k % 2])
+        tcall = time.perf_counter()
         if self.fused:
-            res = self.aligner.convertAlignBatch(self.converter, None, None, None, None, raw_scale=0.001, records=self.records, pair_ids=self.ids,
+            res = self.aligner.convertAlignBatch(self.converter, None, None, None, None, raw_scale=0.001, records=rec, pair_ids=self.ids,
                                                  prepared=self.step_prep)
             if profile:
                 for k in STAGES:
@@ -398,11 +430,22 @@ class BatchWorkload:
             if profile:
                 for k in STAGES[:6]:
                     ms, n = self.ctx.stage_ms(k); self.stage_ms[k] += ms; self.stage_n[k] += n
-            res = self.aligner.alignBatchRecords(None, None, self.records, pair_ids=self.ids, prepared=self.align_prep)
+            res = self.aligner.alignBatchRecords(None, None, rec, pair_ids=self.ids, prepared=self.align_prep)
             if profile:
                 for k in STAGES[6:]:
                     ms, n = self.ctx.stage_ms(k); self.stage_ms[k] += ms; self.stage_n[k] += n
-        self.last["gathered"] = shard.gather_records(self.records, self.world, self.Pmax, force=self.use_dist)      # the only collective of the path
+        self.call_s += time.perf_counter() - tcall
+        if self.inside:
+            self.ctx.take_callback_error()
+            self.last["gathered"] = self.gathered                                      # queued from inside the call (_queue_gather)
+        elif self.use_dist:
+            import torch
+            with torch.cuda.stream(self.gstream[self.k % 2]):                          # after the call has returned: its records are complete
+                self.last["gathered"] = shard.gather_records(rec, self.world, self.Pmax, force=True)
+        else:
+            self.last["gathered"] = shard.gather_records(rec, self.world, self.Pmax, force=False)
+        self.k += 1
+        self._in_step = False
         self.last["res"] = res
 
     def barrier(self):
@@ -542,6 +585,7 @@ class BatchWorkload:
                                    "C_sum": float(b["Cs"].mean()), "chi2_final": float(res["error"].mean()), "inliers_final": float(res["inliers"].mean())})
 
     def close(self):
+        self.ctx.set_enqueued_callback(None)
         self.refs = self.curs = None
         self.ctx.close()
 
@@ -1409,6 +1453,13 @@ def main():
         sys.exit(2)
     if args.dry_run_cpu:
         return dry_run_cpu(args, rank, world)
+    if world > 1 or os.environ.get("PWN_BENCH_FORCE_DIST") == "1":
+        # A rank of a multi-GPU run has more streams than the library's four: the collectives' stream, the side streams the broadcast, the all-gather and
+        # the import are ordered on, the look-ahead helper's.  The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues
+        # (default 4), and two of the library's compute streams that land on one queue run one after the other.  Measured at world size 1 through RCCL
+        # (docs/experiments.md, round 6): partition step 6.54-6.57 ms with 4 queues, 6.46-6.49 with 8 (plain: 6.38); pairs step unchanged.  Read by the
+        # runtime when it initialises, i.e. at the first HIP call of this process -- nothing has made one yet.
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     rows, cols, P = args.rows, args.cols, args.pairs
     K, conv, alig = conf(rows, cols)
     partition = args.mode == "partition"
@@ -1655,6 +1706,9 @@ def main():
             "counters_mean": rep["counters_mean"],
             "gather": gather_info,
             "multi_gpu": multi,
+            "gather_queueing": ({"from_inside_the_call": bool(getattr(w, "inside", False)),
+                                 "host_ms_per_step_inside_the_callback": getattr(w, "cb_s", 0.0) / max(getattr(w, "k", 1), 1) * 1e3,
+                                 "host_ms_per_step_in_the_library_calls": getattr(w, "call_s", 0.0) / max(getattr(w, "k", 1), 1) * 1e3} if (use_dist and not partition) else None),
         }
         if partition:
             out["partition"] = {"accepted_by_closer_thresholds_rank0": rep["accepted_by_closer_thresholds_rank0"], "keyframes_rank0": P,

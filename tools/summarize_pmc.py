@@ -5,6 +5,7 @@ traffic table bench.py reads (profiles/traffic.json).
   tools/summarize_pmc.py <pmc output dir>                                   -> the summary text on stdout (tools/profile_pmc.sh)
   tools/summarize_pmc.py <dir or committed summary .txt> --traffic-json profiles/traffic.json --version r03_v13 [--launch-items 64]
   ... --size-key 960x1280 --pixels 1228800 --launch-items 32 --frame-items 64     -> the table of another frame size, stored under "sizes"
+  ... --mode-key partition --launch-items 64                                      -> the table of another workload (bench.py --mode partition), stored under "modes"
 
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: on gfx950 FETCH_SIZE reports half of the bytes of a wide coalesced read
 (MI355X_MICROARCH.md, HBM section; re-checked in every set of passes on k_probe_read, which streams exactly 2 GiB per launch)."""
@@ -17,7 +18,7 @@ import sys
 from collections import defaultdict
 
 KERNELS = ("k_corr_linearize", "k_stats", "k_unproject_integral", "k_project", "k_strip_count", "k_row_offsets", "k_solve_update",
-           "k_probe_read", "k_probe_copy")
+           "k_match_score", "k_pack_records", "k_probe_read", "k_probe_copy")
 
 
 def short(name):
@@ -117,6 +118,14 @@ def main(argv):
                 old = json.load(open(opts["--traffic-json"]))
             except Exception:
                 old = {}
+        if "--mode-key" in opts:
+            # the same kernels under another workload (e.g. --mode partition: every pair of a launch gathers from the SAME reference cloud, so the
+            # caches serve most of what the algorithmic count charges): beside the pairs table, which stays the top level
+            old.setdefault("modes", {})[opts["--mode-key"]] = t
+            with open(opts["--traffic-json"], "w") as f:
+                json.dump(old, f, indent=1)
+            print("wrote", opts["--traffic-json"], "modes[%s]" % opts["--mode-key"], "version", t["version"], "kernels", sorted(t["kernels"]))
+            return
         if "--size-key" in opts:
             # a table measured at another frame size (e.g. 960x1280: BASELINE configs[4]) goes beside the VGA table, which stays the top level
             old.setdefault("sizes", {})[opts["--size-key"]] = t
@@ -126,6 +135,8 @@ def main(argv):
             return
         if "sizes" in old:
             t["sizes"] = old["sizes"]
+        if "modes" in old:
+            t["modes"] = old["modes"]
         hist = dict(old.get("history", {}))
         if old.get("k_corr_linearize_bytes_per_pair_iteration") and old.get("version", "r02_v11") != t["version"]:
             hist[old.get("version", "r02_v11") + "_k_corr_linearize_bytes_per_pair_iteration"] = old["k_corr_linearize_bytes_per_pair_iteration"]
