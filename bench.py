@@ -660,8 +660,10 @@ class PartitionWorkload:
         if self.P:
             self.converter.computeBatch(self.others, self.other_dev, raw_scale=0.001)
         self.other_dev = None
-        self.cur_dev = torch.from_numpy(current_mm.view(np.int16)).to(dev) if rank == 0 else None
         self.pipeline = not getattr(args, "partition_serial", False)
+        # pipelined: the look-ahead work ROTATES over the ranks (keyframe j is converted, exported and broadcast by rank j % world), so that no rank's step is
+        # longer than the others' by a conversion -- every rank holds the raw `current` frames it will own.  Serial chain: rank 0 does it all.
+        self.cur_dev = torch.from_numpy(current_mm.view(np.int16)).to(dev) if (rank == 0 or self.pipeline) else None
         # rank 0 of a forced one-rank run takes the replica path too (export -> broadcast -> import), so that the byte path is exercised
         self.roundtrip = use_dist and world == 1
         bound = api.Cloud.flatBound(self.N, args.omega_storage, self.N)
@@ -681,7 +683,7 @@ class PartitionWorkload:
                 self.io = api.Context(device=device, max_rows=rows, max_cols=cols, max_batch=1, omega_storage=args.omega_storage)      # imports run here, next to the matches
                 self.rep = [api.Cloud(self.io, self.N) for _ in range(2)]
                 self.flat = [torch.empty(bound, dtype=torch.uint8, device=dev) for _ in range(self.RING)]
-                self.conv_cloud = api.Cloud(self.ctx, self.N) if rank == 0 else None      # what the helper converts into before it exports
+                self.conv_cloud = api.Cloud(self.ctx, self.N)      # what the helper converts into before it exports (on the rank that owns the keyframe)
                 self.side = torch.cuda.Stream(device=dev); self.imp_stream = torch.cuda.Stream(device=dev)
                 self.gstream = [torch.cuda.Stream(device=dev) for _ in range(2)]      # the all-gathers alternate between two streams: step k+1 waits for step k-1's only
                 self.ctrl_send = [torch.zeros(4, dtype=torch.float32).pin_memory() for _ in range(2)]
@@ -716,21 +718,26 @@ class PartitionWorkload:
             cv.computeExportEnd(cv.computeExportBegin(self.rep[0], self.cur_dev))
             self.ticket = cv.computeExportBegin(self.rep[1], self.cur_dev)
             return
+        own = self.owner
         for j in (0, 1, 2):
             n = torch.zeros(1, dtype=torch.int64, device=self.records.device)
-            if self.rank == 0:
+            if self.rank == own(j):
                 w, _ = cv.computeExportEnd(cv.computeExportBegin(self.conv_cloud, self.cur_dev, flat=self.flat[j]))
                 n[0] = w
-            dist.broadcast(n, src=0)
+            dist.broadcast(n, src=own(j))
             self.size[j] = int(n.item())
-        dist.broadcast(self.flat[0][: self.size[0]], src=0)
+        dist.broadcast(self.flat[0][: self.size[0]], src=own(0))
         self.io.wait_stream()
         self.rep[0].importFlat(self.flat[0][: self.size[0]])
         self.flat_bytes = self.size[0]
         with torch.cuda.stream(self.side):
-            self.bw[1] = dist.broadcast(self.flat[1][: self.size[1]], src=0, async_op=True)
-        if self.rank == 0:
+            self.bw[1] = dist.broadcast(self.flat[1][: self.size[1]], src=own(1), async_op=True)
+        if self.rank == own(3):
             self.ticket = cv.computeExportBegin(self.conv_cloud, self.cur_dev, flat=self.flat[3])
+
+    def owner(self, j):
+        """the rank that converts, exports and broadcasts keyframe j"""
+        return j % self.world
 
     def _overlap(self):
         """runs inside step k's match call, after its device work is queued and before it waits"""
@@ -747,25 +754,28 @@ class PartitionWorkload:
             self.gathered = shard.gather_records(self.records2[k % 2], self.world, self.Pmax + 1, force=False)
             self.phase_s["inside_callback"] += time.perf_counter() - tc
             return
-        if self.rank == 0:
-            w, ms = cv.computeExportEnd(self.ticket)                                  # keyframe k+3's flat form is in buffer (k+3) % 4
+        own = self.owner
+        if self.rank == own(k + 3):
+            w, ms = cv.computeExportEnd(self.ticket); self.ticket = None              # keyframe k+3's flat form is in buffer (k+3) % 4 of its owner
             self.rank0_job_ms += ms
-            cs = self.ctrl_send[k % 2]; cs[0] = float(w // 256)                        # its size rides in the control row of this step's all-gather
+            cs = self.ctrl_send[k % 2]; cs[0] = float(w // 256)                        # its size rides in the owner's control row of this step's all-gather
+        if self.rank == own(k + 4):
             self.ticket = cv.computeExportBegin(self.conv_cloud, self.cur_dev, flat=self.flat[(k + 4) % R])      # buffer k % 4: imported during step k-1
+        if self.rank in (own(k + 3), own(k + 4)):
             self.rank0_only_host_s += time.perf_counter() - tc
         if k >= 1:                                                                   # size of keyframe k+2: control row of step k-1's all-gather
             self.ctrl_ev[(k - 1) % 2].synchronize()
             self.size[(k + 2) % R] = int(self.ctrl_host[(k - 1) % 2][0].item()) * 256
         j2 = (k + 2) % R
         with torch.cuda.stream(self.side):                                           # keyframe k+2 travels while keyframe k is matched; only the bytes written
-            self.bw[j2] = dist.broadcast(self.flat[j2][: self.size[j2]], src=0, async_op=True)
+            self.bw[j2] = dist.broadcast(self.flat[j2][: self.size[j2]], src=own(k + 2), async_op=True)
         gs = self.gstream[k % 2]; rec = self.records2[k % 2]
         with torch.cuda.stream(gs):
-            if self.rank == 0:
+            if self.rank == own(k + 3):
                 rec[self.Pmax, :4].copy_(self.ctrl_send[k % 2], non_blocking=True)
             self.ctx.signal_stream(gs)                                               # the gather's stream continues after this call's records are packed
             self.gathered = shard.gather_records(rec, self.world, self.Pmax + 1, force=True)      # the records + one control row per rank
-            self.ctrl_host[k % 2].copy_(self.gathered[self.Pmax, :4], non_blocking=True)   # rank 0's control row: the size of keyframe k+3
+            self.ctrl_host[k % 2].copy_(self.gathered[own(k + 3) * (self.Pmax + 1) + self.Pmax, :4], non_blocking=True)   # its owner's control row: the size of keyframe k+3
             self.ctrl_ev[k % 2].record(gs)
         ti = time.perf_counter()
         j1 = (k + 1) % R
@@ -879,6 +889,7 @@ class PartitionWorkload:
         terr = max(float(np.abs(r["T"][i].reshape(4, 4).T[:3, 3] - synth.pair_pose(PARTITION_POSE0 + k)[:3, 3]).max()) for i, k in enumerate(self.ids)) if P else 0.0
         nst = max(self.steps_done, 1)
         pipe = {"pipelined": bool(self.pipeline), "steps_counted": self.steps_done,
+                "lookahead_rotates_over_ranks": bool(self.pipeline),      # keyframe j is converted / exported / broadcast by rank j % world: rank 0 pays the figures below every world-th step
                 # host time only rank 0 spends per step: collecting the look-ahead job, the control row, starting the next job.  Pipelined: inside the
                 # match call's callback, i.e. while the device works -- not on the step's critical path
                 "rank0_only_host_ms_per_step": self.rank0_only_host_s / nst * 1e3,

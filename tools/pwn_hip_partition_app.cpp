@@ -6,7 +6,7 @@
 //                odometry guess with the z translation zeroed + the depth-agreement score (pwn_matcher_base.cpp:88-183) -- pwn_hip_match_batch_records,
 //                288-byte records written on the device.  Everything else is queued from INSIDE that call (pwn_hip_ctx_set_enqueued_callback: after its
 //                device work is queued, before it waits), on one RCCL stream and a second small context, so that it runs beside the matches:
-//                  rank 0: collect the look-ahead job of keyframe k+3 (its cloud converted and exported into flat buffer (k+3) % 4 by the library's
+//                  the rank that owns keyframe k+3 (j % ranks): collect the look-ahead job of keyframe k+3 (its cloud converted and exported into flat buffer (k+3) % 4 by the library's
 //                          helper thread: pwn_closer.cpp:92-93 _cache->get(current) one keyframe ahead), start the job of keyframe k+4
 //                  ncclBroadcast of keyframe k+2's flat form -- only the bytes written; their count travelled in the control row of step k-1's all-gather
 //                  ncclAllGather of step k's records (ordered behind the call's stream with pwn_hip_ctx_signal_stream) + one control row per rank
@@ -86,13 +86,17 @@ struct Pipeline {
   size_t recFloats() const { return (size_t)(nmax + 1) * PWN_HIP_MATCH_RECORD_FLOATS; }
 };
 static int overlapBody(Pipeline& P) {
-  const int rank = P.rank, k = P.k, R = Pipeline::RING;
-  if (rank == 0) {
+  const int rank = P.rank, k = P.k, R = Pipeline::RING, W = P.world;
+  // the look-ahead work rotates over the ranks: keyframe j is converted, exported and broadcast by rank j % world, so that no rank's step is longer than the
+  // others' by a conversion (a deployment feeds keyframe j's raw frame to that rank)
+  if (rank == (k + 3) % W) {
     float ms = 0.f;
-    const size_t w = P.converter->computeExportEnd(*P.conv, &ms);                    // keyframe k+3's flat form is in buffer (k+3) % 4
+    const size_t w = P.converter->computeExportEnd(*P.conv, &ms);                    // keyframe k+3's flat form is in its owner's buffer (k+3) % 4
     P.jobMs += ms; P.jobPending = false;
-    P.ctrlSend[k % 2][0] = (float)(w / 256);                                         // its size rides in the control row of this step's all-gather
+    P.ctrlSend[k % 2][0] = (float)(w / 256);                                         // its size rides in the owner's control row of this step's all-gather
     HIPCHK_(hipMemcpyAsync(P.rec[k % 2] + (size_t)P.nmax * PWN_HIP_MATCH_RECORD_FLOATS, P.ctrlSend[k % 2], 4 * sizeof(float), hipMemcpyHostToDevice, P.sN));
+  }
+  if (rank == (k + 4) % W) {
     P.converter->computeExportBegin(*P.conv, P.frame, 0.001f, P.rows, P.cols, P.flat[(k + 4) % R], P.bound);      // buffer k % 4: imported during step k-1
     P.jobPending = true;
   }
@@ -101,11 +105,12 @@ static int overlapBody(Pipeline& P) {
     P.size[(k + 2) % R] = (size_t)P.ctrlHost[(k - 1) % 2][0] * 256;
   }
   const int j2 = (k + 2) % R, j1 = (k + 1) % R;
-  NCCLCHK(ncclBroadcast(P.flat[j2], P.flat[j2], P.size[j2], ncclUint8, 0, P.comm, P.sN));      // keyframe k+2 travels while keyframe k is matched
+  NCCLCHK(ncclBroadcast(P.flat[j2], P.flat[j2], P.size[j2], ncclUint8, (k + 2) % W, P.comm, P.sN));      // keyframe k+2 travels from its owner while keyframe k is matched
   HIPCHK_(hipEventRecord(P.evB[j2], P.sN));
   P.ctx->signalStream(P.sN);                                                         // the all-gather runs after this call's records are packed
   NCCLCHK(ncclAllGather(P.rec[k % 2], P.all[k % 2], P.recFloats(), ncclFloat, P.comm, P.sN));
-  HIPCHK_(hipMemcpyAsync(P.ctrlHost[k % 2], P.all[k % 2] + (size_t)P.nmax * PWN_HIP_MATCH_RECORD_FLOATS, 4 * sizeof(float), hipMemcpyDeviceToHost, P.sN));      // rank 0's control row
+  HIPCHK_(hipMemcpyAsync(P.ctrlHost[k % 2], P.all[k % 2] + ((size_t)((k + 3) % W) * (size_t)(P.nmax + 1) + (size_t)P.nmax) * PWN_HIP_MATCH_RECORD_FLOATS, 4 * sizeof(float),
+                         hipMemcpyDeviceToHost, P.sN));                                // the control row of keyframe k+3's owner
   HIPCHK_(hipEventRecord(P.evG[k % 2], P.sN));
   HIPCHK_(hipStreamWaitEvent(P.sImp, P.evB[j1], 0));                                 // keyframe k+1's broadcast (queued during step k-1)
   P.io->waitStream(P.sImp);
@@ -173,7 +178,7 @@ static int runRank(int rank, int world, const std::vector<std::string>& files, c
     std::vector<float> host(recFloats * (size_t)world);
     double msPerStep = 0.0; size_t flatBytes = 0, sentBytes = 0;
     uint16_t* frameDev = nullptr;
-    if (rank == 0) {
+    if (rank == 0 || !serial) {                                // pipelined: every rank owns keyframes (j % world)
       ctx.check(pwn_hip_device_alloc(ctx.handle(), (void**)&frameDev, currentFrame.data.size() * sizeof(uint16_t)));
       ctx.check(pwn_hip_copy(ctx.handle(), frameDev, currentFrame.data.data(), currentFrame.data.size() * sizeof(uint16_t)));
     }
@@ -228,18 +233,18 @@ static int runRank(int rank, int world, const std::vector<std::string>& files, c
       ctx.check(pwn_hip_device_alloc(ctx.handle(), (void**)&sizeDev, sizeof(unsigned long long)));
       for (int j = 0; j < 3; ++j) {
         unsigned long long w = 0;
-        if (rank == 0) { converter.computeExportBegin(conv, frameDev, 0.001f, rows, cols, P.flat[j], bound); w = converter.computeExportEnd(conv); }
+        if (rank == j % world) { converter.computeExportBegin(conv, frameDev, 0.001f, rows, cols, P.flat[j], bound); w = converter.computeExportEnd(conv); }
         ctx.check(pwn_hip_copy(ctx.handle(), sizeDev, &w, sizeof(w)));
-        NCCLCHK(ncclBroadcast(sizeDev, sizeDev, 1, ncclUint64, 0, comm, P.sN));
+        NCCLCHK(ncclBroadcast(sizeDev, sizeDev, 1, ncclUint64, j % world, comm, P.sN));
         HIPCHK_(hipStreamSynchronize(P.sN));
         ctx.check(pwn_hip_copy(ctx.handle(), &w, sizeDev, sizeof(w)));
         P.size[j] = (size_t)w;
       }
       NCCLCHK(ncclBroadcast(P.flat[0], P.flat[0], P.size[0], ncclUint8, 0, comm, P.sN));
       io.waitStream(P.sN); rep0.importFlat(P.flat[0], P.size[0]);
-      NCCLCHK(ncclBroadcast(P.flat[1], P.flat[1], P.size[1], ncclUint8, 0, comm, P.sN));
+      NCCLCHK(ncclBroadcast(P.flat[1], P.flat[1], P.size[1], ncclUint8, 1 % world, comm, P.sN));
       HIPCHK_(hipEventRecord(P.evB[1], P.sN));
-      if (rank == 0) { converter.computeExportBegin(conv, frameDev, 0.001f, rows, cols, P.flat[3], bound); P.jobPending = true; }
+      if (rank == 3 % world) { converter.computeExportBegin(conv, frameDev, 0.001f, rows, cols, P.flat[3], bound); P.jobPending = true; }
       std::vector<Cloud*> from[2] = { std::vector<Cloud*>((size_t)n, &rep0), std::vector<Cloud*>((size_t)n, &rep1) };
       ctx.setEnqueuedCallback(overlap, &P);
       for (int s = 0; s < steps + 1 && !P.rc; ++s) {           // step 0 = warm-up
