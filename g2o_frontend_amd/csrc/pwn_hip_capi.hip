@@ -39,7 +39,9 @@ struct EventRec { std::string stage; hipEvent_t a, b; };
 // pwn_hip_convert_scaled_begin / _end: a helper context (streams and workspaces of its own) driven by a helper thread, so that a frame
 // is converted next to whatever the caller runs on the context meanwhile
 struct AsyncConvert {
-  pwn_hip_ctx* helper = nullptr;
+  pwn_hip_ctx* helper = nullptr;           // default-priority streams: the tracker's look-ahead (a frame converted beside ONE alignment's short kernels)
+  pwn_hip_ctx* helper_hi = nullptr;        // high-priority streams, created on first use: a frame converted beside a BATCH call (pwn_hip_convert_export_begin)
+  pwn_hip_ctx* job_ctx = nullptr;          // the one the current job runs on
   std::thread worker;
   std::mutex m;
   std::condition_variable cv;
@@ -834,9 +836,10 @@ void pwn_hip_default_aligner_params(pwn_hip_aligner_params* p) {
   std::memcpy(p->initial_guess, I.m, sizeof(I.m));
 }
 
-// high_priority: the streams of a look-ahead helper context (AsyncConvert).  Its one-frame jobs run beside a batch whose streams hold hundreds of
-// queued launches; on the default priority a stream of the helper can share a hardware queue with one of those and is then served when that
-// queue has drained -- at the end of the batch instead of beside it.
+// high_priority: the streams of the look-ahead helper context that works beside BATCH calls (AsyncConvert::helper_hi).  Its one-frame jobs run beside
+// streams that hold hundreds of queued launches; on the default priority a stream of the helper can share a hardware queue with one of those and is
+// then served when that queue has drained -- at the end of the batch instead of beside it.  (Only for a context whose streams do not wait on other streams' events: a
+// high-priority context used for the partition step's imports, which wait for a broadcast, made the whole step 8-13 % slower -- docs/experiments.md, round 6.)
 static int ctx_create(pwn_hip_ctx** out, int device, int max_rows, int max_cols, int max_batch, bool high_priority);
 int pwn_hip_ctx_create(pwn_hip_ctx** out, int device, int max_rows, int max_cols, int max_batch) { return ctx_create(out, device, max_rows, max_cols, max_batch, false); }
 static hipError_t make_stream(hipStream_t* s, bool high_priority) {
@@ -913,6 +916,7 @@ int pwn_hip_ctx_destroy(pwn_hip_ctx* ctx) {
     a->cv.notify_all();
     if (a->worker.joinable()) a->worker.join();
     if (a->helper) pwn_hip_ctx_destroy(a->helper);
+    if (a->helper_hi) pwn_hip_ctx_destroy(a->helper_hi);
     delete a; ctx->async = nullptr;
   }
   if (ctx->copy_stream) (void)hipStreamSynchronize(ctx->copy_stream);      // pwn_hip_copy_async transfers still in flight
@@ -1550,16 +1554,16 @@ static void async_convert_loop(AsyncConvert* a, int device) {
     int rc;
     if (a->raw) {
       const uint16_t* frames[1] = { a->raw }; pwn_hip_cloud* clouds[1] = { a->cloud };
-      rc = convert_batch_impl<uint16_t>(a->helper, &a->p, frames, a->raw_scale, 1, a->rows, a->cols, clouds, 0);
+      rc = convert_batch_impl<uint16_t>(a->job_ctx, &a->p, frames, a->raw_scale, 1, a->rows, a->cols, clouds, 0);
     } else {
-      rc = pwn_hip_convert_scaled(a->helper, &a->p, a->depth, a->rows, a->cols, a->step, a->max_depth_cov, a->cloud);
+      rc = pwn_hip_convert_scaled(a->job_ctx, &a->p, a->depth, a->rows, a->cols, a->step, a->max_depth_cov, a->cloud);
     }
     size_t written = 0;
-    if (rc == PWN_HIP_OK && a->flat_dst) rc = pwn_hip_cloud_export(a->helper, a->cloud, a->flat_dst, a->flat_bytes, &written);
+    if (rc == PWN_HIP_OK && a->flat_dst) rc = pwn_hip_cloud_export(a->job_ctx, a->cloud, a->flat_dst, a->flat_bytes, &written);
     const float job_ms = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_begin).count();
     lk.lock();
     a->flat_written = written; a->job_ms = job_ms;
-    a->rc = rc; a->err = rc == PWN_HIP_OK ? std::string() : a->helper->err;
+    a->rc = rc; a->err = rc == PWN_HIP_OK ? std::string() : a->job_ctx->err;
     a->has_job = false; a->done = true;
     lk.unlock();
     a->cv.notify_all();
@@ -1584,6 +1588,8 @@ int pwn_hip_convert_export_begin(pwn_hip_ctx* ctx, const pwn_hip_converter_param
   return async_convert_begin(ctx, p, nullptr, raw_frame, depth_scale, rows, cols, 1, 0.f, cloud, flat_dst, flat_bytes);
 }
 int pwn_hip_convert_export_end(pwn_hip_ctx* ctx, pwn_hip_cloud* cloud, size_t* written, float* job_ms) {
+  if (written) *written = 0;
+  if (job_ms) *job_ms = 0.f;
   const int rc = pwn_hip_convert_end(ctx, cloud);
   if (ctx && ctx->async) {
     if (written) *written = rc == PWN_HIP_OK ? ctx->async->flat_written : 0;
@@ -1597,7 +1603,7 @@ static int async_convert_begin(pwn_hip_ctx* ctx, const pwn_hip_converter_params*
   if (rows / step <= 0 || cols / step <= 0) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "scaled image has zero size");
   if (!ctx->async) {
     AsyncConvert* a = new AsyncConvert();
-    if (int rc = ctx_create(&a->helper, ctx->device, ctx->max_rows, ctx->max_cols, 1, true)) { const std::string m = g_err; delete a; return fail(ctx, rc, "helper context: " + m); }
+    if (int rc = ctx_create(&a->helper, ctx->device, ctx->max_rows, ctx->max_cols, 1, false)) { const std::string m = g_err; delete a; return fail(ctx, rc, "helper context: " + m); }
     a->worker = std::thread(async_convert_loop, a, ctx->device);
     ctx->async = a;
   }
@@ -1605,6 +1611,13 @@ static int async_convert_begin(pwn_hip_ctx* ctx, const pwn_hip_converter_params*
   {
     std::unique_lock<std::mutex> lk(a->m);
     if (a->cloud || !a->done) return fail(ctx, PWN_HIP_ERR_INVALID_ARGUMENT, "a conversion is already in flight on this context (pwn_hip_convert_end first)");
+    // Which helper: the raw-frame form runs beside a batch whose streams hold hundreds of queued launches -- on default priority the one-frame job is
+    // served when a hardware queue it shares with the batch has drained (5.8 ms of wall time instead of 0.5); beside a single alignment (the tracker's
+    // look-ahead) high priority is the wrong way round: it delays the alignment's short dependent kernels (3 070 -> 2 300 frames/s measured).
+    if (raw && !a->helper_hi) {
+      if (int rc = ctx_create(&a->helper_hi, ctx->device, ctx->max_rows, ctx->max_cols, 1, true)) return fail(ctx, rc, "helper context: " + g_err);
+    }
+    a->job_ctx = raw ? a->helper_hi : a->helper;
     // the caller's copies (pwn_hip_copy_async into a device frame) must have landed before the helper's stream reads the frame
     if (int rc = absorb_copies(ctx)) return rc;
     // a device frame the context's own stream may still be writing (pwn_hip_copy_async above): wait for it.  The raw-frame form does not wait --

@@ -368,3 +368,39 @@ def test_single_point_projector_forms_against_the_numpy_model():
     for r in range(12):
         for c in range(16):
             assert proj.projectInterval(c, r, depth[r, c], 0.1) == int(itv[r, c]), (r, c)
+
+
+def test_flat_cloud_buffers_are_checked_before_they_reach_the_library():
+    """Cloud.exportFlat / importFlat hand raw pointers to kernels on the context's device (advisor finding, round 5): a strided view, another
+    element type or a read-only destination is refused in Python, like the records buffers are."""
+    from types import SimpleNamespace
+    from g2o_frontend_amd import api
+    ctx = SimpleNamespace(device=0)
+    ok = np.zeros(1024, np.uint8)
+    api._check_flat(ok, ctx, writable=True)
+    ro = np.zeros(1024, np.uint8); ro.setflags(write=False)
+    api._check_flat(ro, ctx, writable=False)                       # a read-only source is fine
+    for bad in (ro, np.zeros(1024, np.float32), np.zeros((64, 64), np.uint8)[:, ::2]):
+        with pytest.raises(ValueError):
+            api._check_flat(bad, ctx, writable=True)
+    with pytest.raises(TypeError):
+        api._check_flat([0] * 16, ctx, writable=False)
+    import torch
+    t = torch.zeros(1024, dtype=torch.uint8)
+    api._check_flat(t, ctx, writable=True)                         # a host tensor
+    with pytest.raises(ValueError):
+        api._check_flat(torch.zeros(1024, dtype=torch.float32), ctx, writable=True)
+    with pytest.raises(ValueError):
+        api._check_flat(torch.zeros(64, 64, dtype=torch.uint8)[:, ::2], ctx, writable=True)
+
+
+def test_library_default_storage_is_documented_consistently():
+    """the header, the Python mirror and the bench agree on the default storage of the point information matrices (sym6 since round 6)"""
+    from g2o_frontend_amd import api
+    import bench
+    h = open(os.path.join(ROOT, "include", "pwn_hip.h")).read()
+    assert "PWN_HIP_OMEGA_SYM6 (the default since round 6)" in h
+    assert api.Context.DEFAULT_OMEGA_STORAGE == "sym6"
+    assert bench.parse([]).omega_storage == "sym6"
+    src = open(os.path.join(ROOT, "g2o_frontend_amd", "csrc", "pwn_hip_capi.hip")).read()
+    assert "int omega_sym = 1;" in src
