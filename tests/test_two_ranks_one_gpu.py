@@ -58,3 +58,18 @@ def test_partition_mode_two_ranks_on_one_device(serial):
         assert p["broadcast_bytes_per_step"] == p["flat_cloud_bytes"]
         assert p["pipeline"]["rank0_lookahead_job_ms_per_step"] > 0
     assert line["multi_gpu"]["collectives_alone"]["broadcast_ms"] > 0
+
+
+def test_partition_mode_three_ranks_rotate_the_look_ahead():
+    """three ranks (not a divisor of the ring of four flat buffers): keyframe j is converted, exported and broadcast by rank j % 3, every rank imports
+    every keyframe; the records still assemble to the committed digests"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "PWN_BENCH_FORCE_DIST")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--one-device", "--mode", "partition", "--pairs", "32", "--steps", "5", "--warmup", "2",
+                          "--no-cpu-baseline", "--no-latency", "--no-extras"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    c = line["gather"]["records_vs_single_gpu_run"]
+    assert line["n_gpus"] == 3 and line["gather"]["records"] == 96 and c["checked"] == 96 and c["equal"] is True and c["file_is_for_these_kernels"] is True, c
+    p = line["partition"]
+    assert p["pipelined"] is True and p["pipeline"]["lookahead_rotates_over_ranks"] is True and p["pipeline"]["rank0_lookahead_job_ms_per_step"] > 0
