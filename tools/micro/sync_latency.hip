@@ -24,19 +24,19 @@ int main() {
   std::vector<double> a, b, c, d;
   for (int i = 0; i < reps + 20; ++i) {
     double t0 = now_us();
-    (void)0; hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, cycles, (volatile int*)nullptr, 0);
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, cycles, (volatile int*)nullptr, 0);
     hipStreamSynchronize(s);
     if (i >= 20) a.push_back(now_us() - t0);
     t0 = now_us();
-    (void)0; hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, cycles, (volatile int*)nullptr, 0);
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, cycles, (volatile int*)nullptr, 0);
     hipEventRecord(ev, s); hipEventSynchronize(ev);
     if (i >= 20) b.push_back(now_us() - t0);
     t0 = now_us();
-    (void)0; hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, cycles, (volatile int*)nullptr, 0);
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, cycles, (volatile int*)nullptr, 0);
     hipEventRecord(ev, s); while (hipEventQuery(ev) == hipErrorNotReady) { }
     if (i >= 20) c.push_back(now_us() - t0);
     t0 = now_us();
-    (void)0; hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, cycles, (volatile int*)flag, i + 1);
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, s, cycles, (volatile int*)flag, i + 1);
     while (*(volatile int*)flag != i + 1) { }
     if (i >= 20) d.push_back(now_us() - t0);
     hipStreamSynchronize(s);
