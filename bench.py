@@ -613,6 +613,83 @@ def partition_guesses(ids, t_noise=0.01, q_noise=0.004):
     return out
 
 
+def pp_owner(j, world):
+    """pipelined processPartition: the rank that converts, exports and broadcasts keyframe j"""
+    return j % world
+
+
+def pp_ctrl_row(owner, rows_per_rank):
+    """row of the gathered record tensor that holds `owner`'s control row (the last row of its block)"""
+    return owner * rows_per_rank + rows_per_rank - 1
+
+
+def simulate_partition_pipeline_cpu(rank, world, steps, dist):
+    """The bookkeeping of PartitionWorkload's pipelined step with nothing but host tensors and gloo (tests: world 3 and 8 on the CPU) and flat clouds whose
+    SIZE DIFFERS from keyframe to keyframe -- which the GPU benchmark, re-using one `current` frame, never exercises: the ring of four flat buffers, the owner
+    rotation, the size that travels one step ahead in the owner's control row, the broadcast of exactly the bytes written, the import into the replica the
+    NEXT step matches against.  Returns True when every step on this rank matched against the keyframe it should have, with the bytes its owner made."""
+    import torch
+    R, rows = 4, 5                                             # ring; rows per rank in the record tensor (4 records + the control row)
+
+    def payload(j):                                            # the flat form of keyframe j: a multiple of 256 bytes, another length for every j
+        n = 256 * (40 + (j * 37) % 23)
+        return ((np.arange(n, dtype=np.uint64) * 2654435761 + 97 * j) % 251).astype(np.uint8)
+    bound = 256 * 64
+    flat = [torch.zeros(bound, dtype=torch.uint8) for _ in range(R)]
+    size = [0] * R
+    rep_key = [-1, -1]                                         # which keyframe each replica holds
+    ok = True
+
+    def convert_export(j):                                     # the look-ahead job of keyframe j on its owner
+        p = payload(j)
+        flat[j % R][: p.size] = torch.from_numpy(p)
+        return int(p.size)
+
+    def bcast(t, src):
+        if world > 1:
+            dist.broadcast(t, src=src)
+
+    def import_(j):                                            # what arrived must be what keyframe j's owner made, byte for byte
+        nonlocal ok
+        got = flat[j % R][: size[j % R]].numpy()
+        ok = ok and size[j % R] == payload(j).size and np.array_equal(got, payload(j))
+        rep_key[j % 2] = j
+    # prime
+    for j in (0, 1, 2):
+        n = torch.zeros(1, dtype=torch.int64)
+        if rank == pp_owner(j, world):
+            n[0] = convert_export(j)
+        bcast(n, pp_owner(j, world)); size[j] = int(n.item())
+    bcast(flat[0][: size[0]], pp_owner(0, world)); import_(0)
+    bcast(flat[1][: size[1]], pp_owner(1, world))               # (asynchronous on the GPU: imported inside step 0's call)
+    pending = None
+    if rank == pp_owner(3, world):
+        pending = (3, convert_export(3))
+    ctrl_prev = None
+    for k in range(steps):
+        ok = ok and rep_key[k % 2] == k                         # the step's matches run against keyframe k
+        rec = torch.full((rows, 72), -1.0)
+        rec[: rows - 1, 19] = torch.arange(rows - 1, dtype=torch.float32) + rank * (rows - 1)      # four records of this rank
+        # ---- what _overlap() does inside the match call
+        if rank == pp_owner(k + 3, world):
+            ok = ok and pending is not None and pending[0] == k + 3
+            rec[rows - 1, 0] = float(pending[1] // 256); pending = None
+        if rank == pp_owner(k + 4, world):
+            pending = (k + 4, convert_export(k + 4))            # buffer k % 4: keyframe k was imported during step k-1
+        if k >= 1:
+            size[(k + 2) % R] = ctrl_prev
+        bcast(flat[(k + 2) % R][: size[(k + 2) % R]], pp_owner(k + 2, world))
+        g = torch.empty((world * rows, 72))
+        if world > 1:
+            dist.all_gather(list(g.view(world, rows, 72).unbind(0)), rec)
+        else:
+            g = rec
+        ctrl_prev = int(g[pp_ctrl_row(pp_owner(k + 3, world), rows), 0].item()) * 256      # the size of keyframe k+3, for step k+1's broadcast
+        ok = ok and sorted(int(x) for x in g[:, 19].tolist() if x >= 0) == list(range(world * (rows - 1)))
+        import_(k + 1)
+    return bool(ok)
+
+
 class PartitionWorkload:
     """PwnCloser::processPartition (pwn_tracker/pwn_closer.cpp:85-111) sharded over the GPUs of a node (SURVEY.md 8(e), Partitioning): the clouds of the
     other partition stay on the GPU that converted them (PwnCache: pwn_tracker_cache.cpp:24-51), the cloud of `current` is converted on rank 0 and
@@ -737,7 +814,7 @@ class PartitionWorkload:
 
     def owner(self, j):
         """the rank that converts, exports and broadcasts keyframe j"""
-        return j % self.world
+        return pp_owner(j, self.world)
 
     def _overlap(self):
         """runs inside step k's match call, after its device work is queued and before it waits"""
@@ -775,7 +852,7 @@ class PartitionWorkload:
                 rec[self.Pmax, :4].copy_(self.ctrl_send[k % 2], non_blocking=True)
             self.ctx.signal_stream(gs)                                               # the gather's stream continues after this call's records are packed
             self.gathered = shard.gather_records(rec, self.world, self.Pmax + 1, force=True)      # the records + one control row per rank
-            self.ctrl_host[k % 2].copy_(self.gathered[own(k + 3) * (self.Pmax + 1) + self.Pmax, :4], non_blocking=True)   # its owner's control row: the size of keyframe k+3
+            self.ctrl_host[k % 2].copy_(self.gathered[pp_ctrl_row(own(k + 3), self.Pmax + 1), :4], non_blocking=True)   # its owner's control row: the size of keyframe k+3
             self.ctrl_ev[k % 2].record(gs)
         ti = time.perf_counter()
         j1 = (k + 1) % R
@@ -1349,7 +1426,8 @@ def dry_run_cpu(args, rank, world):
         flat = torch.from_numpy(pattern.copy() if rank == 0 else np.zeros(nbytes, np.uint8))
         if world > 1:
             dist.broadcast(flat, src=0)
-        ok = torch.tensor([1.0 if np.array_equal(flat.numpy(), pattern) else 0.0], dtype=torch.float64)
+        pipe = simulate_partition_pipeline_cpu(rank, world, 11, dist)      # the pipelined step's bookkeeping with flat clouds of varying size
+        ok = torch.tensor([1.0 if (np.array_equal(flat.numpy(), pattern) and pipe) else 0.0], dtype=torch.float64)
         if world > 1:
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         flat_ok = bool(ok.item() == 1.0)

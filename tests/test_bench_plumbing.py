@@ -192,10 +192,22 @@ def test_partition_mode_byte_plumbing_world_2_and_8_gloo():
                              capture_output=True, text=True, timeout=300, env=dict(os.environ, PWN_BENCH_NO_AFFINITY="1"))
         assert out.returncode == 0, out.stderr[-1500:]
         return json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
-    one, two, eight = run(1, 24), run(2, 24), run(8, 24)
-    for r, n in ((one, 1), (two, 2), (eight, 8)):
+    one, two, three, eight = run(1, 24), run(2, 24), run(3, 24), run(8, 24)
+    # flat_cloud_broadcast_ok also covers bench.simulate_partition_pipeline_cpu: the pipelined step's bookkeeping (ring of four flat buffers, owner rotation
+    # j % world, sizes one step ahead in the owner's control row, import into the replica the next step matches against) with flat clouds of VARYING size,
+    # eleven steps, every arrived keyframe compared byte for byte with what its owner made -- at world 3 (no divisor of the ring) and 8
+    for r, n in ((one, 1), (two, 2), (three, 3), (eight, 8)):
         assert r["mode"] == "partition" and r["n_gpus"] == n and r["records"] == 24 and r["records_ok"] is True and r["flat_cloud_broadcast_ok"] is True
-    assert one["records_crc_all"] == two["records_crc_all"] == eight["records_crc_all"]
+    assert one["records_crc_all"] == two["records_crc_all"] == three["records_crc_all"] == eight["records_crc_all"]
+
+
+def test_pipeline_simulation_notices_a_wrong_protocol(monkeypatch):
+    """the CPU simulation is not vacuous: with the size read from the wrong row it reports failure"""
+    sys.path.insert(0, ROOT)
+    import bench
+    assert bench.simulate_partition_pipeline_cpu(0, 1, 9, None) is True
+    monkeypatch.setattr(bench, "pp_ctrl_row", lambda owner, rows: 0)
+    assert bench.simulate_partition_pipeline_cpu(0, 1, 9, None) is False
 
 
 def test_host_cpu_info_names_what_cores_means():
